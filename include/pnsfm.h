@@ -1,0 +1,148 @@
+/* pnsfm.h -- C ABI of libpnsfm_hip.so: the MI355X (gfx950) kernels behind the PackNet-SfM
+ * data-parallel training hot path (PackNet01 depth network + multi-view photometric loss).
+ *
+ * The reference (TRI-ML/packnet-sfm, /root/reference) has no FFI of its own: every op it
+ * runs is a torch.nn / torch.nn.functional call.  Each entry point below therefore names
+ * the reference *call site* (file:line under /root/reference) whose arithmetic it replaces.
+ * The Python modules in packnet-sfm_amd/packnet_sfm/ bind these with ctypes and re-expose
+ * them behind the reference's own module API (PackNet01, MultiViewPhotometricLoss, ...).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (unless typed otherwise), NCHW;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing syncs;
+ *   - outputs are caller-allocated; the library never allocates device memory;
+ *   - return value: 0 on success, non-zero on error (pnsfm_last_error() has the message).
+ */
+#ifndef PNSFM_H
+#define PNSFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pnsfm_version(void);
+const char* pnsfm_last_error(void);
+/* "gfx950" for the product build, "emu" for the host-emulated test build (tests/emu). */
+const char* pnsfm_build_target(void);
+
+/* ---- 2-D convolution (stride 1, zero pad k/2) as fp32-MFMA implicit GEMM -------------------
+ * replaces nn.Conv2d + nn.ConstantPad2d in Conv2D/ResidualConv/InvDepth/Pack/Unpack blocks:
+ *   packnet_sfm/networks/layers/packnet/layers01.py:28-36, :57-60, :115-121, :235-246, :274-281
+ * Weights are consumed in a packed layout [k*k][KP][MP] (M = output channel fastest) produced by
+ * pnsfm_conv2d_pack_weights from the reference layout [Cout][Cin][k][k] (state-dict contract,
+ * packnet_sfm/utils/load.py:114-163).  wp_fwd is used by _forward, wp_bwd by _backward_data. */
+size_t pnsfm_conv2d_packed_elems_fwd(int Cin, int Cout, int ks);
+size_t pnsfm_conv2d_packed_elems_bwd(int Cin, int Cout, int ks);
+int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd /*nullable*/, float* wp_bwd /*nullable*/,
+                              int Cin, int Cout, int ks, void* stream);
+int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias /*nullable*/, float* y,
+                         int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
+                               int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* dw in the reference layout [Cout][Cin][k][k]; dbias [Cout] (nullable). Both are overwritten. */
+int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
+                                 int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+
+/* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
+ * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the
+ * residual form `activ(normalize(x_out + shortcut))`: layers01.py:61-62,72.
+ * act: 0 = identity, 1 = ELU(alpha=1), 2 = ReLU (PoseNet, networks/pose/PoseNet.py:28-34).
+ * stats_ws: double[2*B*G] scratch; mean/rstd: float[B*G] saved for backward. */
+int pnsfm_groupnorm_act_forward(const float* x, const float* res /*nullable*/, const float* gamma,
+                                const float* beta, float* y, float* mean, float* rstd, double* stats_ws,
+                                int B, int C, int HW, int G, float eps, int act, void* stream);
+/* red_ws: double[2*B*C] scratch. dx is the gradient w.r.t. x (and, identically, w.r.t. res). */
+int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* res /*nullable*/,
+                                 const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                 float* dx, float* dgamma, float* dbeta, double* red_ws,
+                                 int B, int C, int HW, int G, int act, void* stream);
+
+/* ---- packing / unpacking data movement ------------------------------------------------------
+ * space_to_depth == `packing(x, r=2)` layers01.py:126-148 (== F.pixel_unshuffle):
+ *   y[b][4c+2i+j][h][w] = x[b][c][2h+i][2w+j];  x:[B,C,H,W] -> y:[B,4C,H/2,W/2]
+ * depth_to_space == nn.PixelShuffle(2) layers01.py:275,285:  x:[B,4C,H,W] -> y:[B,C,2H,2W]
+ * Each is the other's backward. */
+int pnsfm_space_to_depth(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, void* stream);
+
+/* ---- Conv3d(1 -> 8, 3x3x3, padding 1) over the (channel, y, x) volume ----------------------
+ * replaces self.conv3d in PackLayerConv3d / UnpackLayerConv3d: layers01.py:236-237,241-245,
+ * :276-277,280-284.  p:[B,D,H,W] (the unsqueezed single 3-D feature), out:[B,8*D,H,W] with
+ * channel f*D+d (the `.view(b, c*d, h, w)` at :244-245).  w3:[8][27] (= [8,1,3,3,3]), b3:[8]. */
+int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, float* out,
+                              int B, int D, int H, int W, void* stream);
+int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp,
+                                    int B, int D, int H, int W, void* stream);
+/* dw3:[8*27], db3:[8]; overwritten. ws: double[8*28] scratch. */
+int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws,
+                                      int B, int D, int H, int W, void* stream);
+
+/* ---- InvDepth activation: y = sigmoid(x) / min_depth  (layers01.py:119-122) --------------- */
+int pnsfm_invdepth_act_forward(const float* x, float* y, size_t n, float min_depth, void* stream);
+int pnsfm_invdepth_act_backward(const float* dy, const float* y, float* dx, size_t n, float min_depth,
+                                void* stream);
+
+/* ---- view synthesis: inv2depth -> Camera.reconstruct -> Camera.project -> grid_sample ------
+ * replaces MultiViewPhotometricLoss.warp_ref_image for ONE scale and J context images:
+ *   losses/multiview_photometric_loss.py:127-165, utils/depth.py:103-120 (inv2depth),
+ *   geometry/camera.py:112-148 (reconstruct), :150-191 (project),
+ *   geometry/camera_utils.py:27-59 (view_synthesis: bilinear, zeros, align_corners=True).
+ * inv_depth:[B,1,H,W]; ref:[J,B,3,H,W]; K, refK:[B,3,3] already scaled to this resolution;
+ * T:[J,B,4,4] target->context rigid transforms (Pose.mat); warped:[J,B,3,H,W]. */
+int pnsfm_view_synthesis_forward(const float* inv_depth, const float* ref, const float* K, const float* refK,
+                                 const float* T, float* warped, int J, int B, int H, int W, void* stream);
+/* d_inv_depth:[B,1,H,W] (sum over J, overwritten); dT:[J,B,4,4] (rows 0..2 filled, row 3 zero).
+ * ws: double[J*B*12] scratch (fp64 accumulation of the pose gradient). */
+int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth, const float* ref,
+                                  const float* K, const float* refK, const float* T,
+                                  float* d_inv_depth, float* dT, double* ws, int J, int B, int H, int W, void* stream);
+
+/* ---- photometric loss of one scale: SSIM + L1, automask, min/mean reduce -------------------
+ * replaces SSIM() :14-53, MultiViewPhotometricLoss.SSIM :169-186, calc_photometric_loss :188-223
+ * (clip_loss == 0 only) and the per-scale body of reduce_photometric_loss :225-253.
+ * Candidates per pixel, in the reference's order (:321-334): warped[0], ref[0], warped[1], ref[1], ...
+ * (ref[j] entries only when automask != 0).  reduce_op: 0 = 'min', 1 = 'mean'.
+ * loss_sum: double[1], receives sum over pixels of the reduced per-pixel loss (caller divides by B*H*W);
+ * argmin: uint8[B*H*W] (candidate index chosen per pixel; written for reduce_op==0). */
+int pnsfm_photometric_forward(const float* warped, const float* ref, const float* target,
+                              double* loss_sum, uint8_t* argmin, int J, int B, int H, int W,
+                              float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
+/* d_warped:[J,B,3,H,W] = grad_scale * d(loss_sum)/d(warped), overwritten. */
+int pnsfm_photometric_backward(const float* warped, const float* target, const uint8_t* argmin,
+                               float* d_warped, float grad_scale, int J, int B, int H, int W,
+                               float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
+
+/* ---- edge-aware smoothness of one scale ------------------------------------------------------
+ * replaces calc_smoothness utils/depth.py:165-198 (after inv_depths_normalize :146-162) with
+ * gradient_x/y utils/image.py:85-113, and the |.|.mean() of calc_smoothness_loss
+ * multiview_photometric_loss.py:276-278.  inv_norm:[B,1,H,W] mean-normalised inverse depth,
+ * image:[B,3,H,W].  sums: double[2] = { sum |Sx|, sum |Sy| }. */
+int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums,
+                             int B, int H, int W, void* stream);
+/* d_inv_norm = gx * d(sum|Sx|)/d(inv_norm) + gy * d(sum|Sy|)/d(inv_norm), overwritten. */
+int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* d_inv_norm,
+                              float gx, float gy, int B, int H, int W, void* stream);
+
+/* ---- Adam over a flat fp32 parameter buffer (torch.optim.Adam semantics, no amsgrad) -------
+ * replaces the optimizer.step() of models/model_wrapper.py:128-149 / trainers/horovod_trainer.py:93
+ * for one parameter group.  grad_scale multiplies the gradient first (1/world_size after a
+ * sum-all-reduce).  step is the 1-based step count used for bias correction. */
+int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                    int step, void* stream);
+
+/* ---- live timing of the dominant kernels (used by bench.py's roofline block) ---------------
+ * When enabled, every launch of kind k is bracketed by hipEvents on its own stream.
+ * kinds: 0 = conv2d forward/backward-data MFMA kernel, 1 = conv2d backward-weight MFMA kernel.
+ * collect() synchronises the recorded events and returns totals since the last reset. */
+int pnsfm_prof_enable(int on);
+int pnsfm_prof_reset(void);
+int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNSFM_H */

@@ -1,0 +1,48 @@
+"""TEST INFRASTRUCTURE (this container only): make the reference's hot-path modules importable from
+/root/reference without copying them.  Stubs the third-party modules the image lacks (cv2, torchvision,
+yacs, termcolor), patches matplotlib.cm.get_cmap (removed in matplotlib>=3.9, used at utils/depth.py:6) and
+works around `ref_image.get_device()` == -1 on CPU (losses/multiview_photometric_loss.py:150,156-157).
+Recipe from SURVEY.md Appendix C.  Nothing here runs on the GPU box (no /root/reference there)."""
+import os
+import sys
+import types
+
+REFERENCE = '/root/reference'
+
+
+def install():
+    if not os.path.isdir(REFERENCE):
+        raise RuntimeError('reference checkout not present at %s' % REFERENCE)
+    import torch
+    import matplotlib
+    import matplotlib.cm as cm
+
+    def _mod(n):
+        m = types.ModuleType(n)
+        sys.modules[n] = m
+        return m
+
+    if 'cv2' not in sys.modules:
+        _mod('cv2')
+    if 'torchvision' not in sys.modules:
+        tv = _mod('torchvision')
+        tv.transforms = _mod('torchvision.transforms')
+    if 'yacs' not in sys.modules:
+        y = _mod('yacs')
+        y.config = _mod('yacs.config')
+        y.config.CfgNode = type('CfgNode', (dict,), {})
+    if 'termcolor' not in sys.modules:
+        _mod('termcolor').colored = lambda s, *a, **k: s
+    if not hasattr(cm, 'get_cmap'):
+        cm.get_cmap = lambda n: matplotlib.colormaps[n]
+    if not getattr(torch.Tensor.get_device, '_pnsfm_patched', False):
+        _gd = torch.Tensor.get_device
+
+        def get_device(self):
+            d = _gd(self)
+            return self.device if d < 0 else d
+        get_device._pnsfm_patched = True
+        torch.Tensor.get_device = get_device
+    sys.dont_write_bytecode = True
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)

@@ -1,0 +1,296 @@
+"""TEST INFRASTRUCTURE (this container only): pin oracle/packnet_oracle.py against the reference's own modules
+imported from /root/reference, and (re)generate the golden vectors committed under tests/golden/.
+
+    python oracle/pin_against_reference.py            # checks + writes tests/golden/*.pt
+
+The reference ships no tests or golden vectors, so the reference *code* run here on CPU fp32 is
+the only anchor.  Every case below (a) runs the reference module, (b) runs the oracle restatement on the same
+seeded inputs/weights, (c) asserts they agree to fp32 round-off, (d) stores inputs + reference outputs (and
+reference gradients) as a small fixture.  Tests then check the oracle (CPU) and the HIP kernels (GPU) against
+those fixtures without needing /root/reference.
+"""
+import os
+import random
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..'))
+sys.path.insert(0, ROOT)
+from oracle import _refstubs  # noqa: E402
+_refstubs.install()
+from oracle import packnet_oracle as O  # noqa: E402
+
+from packnet_sfm.networks.layers.packnet import layers01 as R  # noqa: E402  (reference)
+from packnet_sfm.networks.depth.PackNet01 import PackNet01 as RefPackNet01  # noqa: E402
+from packnet_sfm.networks.pose.PoseNet import PoseNet as RefPoseNet  # noqa: E402
+from packnet_sfm.losses.multiview_photometric_loss import MultiViewPhotometricLoss as RefLoss  # noqa: E402
+from packnet_sfm.geometry.pose import Pose as RefPose  # noqa: E402
+from packnet_sfm.models.SelfSupModel import SelfSupModel as RefSelfSup  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+torch.set_num_threads(8)
+
+
+def close(a, b, tol, what):
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-30
+    assert err <= tol * max(ref, 1.0) or err / ref <= tol, '%s: max err %.3e (ref max %.3e)' % (what, err, ref)
+    return err / ref
+
+
+def smooth_images(B, H, W, gen, n=3, shift=2.0):
+    """KITTI-ish synthetic frames: low-res noise upsampled x8 (+ detail) and horizontally shifted context views."""
+    import torch.nn.functional as F
+    base = torch.rand(B, 3, H // 8 + 2, W // 8 + 4, generator=gen)
+    big = F.interpolate(base, size=(H + 16, W + 32), mode='bicubic', align_corners=True).clamp(0, 1)
+    big = (big + 0.05 * torch.rand(big.shape, generator=gen)).clamp(0, 1)
+    outs = []
+    for i in range(n):
+        dx = int(round((i - 1) * shift)) + 8
+        outs.append(big[:, :, 8:8 + H, dx:dx + W].contiguous())
+    return outs[1], [outs[0], outs[2]]
+
+
+def randomize(module, gen, scale=0.1):
+    """Non-trivial biases / GroupNorm affine so that the fixtures exercise them."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() == 1:
+                if 'normalize.weight' in n or n.endswith('.1.weight'):
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+                else:
+                    p.copy_(scale * torch.randn(p.shape, generator=gen))
+
+
+def grads_of(out, params):
+    g = torch.autograd.grad(out, params, allow_unused=True)
+    return [None if t is None else t.detach().clone() for t in g]
+
+
+def case_layers(gen):
+    """Block-level fixtures with small channel counts."""
+    fx = {}
+    # Conv2D (pad+conv+GN+ELU) -- several kernel sizes / odd channel counts
+    for name, cin, cout, k, H, W in (('conv2d_k3', 19, 32, 3, 12, 40), ('conv2d_k5', 3, 16, 5, 10, 32),
+                                      ('conv2d_k7', 16, 16, 7, 8, 64)):
+        m = R.Conv2D(cin, cout, k, 1)
+        randomize(m, gen)
+        x = torch.randn(2, cin, H, W, generator=gen, requires_grad=True)
+        y = m(x)
+        sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+        yo = O.conv2d_gn_elu(x, {'l.' + kk: v for kk, v in sd.items()}, 'l', k)
+        close(yo, y, 2e-5, name)
+        dy = torch.randn(y.shape, generator=gen)
+        params = [x] + list(m.parameters())
+        g = grads_of((y * dy).sum(), params)
+        fx[name] = dict(k=k, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                        dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    # ResidualConv
+    m = R.ResidualConv(16, 32, 1)
+    randomize(m, gen)
+    x = torch.randn(2, 16, 6, 20, generator=gen, requires_grad=True)
+    y = m(x)
+    sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+    close(O.residual_conv(x, {'l.' + kk: v for kk, v in sd.items()}, 'l'), y, 2e-5, 'residual_conv')
+    dy = torch.randn(y.shape, generator=gen)
+    g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+    fx['residual_conv'] = dict(x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                               dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    # packing
+    x = torch.randn(2, 5, 6, 8, generator=gen)
+    close(O.packing(x), R.packing(x), 0, 'packing')
+    fx['packing'] = dict(x=x, y=R.packing(x))
+    # PackLayerConv3d
+    for name, c, k, H, W in (('pack_k3', 16, 3, 12, 40), ('pack_k5', 16, 5, 8, 64)):
+        m = R.PackLayerConv3d(c, k)
+        randomize(m, gen)
+        with torch.no_grad():
+            m.conv3d.weight.copy_(0.3 * torch.randn(m.conv3d.weight.shape, generator=gen))
+        x = torch.randn(2, c, H, W, generator=gen, requires_grad=True)
+        y = m(x)
+        sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+        close(O.pack_layer_conv3d(x, {'l.' + kk: v for kk, v in sd.items()}, 'l', k), y, 2e-5, name)
+        dy = torch.randn(y.shape, generator=gen)
+        g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+        fx[name] = dict(k=k, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                        dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    # UnpackLayerConv3d
+    m = R.UnpackLayerConv3d(32, 32, 3)
+    randomize(m, gen)
+    with torch.no_grad():
+        m.conv3d.weight.copy_(0.3 * torch.randn(m.conv3d.weight.shape, generator=gen))
+    x = torch.randn(2, 32, 6, 20, generator=gen, requires_grad=True)
+    y = m(x)
+    sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+    close(O.unpack_layer_conv3d(x, {'l.' + kk: v for kk, v in sd.items()}, 'l', 3), y, 2e-5, 'unpack')
+    dy = torch.randn(y.shape, generator=gen)
+    g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+    fx['unpack'] = dict(k=3, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                        dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    # InvDepth
+    m = R.InvDepth(16)
+    randomize(m, gen)
+    x = torch.randn(2, 16, 6, 20, generator=gen, requires_grad=True)
+    y = m(x)
+    sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+    close(O.inv_depth_head(x, {'l.' + kk: v for kk, v in sd.items()}, 'l'), y, 2e-5, 'invdepth')
+    dy = torch.randn(y.shape, generator=gen)
+    g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+    fx['invdepth'] = dict(x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                          dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    return fx
+
+
+def kitti_K(B, H, W):
+    return torch.tensor([[0.58 * W, 0., 0.5 * W], [0., 1.92 * H, 0.5 * H], [0., 0., 1.]], dtype=torch.float64).repeat(B, 1, 1)
+
+
+def case_loss(gen):
+    """MultiViewPhotometricLoss fixtures: default config (upsampled scales, min+automask) and the
+    non-upsampled / mean variants."""
+    import torch.nn.functional as F
+    fx = {}
+    B, H, W = 2, 48, 64
+    image, context = smooth_images(B, H, W, gen)
+    K = kitti_K(B, H, W)
+    pose_vec = torch.cat([0.05 * torch.randn(B, 2, 3, generator=gen), 0.01 * torch.randn(B, 2, 3, generator=gen)], 2)
+    for name, kwargs, upsample in (
+            ('loss_default', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                                  automask_loss=True, clip_loss=0.0), True),
+            ('loss_multires_mean', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.1,
+                                        photometric_reduce_op='mean', automask_loss=False, clip_loss=0.0), False)):
+        inv = [(0.05 + 0.5 * torch.rand(B, 1, H >> i, W >> i, generator=gen)) for i in range(4)]
+        inv = [F.interpolate(F.avg_pool2d(t, 3, 1, 1), size=t.shape[-2:]) for t in inv]  # mild smoothing
+        if upsample:
+            inv = [F.interpolate(t, (H, W), mode='nearest') for t in inv]
+        inv = [t.clone().requires_grad_(True) for t in inv]
+        pv = pose_vec.clone().requires_grad_(True)
+        poses = [RefPose.from_vec(pv[:, i], 'euler') for i in range(2)]
+        loss_mod = RefLoss(**kwargs)
+        out = loss_mod(image, context, inv, K, K, poses)
+        loss = out['loss']
+        g = grads_of(loss.sum(), inv + [pv])
+        # oracle on the same inputs
+        inv_o = [t.detach().clone().requires_grad_(True) for t in inv]
+        pv_o = pose_vec.clone().requires_grad_(True)
+        mats = [O.pose_vec2mat44(pv_o[:, i]) for i in range(2)]
+        okw = {k: v for k, v in kwargs.items() if k != 'clip_loss'}
+        lo, po, so = O.multiview_photometric_loss(image, context, inv_o, K, K, mats, **okw)
+        go = grads_of(lo.sum(), inv_o + [pv_o])
+        close(lo, loss.detach(), 1e-5, name + '.loss')
+        for i in range(5):
+            close(go[i], g[i], 2e-4, '%s.grad%d' % (name, i))
+        fx[name] = dict(kwargs=okw, image=image, context=context, K=K, inv_depths=[t.detach() for t in inv],
+                        pose_vec=pose_vec, loss=loss.detach(), photometric_loss=out['metrics']['photometric_loss'],
+                        smoothness_loss=out['metrics']['smoothness_loss'], d_inv_depths=g[:4], d_pose_vec=g[4])
+    return fx
+
+
+def case_network(gen):
+    """PackNet01('1A') and PoseNet with seeded parameters at 32x64: outputs + per-parameter gradient norms."""
+    fx = {}
+    shapes = O.packnet01_param_shapes('1A')
+    sd = O.init_params(shapes, seed=1234, randomize_affine=True)
+    net = RefPackNet01(dropout=0.0, version='1A')
+    ref_sd = net.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), 'state-dict key mismatch'
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd)
+    net.train()
+    rgb = torch.rand(1, 3, 32, 64, generator=gen)
+    disps = net(rgb)['inv_depths']
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    disps_o = O.packnet01_forward(sdo, rgb, '1A', True)
+    for a, b in zip(disps_o, disps):
+        close(a, b.detach(), 5e-5, 'packnet01.disp')
+    dys = [torch.randn(d.shape, generator=gen) for d in disps]
+    names = [n for n, _ in net.named_parameters()]
+    g = grads_of(sum((d * dy).sum() for d, dy in zip(disps, dys)), list(net.parameters()))
+    go = grads_of(sum((d * dy).sum() for d, dy in zip(disps_o, dys)), [sdo[n] for n in names])
+    for n, a, b in zip(names, go, g):
+        close(a, b, 5e-4, 'packnet01.grad.' + n)
+    net.eval()
+    with torch.no_grad():
+        d_eval = net(rgb)['inv_depths']
+    assert torch.is_tensor(d_eval)
+    fx['packnet01'] = dict(seed=1234, rgb=rgb, disps=[d.detach() for d in disps], dys=dys, disp_eval=d_eval,
+                           grad_norms={n: float(t.norm()) for n, t in zip(names, g)},
+                           grad_samples={n: t.flatten()[:: max(1, t.numel() // 16)][:16].clone() for n, t in zip(names, g)})
+    # PoseNet
+    pshapes = O.posenet_param_shapes(2)
+    psd = O.init_params(pshapes, seed=4321, randomize_affine=True)
+    pnet = RefPoseNet(nb_ref_imgs=2)
+    assert set(pnet.state_dict().keys()) == set(psd.keys())
+    pnet.load_state_dict(psd)
+    img = torch.rand(2, 3, 64, 128, generator=gen)
+    ctx = [torch.rand(2, 3, 64, 128, generator=gen) for _ in range(2)]
+    pv = pnet(img, ctx)
+    close(O.posenet_forward(psd, img, ctx), pv.detach(), 1e-5, 'posenet')
+    fx['posenet'] = dict(seed=4321, image=img, context=ctx, pose_vec=pv.detach())
+    return fx
+
+
+def case_step(gen):
+    """One full SelfSupModel training forward/backward at 64x96, B=1, default loss config, both flip states."""
+    fx = {}
+    B, H, W = 1, 64, 96
+    image, context = smooth_images(B, H, W, gen)
+    batch = {'rgb': image, 'rgb_context': context, 'rgb_original': image, 'rgb_context_original': context,
+             'intrinsics': kitti_K(B, H, W)}
+    sd = O.init_params(O.packnet01_param_shapes('1A'), seed=42)
+    psd = O.init_params(O.posenet_param_shapes(2), seed=43)
+    with torch.no_grad():  # PoseNet at init predicts ~0 motion: give the head a bias so warps are non-trivial
+        psd['pose_pred.bias'] = torch.tensor([2., 0.5, -1., 0.3, -0.2, 0.1, -2., -0.5, 1., -0.3, 0.2, -0.1])
+    loss_kwargs = dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                       automask_loss=True)
+    for flip in (False, True):
+        model = RefSelfSup(num_scales=4, ssim_loss_weight=0.85, occ_reg_weight=0.1, smooth_loss_weight=0.001, C1=1e-4, C2=9e-4,
+                           photometric_reduce_op='min', disp_norm=True, clip_loss=0.0, progressive_scaling=0.0,
+                           padding_mode='zeros', automask_loss=True, flip_lr_prob=1.0 if flip else 0.0,
+                           rotation_mode='euler', upsample_depth_maps=True)
+        dn, pn = RefPackNet01(dropout=0.0, version='1A'), RefPoseNet(nb_ref_imgs=2)
+        dn.load_state_dict(sd)
+        pn.load_state_dict(psd)
+        model.add_depth_net(dn)
+        model.add_pose_net(pn)
+        model.train()
+        random.seed(0)
+        out = model({k: (v if not isinstance(v, list) else list(v)) for k, v in batch.items()}, progress=0.0)
+        loss = out['loss']
+        names = ['depth_net.' + n for n, _ in dn.named_parameters()] + ['pose_net.' + n for n, _ in pn.named_parameters()]
+        g = grads_of(loss.sum(), list(dn.parameters()) + list(pn.parameters()))
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        psdo = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        oo = O.selfsup_forward(sdo, psdo, batch, flip=flip, **loss_kwargs)
+        close(oo['loss'], loss.detach(), 2e-5, 'step.loss')
+        go = grads_of(oo['loss'].sum(), [sdo[n] for n, _ in dn.named_parameters()] + [psdo[n] for n, _ in pn.named_parameters()])
+        worst = 0.0
+        for n, a, b in zip(names, go, g):
+            worst = max(worst, close(a, b, 2e-3, 'step.grad.' + n))
+        print('  step flip=%s loss=%.6f  worst rel grad err oracle-vs-reference %.2e' % (flip, float(loss), worst))
+        fx['step_flip%d' % int(flip)] = dict(
+            depth_seed=42, pose_seed=43, pose_pred_bias=psd['pose_pred.bias'], loss_kwargs=loss_kwargs, flip=flip,
+            batch=batch, loss=loss.detach(), photometric_loss=out['metrics']['photometric_loss'],
+            smoothness_loss=out['metrics']['smoothness_loss'], inv_depth0=out['inv_depths'][0].detach(),
+            grad_norms={n: float(t.norm()) for n, t in zip(names, g)},
+            grad_samples={n: t.flatten()[:: max(1, t.numel() // 8)][:8].clone() for n, t in zip(names, g)})
+    return fx
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    gen = torch.Generator().manual_seed(20260923)
+    for name, fn in (('layers', case_layers), ('loss', case_loss), ('network', case_network), ('step', case_step)):
+        print('pinning', name, '...', flush=True)
+        fx = fn(gen)
+        path = os.path.join(GOLD, name + '.pt')
+        torch.save(fx, path)
+        print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+    print('oracle pinned against /root/reference: OK')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,129 @@
+// api.hip -- error plumbing, build identification and live kernel timing for libpnsfm_hip.so.
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+namespace pnsfm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  int e = (int)hipGetLastError();
+  if (e != 0) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString((hipError_t)e));
+    return e;
+  }
+  return 0;
+}
+
+// ---- live timing -------------------------------------------------------------------------------
+// bench.py needs the dominant kernel's duration measured "live" with events recorded on the very
+// stream the kernel is launched on.  When enabled, each profiled launch records a (start, stop)
+// event pair; collect() synchronises on them and adds up hipEventElapsedTime.
+#ifndef PNSFM_EMU
+struct ProfRec { hipEvent_t a, b; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs[2];
+static std::vector<hipEvent_t> g_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(int kind, double flops, hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.a = get_event();
+  r.b = get_event();
+  r.flops = flops;
+  hipEventRecord(r.a, stream);
+  g_recs[kind].push_back(r);
+}
+
+void prof_end(int kind, hipStream_t stream) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_recs[kind].empty()) return;
+  hipEventRecord(g_recs[kind].back().b, stream);
+}
+#else
+void prof_begin(int, double, hipStream_t) {}
+void prof_end(int, hipStream_t) {}
+#endif
+
+}  // namespace pnsfm
+
+extern "C" {
+
+int pnsfm_version(void) { return 1; }
+
+const char* pnsfm_last_error(void) { return pnsfm::g_err; }
+
+const char* pnsfm_build_target(void) {
+#ifdef PNSFM_EMU
+  return "emu";
+#else
+  return "gfx950";
+#endif
+}
+
+int pnsfm_prof_enable(int on) {
+#ifndef PNSFM_EMU
+  std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);
+  pnsfm::g_prof_on = on != 0;
+#else
+  (void)on;
+#endif
+  return 0;
+}
+
+int pnsfm_prof_reset(void) {
+#ifndef PNSFM_EMU
+  std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);
+  for (int k = 0; k < 2; ++k) {
+    for (auto& r : pnsfm::g_recs[k]) {
+      hipEventSynchronize(r.b);
+      pnsfm::g_pool.push_back(r.a);
+      pnsfm::g_pool.push_back(r.b);
+    }
+    pnsfm::g_recs[k].clear();
+  }
+#endif
+  return 0;
+}
+
+int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long long* launches) {
+  if (kind < 0 || kind > 1) { pnsfm::set_error("prof_collect: bad kind %d", kind); return -1; }
+  double ms = 0.0, fl = 0.0;
+  long long n = 0;
+#ifndef PNSFM_EMU
+  std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);
+  for (auto& r : pnsfm::g_recs[kind]) {
+    hipEventSynchronize(r.b);
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; fl += r.flops; n++; }
+  }
+#endif
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
+
+}  // extern "C"

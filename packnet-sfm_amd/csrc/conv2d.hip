@@ -1,0 +1,561 @@
+// conv2d.hip -- stride-1, zero-padded KxK convolution as an exact-fp32 MFMA implicit GEMM for gfx950.
+//
+// Replaces nn.ConstantPad2d(k//2) + nn.Conv2d(stride=1) of the reference's Conv2D / ResidualConv /
+// InvDepth / PackLayerConv3d / UnpackLayerConv3d blocks
+//   (/root/reference/packnet_sfm/networks/layers/packnet/layers01.py:28-36, 57-60, 115-121, 235-246, 274-281)
+// and their autograd (dgrad = same kernel on a tap-flipped / transposed packed weight; wgrad below).
+//
+// GEMM view (forward):  Y[M = co][N = pixel] = sum_{tap, ci} Wp[tap][ci][co] * X[ci][pixel + off(tap)]
+//   * one workgroup = 4 wave64; block tile = (32*MT output channels) x (4 waves * NT * 32 pixels);
+//   * the input halo patch for CI (<=16) channels is staged ONCE in LDS and reused by all k*k taps
+//     (and by every output channel of the tile) -- NCHW rows are read as coalesced row segments;
+//   * per tap, a [CI][BM] weight slab (M fastest -> conflict-free ds_read_b32 for the MFMA A operand)
+//     is double-buffered through registers while the previous tap's MFMAs run;
+//   * v_mfma_f32_32x32x2_f32 (A: lane l holds W[m = l&31][k = l>>5], B: lane l holds X[k = l>>5][n = l&31]),
+//     i.e. two input channels per instruction, exact fp32 (bitwise an fmaf chain) -- no TF32/bf16 shortcut;
+//   * K (= taps x channels) can be split across blockIdx.z for the low-resolution layers whose pixel
+//     count cannot fill 256 CUs (pack4/pack5: 480 pixels, K = 147456); partial sums meet with fp32 atomics.
+// Roofline: MFMA-bound. 2*Cout*Cin*k*k*B*H*W flop per launch against the 157.3 TFLOP/s fp32 matrix peak.
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+namespace pnsfm {
+
+int conv_pick_MT(int Mc) { return (round_up(Mc, 64) == round_up(Mc, 32)) ? 2 : 1; }
+int conv_pack_MP(int Mc) { return round_up(Mc, 32 * conv_pick_MT(Mc)); }
+int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
+
+static const size_t kMaxSmem = 64 * 1024;
+
+ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
+  ConvGeom g;
+  g.MT = conv_pick_MT(Cout);
+  const int BM = 32 * g.MT;
+  g.MP = conv_pack_MP(Cout);
+  g.KP = conv_pack_KP(Cin);
+  g.CI = g.KP < 16 ? g.KP : 16;
+  g.mode = (W % 32 == 0) ? 0 : 1;
+  const int m_tiles = g.MP / BM;
+  const int HW = H * W;
+  for (int NT = 2; NT >= 1; --NT) {
+    g.NT = NT;
+    if (g.mode == 0) {
+      g.tiles_x = W / 32;
+      g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
+      g.PH = 4 * NT + ks - 1;
+      g.PW = 32 + ks - 1;
+    } else {
+      const int tile_px = 128 * NT;
+      g.tiles_x = 0;
+      g.tiles_per_img = ceil_div(HW, tile_px);
+      int rows = (tile_px + W - 2) / W + 1;
+      if (rows > H) rows = H;
+      g.PH = rows + ks - 1;
+      g.PW = W + ks - 1;
+    }
+    long blocks = (long)B * g.tiles_per_img * m_tiles;
+    size_t smem = ((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float);
+    if (NT == 2 && (blocks < 768 || smem > kMaxSmem)) continue;
+    break;
+  }
+  // shrink the channel chunk if the halo patch of a very wide image does not fit
+  while (((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 2) g.CI /= 2;
+  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float);
+  g.nchunks = ceil_div(g.KP, g.CI);
+  long blocks = (long)B * g.tiles_per_img * m_tiles;
+  g.splitK = 1;
+  if (blocks < 512 && g.nchunks > 1) {
+    int want = (int)((1024 + blocks - 1) / blocks);
+    if (want > g.nchunks) want = g.nchunks;
+    int cps = ceil_div(g.nchunks, want);
+    g.splitK = ceil_div(g.nchunks, cps);
+  }
+  return g;
+}
+
+struct ConvArgs {
+  const float* x;     // [B][Cin][H][W]
+  const float* wp;    // [KK][KP][MP]
+  const float* bias;  // [Cout] or null
+  float* y;           // [B][Cout][H][W]
+  int B, Cin, Cout, H, W, KS;
+  int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
+  float invPW;
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
+  PNSFM_DYN_SMEM(float, smem);
+  constexpr int BM = 32 * MT;
+  const int PS = a.PH * a.PW;
+  float* patch = smem;               // [CI][PS]
+  float* wbuf = smem + a.CI * PS;    // [2][CI][BM]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int P = a.KS >> 1, KK = a.KS * a.KS;
+  const int H = a.H, W = a.W, HW = H * W;
+
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int t = blockIdx.x - b * a.tiles_per_img;
+  const int co0 = blockIdx.y * BM;
+  const int c_begin = blockIdx.z * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  if (c_end > a.nchunks) c_end = a.nchunks;
+
+  // ---- pixel-tile geometry: where this lane's output pixels are, and where they sit in the patch
+  int py0, px0;
+  int boff[NT], oy[NT], ox[NT];
+  bool pvalid[NT];
+  if (a.mode == 0) {
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int y0 = ty * 4 * NT, x0 = tx * 32;
+    py0 = y0 - P;
+    px0 = x0 - P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wave * NT + nt;
+      oy[nt] = y0 + row;
+      ox[nt] = x0 + l32;
+      pvalid[nt] = oy[nt] < H;
+      boff[nt] = row * a.PW + l32;
+    }
+  } else {
+    const int n0 = t * 128 * NT;
+    const int r0 = n0 / W;
+    py0 = r0 - P;
+    px0 = -P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wave * NT + nt) * 32 + l32;
+      pvalid[nt] = n < HW;
+      const int yy = pvalid[nt] ? n / W : r0;
+      oy[nt] = yy;
+      ox[nt] = pvalid[nt] ? n - yy * W : 0;
+      boff[nt] = (yy - r0) * a.PW + ox[nt];
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const float* xb = a.x + (size_t)b * a.Cin * HW;
+  // weight slab loader geometry: slab = [cnt][BM] floats, one float4 per thread
+  const int wrow = tid / (BM / 4), wc4 = tid - wrow * (BM / 4);
+
+  for (int c = c_begin; c < c_end; ++c) {
+    const int ci0 = c * a.CI;
+    int cnt = a.KP - ci0;
+    if (cnt > a.CI) cnt = a.CI;
+    __syncthreads();  // all waves are done with the previous chunk's patch / weight buffers
+    // ---- stage the halo patch of `cnt` input channels (zero padding by predication)
+    for (int cil = 0; cil < cnt; ++cil) {
+      const int ci = ci0 + cil;
+      const float* xc = xb + (size_t)ci * HW;
+      const bool cok = ci < a.Cin;
+      for (int e = tid; e < PS; e += 256) {
+        const int r = (int)(((float)e + 0.5f) * a.invPW);
+        const int cc = e - r * a.PW;
+        const int yy = py0 + r, xx = px0 + cc;
+        float v = 0.f;
+        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xc[yy * W + xx];
+        patch[cil * PS + e] = v;
+      }
+    }
+    // ---- tap 0 weight slab
+    const bool wact = wrow < cnt;
+    float4 wreg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wact) wreg = *reinterpret_cast<const float4*>(a.wp + ((size_t)(0 * a.KP + ci0 + wrow)) * a.MP + co0 + wc4 * 4);
+    if (wact) *reinterpret_cast<float4*>(wbuf + wrow * BM + wc4 * 4) = wreg;
+    __syncthreads();
+
+    const int ksteps = cnt >> 1;
+    for (int tap = 0; tap < KK; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < KK && wact)
+        wreg = *reinterpret_cast<const float4*>(a.wp + ((size_t)((tap + 1) * a.KP + ci0 + wrow)) * a.MP + co0 + wc4 * 4);
+      const int ky = tap / a.KS, kx = tap - ky * a.KS;
+      const float* wb = wbuf + cur * a.CI * BM + half * BM + l32;
+      const float* pb = patch + half * PS + ky * a.PW + kx;
+      for (int kk = 0; kk < ksteps; ++kk) {
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = wb[kk * 2 * BM + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = pb[kk * 2 * PS + boff[nt]];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[mt], bv[nt], acc[mt][nt]);
+      }
+      if (tap + 1 < KK && wact) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l32
+  float* yb = a.y + (size_t)b * a.Cout * HW;
+  const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout) {
+        const float bval = add_bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (pvalid[nt]) {
+            float* dst = yb + (size_t)co * HW + oy[nt] * W + ox[nt];
+            const float v = acc[mt][nt][r] + bval;
+            if (a.splitK == 1) *dst = v; else atomicAdd(dst, v);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
+                       int H, int W, int ks, hipStream_t stream, const char* what) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
+  ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks);
+  if (g.smem_bytes > kMaxSmem) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
+  ConvArgs a;
+  a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
+  a.CI = g.CI; a.mode = g.mode; a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img;
+  a.PH = g.PH; a.PW = g.PW; a.KP = g.KP; a.MP = g.MP; a.nchunks = g.nchunks;
+  a.chunks_per_split = ceil_div(g.nchunks, g.splitK); a.splitK = g.splitK;
+  a.invPW = 1.0f / (float)g.PW;
+  if (g.splitK > 1) {
+    int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
+    if (e) { set_error("%s: memset failed", what); return e; }
+  }
+  dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
+  const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
+  prof_begin(0, flops, stream);
+  if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a);
+  else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a);
+  else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a);
+  else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a);
+  prof_end(0, stream);
+  return check_launch(what);
+}
+
+// ---- weight packers -----------------------------------------------------------------------------
+// forward:  wp[tap][ci][co]            = w[co][ci][tap]                (K = Cin,  M = Cout)
+// backward: wp[tap][co][ci]            = w[co][ci][KK-1-tap]           (K = Cout, M = Cin; taps flipped)
+// Both go through LDS so that global reads (tap fastest) and writes (M fastest) are both contiguous.
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                        int Cin, int Cout, int KK, int KP, int MP) {
+  __shared__ float tile[64 * 49];
+  const int ci = blockIdx.x;       // < KP
+  const int co0 = blockIdx.y * 64;
+  const int n = 64 * KK;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int col = e / KK, tap = e - col * KK;  // read order: tap fastest
+    const int co = co0 + col;
+    float v = 0.f;
+    if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * KK + tap];
+    tile[col * KK + tap] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int tap = e >> 6, col = e & 63;  // write order: co fastest
+    const int co = co0 + col;
+    if (co < MP) wp[((size_t)tap * KP + ci) * MP + co] = tile[col * KK + tap];
+  }
+}
+
+__global__ void __launch_bounds__(256) pack_bwd_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                        int Cin, int Cout, int KK, int KP, int MP) {
+  __shared__ float tile[64 * 49];
+  const int co = blockIdx.x;       // < KP (K dimension = Cout)
+  const int ci0 = blockIdx.y * 64;
+  const int n = 64 * KK;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int col = e / KK, tap = e - col * KK;
+    const int ci = ci0 + col;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KK + tap];  // contiguous over (ci, tap)
+    tile[col * KK + tap] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int tap = e >> 6, col = e & 63;
+    const int ci = ci0 + col;
+    if (ci < MP) wp[((size_t)(KK - 1 - tap) * KP + co) * MP + ci] = tile[col * KK + tap];
+  }
+}
+
+// ---- backward-weight -------------------------------------------------------------------------------
+// dW[co][n] with n = ci*KK + tap (the reference's [Cout][Cin][k][k] layout, contiguous in n):
+//   dW[co][n] = sum_{b, pixel} dY[co][pixel] * X[ci(n)][pixel + off(tap(n))]
+// GEMM view: M = co (32*MT per block), N = n (4 waves x 32), K = pixels (tiles of PT pixels).
+// A operand: dY tile in LDS [BM][PT+1] (lane m = l&31, k = pixel parity l>>5) -- stride PT+1 is conflict-free;
+// B operand: the halo patch of the <= NCI input channels this n-range touches; each lane owns one (ci, tap)
+// and walks the pixels through a per-tile offset table.  Pixel tiles are split over blockIdx.z and the
+// partial dW meet with fp32 atomics (dW is small next to the activations).
+struct WgradArgs {
+  const float* x;   // [B][Cin][H][W]
+  const float* dy;  // [B][Cout][H][W]
+  float* dw;        // [Cout][Cin*KK]
+  int B, Cin, Cout, H, W, KS;
+  int PT, mode, tiles_x, tiles_per_img, PH, PW, NCI, total_tiles, tiles_per_split, splitP;
+  float invPW;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
+  PNSFM_DYN_SMEM(float, smem);
+  constexpr int BM = 32 * MT;
+  const int PT = a.PT, DS = PT + 1;
+  const int PS = a.PH * a.PW;
+  float* dys = smem;                       // [BM][PT+1]
+  float* patch = smem + BM * DS;           // [NCI][PS]
+  int* poff = reinterpret_cast<int*>(patch + a.NCI * PS);  // [PT]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int P = a.KS >> 1, KK = a.KS * a.KS;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int N = a.Cin * KK;
+
+  const int n0 = blockIdx.x * 128;
+  const int co0 = blockIdx.y * BM;
+  const int ci_lo = n0 / KK;
+  const int n = n0 + wave * 32 + l32;
+  const bool nvalid = n < N;
+  int lane_b = 0;
+  if (nvalid) {
+    const int ci_n = n / KK, tap = n - ci_n * KK;
+    const int ky = tap / a.KS, kx = tap - ky * a.KS;
+    lane_b = (ci_n - ci_lo) * PS + ky * a.PW + kx;
+  }
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const int t_begin = blockIdx.z * a.tiles_per_split;
+  int t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.total_tiles) t_end = a.total_tiles;
+
+  for (int tt = t_begin; tt < t_end; ++tt) {
+    const int b = tt / a.tiles_per_img;
+    const int t = tt - b * a.tiles_per_img;
+    int py0, px0, y0 = 0, x0 = 0, pn0 = 0, r0 = 0;
+    if (a.mode == 0) {
+      const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+      y0 = ty * (PT >> 5);
+      x0 = tx * 32;
+      py0 = y0 - P;
+      px0 = x0 - P;
+    } else {
+      pn0 = t * PT;
+      r0 = pn0 / W;
+      py0 = r0 - P;
+      px0 = -P;
+    }
+    __syncthreads();  // previous tile fully consumed
+    // ---- dY tile [BM][PT] (zero for channels / pixels outside the tensor)
+    const float* dyb = a.dy + (size_t)b * a.Cout * HW;
+    for (int e = tid; e < BM * PT; e += 256) {
+      const int m = e / PT, p = e - m * PT;
+      int yy, xx;
+      bool ok;
+      if (a.mode == 0) { yy = y0 + (p >> 5); xx = x0 + (p & 31); ok = yy < H; }
+      else { const int pn = pn0 + p; ok = pn < HW; yy = ok ? pn / W : 0; xx = ok ? pn - yy * W : 0; }
+      const int co = co0 + m;
+      float v = 0.f;
+      if (ok && co < a.Cout) v = dyb[(size_t)co * HW + yy * W + xx];
+      dys[m * DS + p] = v;
+    }
+    // ---- pixel -> patch offset table
+    if (tid < PT) {
+      const int p = tid;
+      int off;
+      if (a.mode == 0) off = (p >> 5) * a.PW + (p & 31);
+      else { const int pn = pn0 + p; const bool ok = pn < HW; const int yy = ok ? pn / W : r0; const int xx = ok ? pn - yy * W : 0; off = (yy - r0) * a.PW + xx; }
+      poff[p] = off;
+    }
+    // ---- input halo patch for channels ci_lo .. ci_lo+NCI-1
+    const float* xb = a.x + (size_t)b * a.Cin * HW;
+    for (int cil = 0; cil < a.NCI; ++cil) {
+      const int ci = ci_lo + cil;
+      const bool cok = ci < a.Cin;
+      const float* xc = xb + (size_t)ci * HW;
+      for (int e = tid; e < PS; e += 256) {
+        const int r = (int)(((float)e + 0.5f) * a.invPW);
+        const int cc = e - r * a.PW;
+        const int yy = py0 + r, xx = px0 + cc;
+        float v = 0.f;
+        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xc[yy * W + xx];
+        patch[cil * PS + e] = v;
+      }
+    }
+    __syncthreads();
+    const float* ab = dys + l32 * DS + half;
+    const float* bb = patch + lane_b;
+    const int ksteps = PT >> 1;
+    for (int kk = 0; kk < ksteps; ++kk) {
+      const float bv = bb[poff[2 * kk + half]];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = pnsfm_mfma_32x32x2(ab[mt * 32 * DS + 2 * kk], bv, acc[mt]);
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && nvalid) {
+        float* dst = a.dw + (size_t)co * N + n;
+        if (a.splitP == 1) *dst = acc[mt][r]; else atomicAdd(dst, acc[mt][r]);
+      }
+    }
+  }
+}
+
+// per-channel sum over (batch, pixels): dbias[c] = sum dy[b][c][:]
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ out,
+                                                           int B, int C, int HW, int nsplit) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const int s = blockIdx.y;
+  const long total = (long)B * HW;
+  const long per = (total + nsplit - 1) / nsplit;
+  const long beg = s * per;
+  long end = beg + per;
+  if (end > total) end = total;
+  double acc = 0.0;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const long b = i / HW, p = i - b * HW;
+    acc += (double)dy[((size_t)b * C + c) * HW + p];
+  }
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[c], (float)(red[0] + red[1] + red[2] + red[3]));
+}
+
+}  // namespace pnsfm
+
+using namespace pnsfm;
+
+extern "C" {
+
+size_t pnsfm_conv2d_packed_elems_fwd(int Cin, int Cout, int ks) {
+  return (size_t)ks * ks * conv_pack_KP(Cin) * conv_pack_MP(Cout);
+}
+size_t pnsfm_conv2d_packed_elems_bwd(int Cin, int Cout, int ks) {
+  return (size_t)ks * ks * conv_pack_KP(Cout) * conv_pack_MP(Cin);
+}
+
+int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int Cin, int Cout, int ks, void* stream) {
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("pack_weights: unsupported kernel size %d", ks); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int KK = ks * ks;
+  if (wp_fwd) {
+    const int KP = conv_pack_KP(Cin), MP = conv_pack_MP(Cout);
+    PNSFM_LAUNCH(pack_fwd_kernel, dim3(KP, ceil_div(MP, 64)), dim3(256), 0, s, w, wp_fwd, Cin, Cout, KK, KP, MP);
+    int e = check_launch("pack_fwd");
+    if (e) return e;
+  }
+  if (wp_bwd) {
+    const int KP = conv_pack_KP(Cout), MP = conv_pack_MP(Cin);
+    PNSFM_LAUNCH(pack_bwd_kernel, dim3(KP, ceil_div(MP, 64)), dim3(256), 0, s, w, wp_bwd, Cin, Cout, KK, KP, MP);
+    int e = check_launch("pack_bwd");
+    if (e) return e;
+  }
+  return 0;
+}
+
+int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin, int Cout,
+                         int H, int W, int ks, void* stream) {
+  return launch_conv(x, wp_fwd, bias, y, B, Cin, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward");
+}
+
+int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx, int B, int Cin, int Cout, int H,
+                               int W, int ks, void* stream) {
+  // dX = conv(dY, flipped/transposed W): K-channels = Cout, M-channels = Cin
+  return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data");
+}
+
+int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
+                                 int H, int W, int ks, void* stream) {
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("backward_weight: unsupported kernel size %d", ks); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int KK = ks * ks, N = Cin * KK, HW = H * W;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
+  const int MT = conv_pick_MT(Cout), BM = 32 * MT;
+  a.mode = (W % 32 == 0) ? 0 : 1;
+  a.NCI = 127 / KK + 2;
+  if (a.NCI > Cin) a.NCI = Cin;
+  size_t smem = 0;
+  for (int PT = (KK == 1 ? 64 : 128); PT >= 32; PT >>= 1) {
+    a.PT = PT;
+    if (a.mode == 0) {
+      a.tiles_x = W / 32;
+      a.tiles_per_img = a.tiles_x * ceil_div(H, PT / 32);
+      a.PH = PT / 32 + ks - 1;
+      a.PW = 32 + ks - 1;
+    } else {
+      a.tiles_x = 0;
+      a.tiles_per_img = ceil_div(HW, PT);
+      int rows = (PT + W - 2) / W + 1;
+      if (rows > H) rows = H;
+      a.PH = rows + ks - 1;
+      a.PW = W + ks - 1;
+    }
+    smem = ((size_t)BM * (PT + 1) + (size_t)a.NCI * a.PH * a.PW + PT) * sizeof(float);
+    if (smem <= kMaxSmem) break;
+  }
+  if (smem > kMaxSmem) { set_error("backward_weight: image too wide for the LDS halo patch (W=%d)", W); return -1; }
+  a.invPW = 1.0f / (float)a.PW;
+  a.total_tiles = B * a.tiles_per_img;
+  const int n_tiles = ceil_div(N, 128), m_tiles = ceil_div(Cout, BM);
+  int want = ceil_div(1536, n_tiles * m_tiles);
+  if (want < 1) want = 1;
+  if (want > a.total_tiles) want = a.total_tiles;
+  a.tiles_per_split = ceil_div(a.total_tiles, want);
+  a.splitP = ceil_div(a.total_tiles, a.tiles_per_split);
+  if (a.splitP > 1) {
+    int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * N * sizeof(float), s);
+    if (e) { set_error("backward_weight: memset failed"); return e; }
+  }
+  dim3 grid(n_tiles, m_tiles, a.splitP);
+  const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
+  prof_begin(1, flops, s);
+  if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, a);
+  else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, a);
+  prof_end(1, s);
+  int e = check_launch("conv2d_backward_weight");
+  if (e) return e;
+  if (dbias) {
+    e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+    if (e) { set_error("backward_weight: memset failed"); return e; }
+    int nsplit = ceil_div(512, Cout);
+    long total = (long)B * HW;
+    if (nsplit > (int)((total + 1023) / 1024)) nsplit = (int)((total + 1023) / 1024);
+    if (nsplit < 1) nsplit = 1;
+    PNSFM_LAUNCH(channel_sum_kernel, dim3(Cout, nsplit), dim3(256), 0, s, dy, dbias, B, Cout, HW, nsplit);
+    e = check_launch("channel_sum");
+  }
+  return e;
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+// loss.hip -- the self-supervised photometric objective of PackNet-SfM as fused gfx950 kernels.
+//
+//  view_synthesis_{forward,backward}: inv2depth -> Camera.reconstruct -> Camera.project -> grid_sample
+//      /root/reference/packnet_sfm/losses/multiview_photometric_loss.py:127-165
+//      /root/reference/packnet_sfm/utils/depth.py:103-120, geometry/camera.py:72-80,112-191,
+//      geometry/camera_utils.py:27-59 (bilinear, padding 'zeros', align_corners=True)
+//  photometric_{forward,backward}: SSIM (:14-53), clamp((1-ssim)/2) (:169-186), 0.85/0.15 SSIM/L1 mix (:188-223,
+//      clip_loss == 0), automask + per-pixel min / mean over candidates (:225-253, :321-334)
+//  smoothness_{forward,backward}: utils/depth.py:165-198 + utils/image.py:85-113 + loss :276-278
+//
+// The reference runs this as ~1500 ATen launches moving 2.7 GB per image; here one scale is three launches
+// forward and three backward, each HBM-bound: every pixel's geometry lives in registers, SSIM windows are
+// staged through LDS tiles (reflect halo), and all scalar reductions are wave-shuffle -> LDS -> one fp64 atomic.
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+namespace pnsfm {
+
+__device__ __forceinline__ double block_sum_256d(double v, double* red) {
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+struct Cam {
+  float k[9];     // target intrinsics K (row major)
+  float ki[9];    // Kinv as the reference builds it (camera.py:72-80): K with 4 entries replaced
+  float rk[9];    // context ("ref") intrinsics
+};
+
+__device__ __forceinline__ void load_cam(const float* K, const float* refK, int b, Cam& c) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { c.k[i] = K[b * 9 + i]; c.rk[i] = refK[b * 9 + i]; c.ki[i] = c.k[i]; }
+  const float fx = c.k[0], fy = c.k[4], cx = c.k[2], cy = c.k[5];
+  c.ki[0] = 1.f / fx;
+  c.ki[4] = 1.f / fy;
+  c.ki[2] = -1.f * cx / fx;
+  c.ki[5] = -1.f * cy / fy;
+}
+
+struct Proj {
+  float X[3];      // 3-D point in the target camera frame
+  float ray[3];    // Kinv * [u, v, 1]
+  float d;         // depth
+  float Xr[3];     // point in the context camera frame
+  float p[3];      // refK * Xr
+  float z;         // clamped p.z
+  float ix, iy;    // un-normalised sampling coordinates
+};
+
+__device__ __forceinline__ void project_pixel(const Cam& c, const float* T, float rho, int u, int v, int H, int W, Proj& q) {
+  q.d = 1.f / fmaxf(rho, 1e-6f);
+  const float fu = (float)u, fv = (float)v;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    q.ray[i] = c.ki[3 * i + 0] * fu + c.ki[3 * i + 1] * fv + c.ki[3 * i + 2];
+    q.X[i] = q.ray[i] * q.d;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q.Xr[i] = T[4 * i + 0] * q.X[0] + T[4 * i + 1] * q.X[1] + T[4 * i + 2] * q.X[2] + T[4 * i + 3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q.p[i] = c.rk[3 * i + 0] * q.Xr[0] + c.rk[3 * i + 1] * q.Xr[1] + c.rk[3 * i + 2] * q.Xr[2];
+  q.z = fmaxf(q.p[2], 1e-5f);
+  const float xn = 2.f * (q.p[0] / q.z) / (float)(W - 1) - 1.f;
+  const float yn = 2.f * (q.p[1] / q.z) / (float)(H - 1) - 1.f;
+  q.ix = ((xn + 1.f) * 0.5f) * (float)(W - 1);
+  q.iy = ((yn + 1.f) * 0.5f) * (float)(H - 1);
+}
+
+// grid: (ceil(HW/256), B, J)
+__global__ void __launch_bounds__(256) view_synthesis_fwd_kernel(const float* __restrict__ inv_depth, const float* __restrict__ ref,
+                                                                  const float* __restrict__ K, const float* __restrict__ refK,
+                                                                  const float* __restrict__ T, float* __restrict__ warped,
+                                                                  int B, int H, int W) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, j = blockIdx.z;
+  if (pix >= HW) return;
+  Cam cam;
+  load_cam(K, refK, b, cam);
+  float Tm[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Tm[i] = T[((size_t)j * B + b) * 16 + i];
+  const int v = pix / W, u = pix - v * W;
+  Proj q;
+  project_pixel(cam, Tm, inv_depth[(size_t)b * HW + pix], u, v, H, W, q);
+  float out[3] = {0.f, 0.f, 0.f};
+  if (q.ix > -1.f && q.ix < (float)W && q.iy > -1.f && q.iy < (float)H) {
+    const float fx0 = floorf(q.ix), fy0 = floorf(q.iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float ax = q.ix - fx0, ay = q.iy - fy0;
+    const float wnw = (1.f - ax) * (1.f - ay), wne = ax * (1.f - ay), wsw = (1.f - ax) * ay, wse = ax * ay;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const float* rb = ref + ((size_t)j * B + b) * 3 * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* rc = rb + (size_t)c * HW;
+      float acc = 0.f;
+      if (vx0 && vy0) acc += rc[y0 * W + x0] * wnw;
+      if (vx1 && vy0) acc += rc[y0 * W + x1] * wne;
+      if (vx0 && vy1) acc += rc[y1 * W + x0] * wsw;
+      if (vx1 && vy1) acc += rc[y1 * W + x1] * wse;
+      out[c] = acc;
+    }
+  }
+  float* wb = warped + ((size_t)j * B + b) * 3 * HW + pix;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) wb[(size_t)c * HW] = out[c];
+}
+
+// grid: (ceil(HW/256), B). Loops over the J context images so that d_inv_depth needs no atomics.
+// ws: double[J*B*12] (zeroed by the caller) receives d(loss)/d(T[:3,:4]).
+__global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __restrict__ d_warped, const float* __restrict__ inv_depth,
+                                                                  const float* __restrict__ ref, const float* __restrict__ K,
+                                                                  const float* __restrict__ refK, const float* __restrict__ T,
+                                                                  float* __restrict__ d_inv_depth, double* __restrict__ ws,
+                                                                  int J, int B, int H, int W) {
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const bool active = pix < HW;
+  Cam cam;
+  load_cam(K, refK, b, cam);
+  const int v = active ? pix / W : 0, u = active ? pix - v * W : 0;
+  const float rho = active ? inv_depth[(size_t)b * HW + pix] : 1.f;
+  float g_rho = 0.f;
+  for (int j = 0; j < J; ++j) {
+    float Tm[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tm[i] = T[((size_t)j * B + b) * 16 + i];
+    float gT[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gT[i] = 0.f;
+    if (active) {
+      Proj q;
+      project_pixel(cam, Tm, rho, u, v, H, W, q);
+      float gix = 0.f, giy = 0.f;
+      if (q.ix > -1.f && q.ix < (float)W && q.iy > -1.f && q.iy < (float)H) {
+        const float fx0 = floorf(q.ix), fy0 = floorf(q.iy);
+        const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        const float ax = q.ix - fx0, ay = q.iy - fy0;
+        const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        const float* rb = ref + ((size_t)j * B + b) * 3 * HW;
+        const float* gb = d_warped + ((size_t)j * B + b) * 3 * HW + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* rc = rb + (size_t)c * HW;
+          const float g = gb[(size_t)c * HW];
+          const float nw = (vx0 && vy0) ? rc[y0 * W + x0] : 0.f;
+          const float ne = (vx1 && vy0) ? rc[y0 * W + x1] : 0.f;
+          const float sw = (vx0 && vy1) ? rc[y1 * W + x0] : 0.f;
+          const float se = (vx1 && vy1) ? rc[y1 * W + x1] : 0.f;
+          // d out / d ix = (ne - nw)(1-ay) + (se - sw) ay ;  d out / d iy = (sw - nw)(1-ax) + (se - ne) ax
+          gix += g * ((ne - nw) * (1.f - ay) + (se - sw) * ay);
+          giy += g * ((sw - nw) * (1.f - ax) + (se - ne) * ax);
+        }
+      }
+      // ix = p.x / z, iy = p.y / z (the (W-1)/2 factors of normalise/un-normalise cancel)
+      const float iz = 1.f / q.z;
+      float gp[3];
+      gp[0] = gix * iz;
+      gp[1] = giy * iz;
+      gp[2] = (q.p[2] >= 1e-5f) ? -(gix * q.p[0] + giy * q.p[1]) * iz * iz : 0.f;
+      float gXr[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gXr[i] = cam.rk[0 + i] * gp[0] + cam.rk[3 + i] * gp[1] + cam.rk[6 + i] * gp[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        gT[4 * i + 0] = gXr[i] * q.X[0];
+        gT[4 * i + 1] = gXr[i] * q.X[1];
+        gT[4 * i + 2] = gXr[i] * q.X[2];
+        gT[4 * i + 3] = gXr[i];
+      }
+      float gd = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float gX = Tm[0 + k] * gXr[0] + Tm[4 + k] * gXr[1] + Tm[8 + k] * gXr[2];
+        gd += q.ray[k] * gX;
+      }
+      if (rho >= 1e-6f) g_rho += -gd * q.d * q.d;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const double s = block_sum_256d((double)gT[i], red);
+      if (threadIdx.x == 0) atomicAdd(&ws[((size_t)j * B + b) * 12 + i], s);
+    }
+  }
+  if (active) d_inv_depth[(size_t)b * HW + pix] = g_rho;
+}
+
+__global__ void view_synthesis_bwd_finish_kernel(const double* __restrict__ ws, float* __restrict__ dT, int n_mats) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_mats * 16) {
+    const int m = i >> 4, e = i & 15;
+    dT[i] = e < 12 ? (float)ws[m * 12 + e] : 0.f;
+  }
+}
+
+// ---- SSIM / L1 photometric terms -------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // nn.ReflectionPad2d(1) index map, then clamped so far-outside tile padding never reads out of bounds
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  if (i < 0) i = 0;
+  if (i >= n) i = n - 1;
+  return i;
+}
+
+struct WinStats { float mx, my, sxx, syy, sxy; };
+
+// 3x3 mean statistics of (x, y) around LDS position `c` (row stride `S`)
+__device__ __forceinline__ WinStats win_stats(const float* xs, const float* ys, int c, int S) {
+  float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const float a = xs[c + dy * S + dx], b = ys[c + dy * S + dx];
+      sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+    }
+  WinStats w;
+  const float inv9 = 1.f / 9.f;
+  w.mx = sx * inv9; w.my = sy * inv9; w.sxx = sxx * inv9; w.syy = syy * inv9; w.sxy = sxy * inv9;
+  return w;
+}
+
+struct SsimTerms { float ssim, A1, A2, B1, B2; };
+
+__device__ __forceinline__ SsimTerms ssim_terms(const WinStats& w, float C1, float C2) {
+  SsimTerms t;
+  const float mxmy = w.mx * w.my, mx2 = w.mx * w.mx, my2 = w.my * w.my;
+  const float sig_x = w.sxx - mx2, sig_y = w.syy - my2, sig_xy = w.sxy - mxmy;
+  t.A1 = 2.f * mxmy + C1;
+  t.A2 = 2.f * sig_xy + C2;
+  t.B1 = mx2 + my2 + C1;
+  t.B2 = sig_x + sig_y + C2;
+  t.ssim = (t.A1 * t.A2) / (t.B1 * t.B2);
+  return t;
+}
+
+#define PH_T 16           // output tile edge
+#define PH_S1 (PH_T + 2)  // with 1-pixel halo
+#define PH_S2 (PH_T + 4)  // with 2-pixel halo
+
+// grid: (ceil(W/16), ceil(H/16), B); block 256 = 16x16 pixels. LDS: (1 + 2J) images x 3 ch x 18x18.
+__global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __restrict__ warped, const float* __restrict__ ref,
+                                                               const float* __restrict__ target, double* __restrict__ loss_sum,
+                                                               uint8_t* __restrict__ argmin, int J, int B, int H, int W,
+                                                               float ssim_w, float C1, float C2, int automask, int reduce_op) {
+  PNSFM_DYN_SMEM(float, smem);
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int b = blockIdx.z;
+  const int tx0 = blockIdx.x * PH_T, ty0 = blockIdx.y * PH_T;
+  const int plane = PH_S1 * PH_S1;
+  // image slots: 0 = target, 1+2j = warped[j], 2+2j = ref[j]
+  const int nimg = 1 + 2 * J;
+  for (int e = threadIdx.x; e < nimg * 3 * plane; e += 256) {
+    const int img = e / (3 * plane);
+    int r = e - img * 3 * plane;
+    const int c = r / plane;
+    r -= c * plane;
+    const int ly = r / PH_S1, lx = r - ly * PH_S1;
+    const int gy = reflect_idx(ty0 + ly - 1, H), gx = reflect_idx(tx0 + lx - 1, W);
+    const float* src;
+    if (img == 0) src = target + (size_t)b * 3 * HW;
+    else {
+      const int j = (img - 1) >> 1;
+      src = (((img - 1) & 1) ? ref : warped) + ((size_t)j * B + b) * 3 * HW;
+    }
+    float v = 0.f;
+    if (img == 0 || !(((img - 1) & 1) && !automask)) v = src[(size_t)c * HW + gy * W + gx];
+    smem[e] = v;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  const int gy = ty0 + ly, gx = tx0 + lx;
+  const bool valid = gy < H && gx < W;
+  const int cpos = (ly + 1) * PH_S1 + lx + 1;
+  float best = 0.f, sum = 0.f;
+  int best_i = 0, ncand = 0;
+  const float* tgt = smem;
+  for (int j = 0; j < J; ++j) {
+    for (int id = 0; id < (automask ? 2 : 1); ++id) {
+      const float* img = smem + (1 + 2 * j + id) * 3 * plane;
+      float ssim_acc = 0.f, l1_acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* xs = img + c * plane;
+        const float* ys = tgt + c * plane;
+        const WinStats w = win_stats(xs, ys, cpos, PH_S1);
+        const SsimTerms t = ssim_terms(w, C1, C2);
+        ssim_acc += fminf(fmaxf((1.f - t.ssim) * 0.5f, 0.f), 1.f);
+        l1_acc += fabsf(xs[cpos] - ys[cpos]);
+      }
+      const float l = ssim_w * (ssim_acc / 3.f) + (1.f - ssim_w) * (l1_acc / 3.f);
+      if (ncand == 0 || l < best) { best = l; best_i = ncand; }
+      sum += l;
+      ncand++;
+    }
+  }
+  float contrib = 0.f;
+  if (valid) {
+    contrib = reduce_op == 0 ? best : sum / (float)ncand;
+    if (reduce_op == 0) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)best_i;
+  }
+  const double s = block_sum_256d((double)contrib, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+}
+
+// grid as forward. LDS: (1 + J) images x 3 ch x 20x20  +  J x 3 ch x 3 coefficient planes x 18x18.
+// d ssim_p / d x_q = alpha_p + beta_p * y_q + gamma_p * x_q for q in the 3x3 window of p,
+// so the gradient at q is a (reflect-aware) 3x3 gather of three coefficient planes.
+__global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __restrict__ warped, const float* __restrict__ target,
+                                                               const uint8_t* __restrict__ argmin, float* __restrict__ d_warped,
+                                                               float grad_scale, int J, int B, int H, int W, float ssim_w,
+                                                               float C1, float C2, int automask, int reduce_op) {
+  PNSFM_DYN_SMEM(float, smem);
+  const int HW = H * W;
+  const int b = blockIdx.z;
+  const int tx0 = blockIdx.x * PH_T, ty0 = blockIdx.y * PH_T;
+  const int plane2 = PH_S2 * PH_S2, plane1 = PH_S1 * PH_S1;
+  float* imgs = smem;                           // [(1+J)][3][20*20]; slot 0 = target, 1+j = warped[j]
+  float* coef = smem + (1 + J) * 3 * plane2;    // [J][3 ch][3 (alpha,beta,gamma)][18*18]
+  for (int e = threadIdx.x; e < (1 + J) * 3 * plane2; e += 256) {
+    const int img = e / (3 * plane2);
+    int r = e - img * 3 * plane2;
+    const int c = r / plane2;
+    r -= c * plane2;
+    const int ly = r / PH_S2, lx = r - ly * PH_S2;
+    const int gy = reflect_idx(ty0 + ly - 2, H), gx = reflect_idx(tx0 + lx - 2, W);
+    const float* src = img == 0 ? target + (size_t)b * 3 * HW : warped + ((size_t)(img - 1) * B + b) * 3 * HW;
+    imgs[e] = src[(size_t)c * HW + gy * W + gx];
+  }
+  __syncthreads();
+  const int ncand = J * (automask ? 2 : 1);
+  // ---- coefficient planes at every p of the 18x18 region
+  for (int e = threadIdx.x; e < plane1; e += 256) {
+    const int ly = e / PH_S1, lx = e - ly * PH_S1;
+    const int py = ty0 + ly - 1, px = tx0 + lx - 1;
+    const bool inside = py >= 0 && py < H && px >= 0 && px < W;
+    const int cpos = (ly + 1) * PH_S2 + lx + 1;
+    int sel = -1;
+    if (inside && reduce_op == 0) sel = (int)argmin[(size_t)b * HW + py * W + px];
+    for (int j = 0; j < J; ++j) {
+      const int cand = j * (automask ? 2 : 1);
+      float up = 0.f;
+      if (inside) up = reduce_op == 0 ? (sel == cand ? grad_scale : 0.f) : grad_scale / (float)ncand;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float ca = 0.f, cb = 0.f, cg = 0.f;
+        if (up != 0.f) {
+          const float* xs = imgs + ((1 + j) * 3 + c) * plane2;
+          const float* ys = imgs + c * plane2;
+          const WinStats w = win_stats(xs, ys, cpos, PH_S2);
+          const SsimTerms t = ssim_terms(w, C1, C2);
+          const float L = (1.f - t.ssim) * 0.5f;
+          if (L >= 0.f && L <= 1.f) {
+            const float den = t.B1 * t.B2;
+            const float k = up * ssim_w * (1.f / 3.f) * (-0.5f) / (9.f * den);
+            ca = k * (2.f * w.my * t.A2 - 2.f * t.A1 * w.my - t.ssim * (2.f * w.mx * t.B2 - 2.f * t.B1 * w.mx));
+            cb = k * (2.f * t.A1);
+            cg = k * (-2.f * t.ssim * t.B1);
+          }
+        }
+        float* cp = coef + ((j * 3 + c) * 3) * plane1;
+        cp[0 * plane1 + e] = ca;
+        cp[1 * plane1 + e] = cb;
+        cp[2 * plane1 + e] = cg;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- gather at q
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  const int qy = ty0 + ly, qx = tx0 + lx;
+  if (qy >= H || qx >= W) return;
+  const int q2 = (ly + 2) * PH_S2 + lx + 2;
+  int selq = -1;
+  if (reduce_op == 0) selq = (int)argmin[(size_t)b * HW + qy * W + qx];
+  for (int j = 0; j < J; ++j) {
+    const int cand = j * (automask ? 2 : 1);
+    const float uq = reduce_op == 0 ? (selq == cand ? grad_scale : 0.f) : grad_scale / (float)ncand;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* cp = coef + ((j * 3 + c) * 3) * plane1;
+      float sa = 0.f, sb = 0.f, sg = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int py = qy + dy;
+        if (py < 0 || py >= H) continue;
+        const float my = 1.f + ((py == 0 && qy == 1) ? 1.f : 0.f) + ((py == H - 1 && qy == H - 2) ? 1.f : 0.f);
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int px = qx + dx;
+          if (px < 0 || px >= W) continue;
+          const float mx = 1.f + ((px == 0 && qx == 1) ? 1.f : 0.f) + ((px == W - 1 && qx == W - 2) ? 1.f : 0.f);
+          const float m = my * mx;
+          const int e = (ly + 1 + dy) * PH_S1 + lx + 1 + dx;
+          sa += m * cp[0 * plane1 + e];
+          sb += m * cp[1 * plane1 + e];
+          sg += m * cp[2 * plane1 + e];
+        }
+      }
+      const float xq = imgs[((1 + j) * 3 + c) * plane2 + q2];
+      const float yq = imgs[c * plane2 + q2];
+      float g = sa + sb * yq + sg * xq;
+      const float diff = xq - yq;
+      const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+      g += uq * (1.f - ssim_w) * (1.f / 3.f) * sgn;
+      d_warped[(((size_t)j * B + b) * 3 + c) * HW + qy * W + qx] = g;
+    }
+  }
+}
+
+// ---- smoothness ------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_weight(const float* img, size_t HW, int i0, int i1) {
+  const float s = fabsf(img[i0] - img[i1]) + fabsf(img[HW + i0] - img[HW + i1]) + fabsf(img[2 * HW + i0] - img[2 * HW + i1]);
+  return expf(-(s / 3.f));
+}
+
+// grid: (ceil(HW/256), B)
+__global__ void __launch_bounds__(256) smoothness_fwd_kernel(const float* __restrict__ inv, const float* __restrict__ image,
+                                                              double* __restrict__ sums, int H, int W) {
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  float sx = 0.f, sy = 0.f;
+  if (pix < HW) {
+    const int y = pix / W, x = pix - y * W;
+    const float* ib = inv + (size_t)b * HW;
+    const float* im = image + (size_t)b * 3 * HW;
+    const float r = ib[pix];
+    if (x + 1 < W) sx = fabsf((r - ib[pix + 1]) * edge_weight(im, HW, pix, pix + 1));
+    if (y + 1 < H) sy = fabsf((r - ib[pix + W]) * edge_weight(im, HW, pix, pix + W));
+  }
+  const double tx = block_sum_256d((double)sx, red);
+  const double ty = block_sum_256d((double)sy, red);
+  if (threadIdx.x == 0) { atomicAdd(&sums[0], tx); atomicAdd(&sums[1], ty); }
+}
+
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(256) smoothness_bwd_kernel(const float* __restrict__ inv, const float* __restrict__ image,
+                                                              float* __restrict__ d_inv, float gx, float gy, int H, int W) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= HW) return;
+  const int y = pix / W, x = pix - y * W;
+  const float* ib = inv + (size_t)b * HW;
+  const float* im = image + (size_t)b * 3 * HW;
+  const float r = ib[pix];
+  float g = 0.f;
+  if (x + 1 < W) { const float w = edge_weight(im, HW, pix, pix + 1); g += gx * sgnf((r - ib[pix + 1]) * w) * w; }
+  if (x >= 1)    { const float w = edge_weight(im, HW, pix - 1, pix); g -= gx * sgnf((ib[pix - 1] - r) * w) * w; }
+  if (y + 1 < H) { const float w = edge_weight(im, HW, pix, pix + W); g += gy * sgnf((r - ib[pix + W]) * w) * w; }
+  if (y >= 1)    { const float w = edge_weight(im, HW, pix - W, pix); g -= gy * sgnf((ib[pix - W] - r) * w) * w; }
+  d_inv[(size_t)b * HW + pix] = g;
+}
+
+}  // namespace pnsfm
+
+using namespace pnsfm;
+
+extern "C" {
+
+int pnsfm_view_synthesis_forward(const float* inv_depth, const float* ref, const float* K, const float* refK, const float* T,
+                                 float* warped, int J, int B, int H, int W, void* stream) {
+  if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_forward: bad shape"); return -1; }
+  dim3 grid(ceil_div(H * W, 256), B, J);
+  PNSFM_LAUNCH(view_synthesis_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, inv_depth, ref, K, refK, T, warped, B, H, W);
+  return check_launch("view_synthesis_forward");
+}
+
+int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth, const float* ref, const float* K,
+                                  const float* refK, const float* T, float* d_inv_depth, float* dT, double* ws, int J, int B,
+                                  int H, int W, void* stream) {
+  if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_backward: bad shape"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  int e = (int)hipMemsetAsync(ws, 0, (size_t)J * B * 12 * sizeof(double), s);
+  if (e) { set_error("view_synthesis_backward: memset failed"); return e; }
+  dim3 grid(ceil_div(H * W, 256), B);
+  PNSFM_LAUNCH(view_synthesis_bwd_kernel, grid, dim3(256), 0, s, d_warped, inv_depth, ref, K, refK, T, d_inv_depth, ws, J, B, H, W);
+  e = check_launch("view_synthesis_backward");
+  if (e) return e;
+  PNSFM_LAUNCH(view_synthesis_bwd_finish_kernel, dim3(ceil_div(J * B * 16, 256)), dim3(256), 0, s, (const double*)ws, dT, J * B);
+  return check_launch("view_synthesis_backward_finish");
+}
+
+int pnsfm_photometric_forward(const float* warped, const float* ref, const float* target, double* loss_sum, uint8_t* argmin,
+                              int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
+                              void* stream) {
+  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
+  if (!(ssim_weight > 0.f)) { set_error("photometric_forward: ssim_weight must be > 0"); return -1; }
+  if (automask && reduce_op != 0) { set_error("photometric_forward: automask requires the 'min' reduce op"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  int e = (int)hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+  if (e) { set_error("photometric_forward: memset failed"); return e; }
+  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+               C1, C2, automask, reduce_op);
+  return check_launch("photometric_forward");
+}
+
+int pnsfm_photometric_backward(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
+                               float grad_scale, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
+                               int automask, int reduce_op, void* stream) {
+  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_backward: bad shape (J<=3)"); return -1; }
+  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
+  PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, warped, target, argmin, d_warped,
+               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op);
+  return check_launch("photometric_backward");
+}
+
+int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums, int B, int H, int W, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int e = (int)hipMemsetAsync(sums, 0, 2 * sizeof(double), s);
+  if (e) { set_error("smoothness_forward: memset failed"); return e; }
+  PNSFM_LAUNCH(smoothness_fwd_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), 0, s, inv_norm, image, sums, H, W);
+  return check_launch("smoothness_forward");
+}
+
+int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* d_inv_norm, float gx, float gy, int B, int H,
+                              int W, void* stream) {
+  PNSFM_LAUNCH(smoothness_bwd_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, inv_norm, image,
+               d_inv_norm, gx, gy, H, W);
+  return check_launch("smoothness_backward");
+}
+
+}  // extern "C"

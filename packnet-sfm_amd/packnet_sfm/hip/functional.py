@@ -1,0 +1,262 @@
+"""torch.autograd bindings of the gfx950 kernels (forward AND hand-written backward kernels).
+
+These Functions are what the drop-in modules (networks/layers/packnet/layers01.py,
+losses/multiview_photometric_loss.py) are made of.  Autograd only sequences the launches; every derivative
+is computed by a HIP kernel of libpnsfm_hip.so.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+# bumped by optimizers that update parameters through raw pointers (bypassing tensor._version)
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
+class PackedConvWeight:
+    """Per-layer cache of the MFMA-friendly weight layouts ([k*k][K][M], see csrc/conv2d.hip).
+
+    Re-packed only when the parameter changed (tensor version / storage / optimizer epoch), so eval loops and the
+    backward pass of the same step reuse the buffers.  Cost when stale: one read + two writes of the weight.
+    """
+
+    def __init__(self):
+        self.wp_fwd = None
+        self.wp_bwd = None
+        self.key_fwd = None
+        self.key_bwd = None
+
+    def get(self, weight, need_bwd):
+        key = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
+        do_f = self.key_fwd != key
+        do_b = need_bwd and self.key_bwd != key
+        if do_f or do_b:
+            w = weight.detach()
+            if do_f and self.wp_fwd is not None and (self.wp_fwd.device != w.device):
+                self.wp_fwd = None
+            if do_b and self.wp_bwd is not None and (self.wp_bwd.device != w.device):
+                self.wp_bwd = None
+            f, b = ops.conv2d_pack(w.contiguous(), self.wp_fwd if do_f else None, self.wp_bwd if do_b else None,
+                                   want_fwd=do_f, want_bwd=do_b)
+            if do_f:
+                self.wp_fwd, self.key_fwd = f, key
+            if do_b:
+                self.wp_bwd, self.key_bwd = b, key
+        return self.wp_fwd, (self.wp_bwd if need_bwd else None)
+
+
+class Conv2dFn(Function):
+    """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (exact-fp32 MFMA implicit GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        x = x.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        wp_fwd, wp_bwd = cache.get(weight, need_dx)
+        Cout, Cin, ks, _ = weight.shape
+        if x.shape[1] != Cin:
+            raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], Cin))
+        y = ops.conv2d_forward(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
+        ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
+        ctx.meta = (Cin, Cout, ks, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wp_bwd = ctx.saved_tensors
+        Cin, Cout, ks, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias)
+        return dx, dw, db, None
+
+
+def conv2d(x, weight, bias, cache):
+    return Conv2dFn.apply(x, weight, bias, cache)
+
+
+class GroupNormActFn(Function):
+    """y = act(GroupNorm_G(x [+ res]))."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, G, eps, act):
+        x = x.contiguous()
+        res = res.contiguous() if res is not None else None
+        y, mean, rstd = ops.groupnorm_act_forward(x, res, gamma.detach(), beta.detach(), G, eps, act)
+        ctx.save_for_backward(x, res if res is not None else x.new_empty(0), gamma, beta, mean, rstd)
+        ctx.meta = (G, act, res is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, res, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, act, has_res = ctx.meta
+        dx, dgamma, dbeta = ops.groupnorm_act_backward(dy.contiguous(), x, res if has_res else None, gamma.detach(), beta.detach(),
+                                                       mean, rstd, G, act)
+        return dx, (dx if has_res else None), dgamma, dbeta, None, None, None
+
+
+def groupnorm_act(x, gamma, beta, G=16, eps=1e-5, act=ops.ACT_ELU, res=None):
+    return GroupNormActFn.apply(x, res, gamma, beta, G, eps, act)
+
+
+class SpaceToDepthFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.space_to_depth(x.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.depth_to_space(dy.contiguous())
+
+
+class DepthToSpaceFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.depth_to_space(x.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.space_to_depth(dy.contiguous())
+
+
+def space_to_depth(x):
+    return SpaceToDepthFn.apply(x)
+
+
+def depth_to_space(x):
+    return DepthToSpaceFn.apply(x)
+
+
+class Conv3d1to8Fn(Function):
+    """[B,D,H,W] -> [B,8*D,H,W]: Conv3d(1,8,3,pad 1) over (channel,y,x), channel index f*D+d."""
+
+    @staticmethod
+    def forward(ctx, p, w3, b3):
+        p = p.contiguous()
+        out = ops.conv3d_forward(p, w3.detach().contiguous(), b3.detach().contiguous())
+        ctx.save_for_backward(p, w3)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        p, w3 = ctx.saved_tensors
+        dout = dout.contiguous()
+        dp = dw3 = db3 = None
+        if ctx.needs_input_grad[0]:
+            dp = ops.conv3d_backward_data(dout, w3.detach().contiguous())
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw3, db3 = ops.conv3d_backward_weight(p, dout)
+        return dp, dw3, db3
+
+
+def conv3d_1to8(p, w3, b3):
+    return Conv3d1to8Fn.apply(p, w3, b3)
+
+
+class InvDepthActFn(Function):
+    @staticmethod
+    def forward(ctx, x, min_depth):
+        y = ops.invdepth_act_forward(x.contiguous(), min_depth)
+        ctx.save_for_backward(y)
+        ctx.min_depth = min_depth
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.invdepth_act_backward(dy.contiguous(), y, ctx.min_depth), None
+
+
+def invdepth_act(x, min_depth):
+    return InvDepthActFn.apply(x, min_depth)
+
+
+class ViewSynthesisFn(Function):
+    """warped[j] = grid_sample(ref[j], project(reconstruct(1/inv_depth))) for the J context views of one scale.
+    Differentiable w.r.t. inv_depth and the [J,B,4,4] pose matrices (the context image is data)."""
+
+    @staticmethod
+    def forward(ctx, inv_depth, ref, K, refK, T):
+        inv_depth, ref, K, refK, T = (t.contiguous() for t in (inv_depth, ref, K, refK, T))
+        warped = ops.view_synthesis_forward(inv_depth, ref, K, refK, T.detach())
+        ctx.save_for_backward(inv_depth, ref, K, refK, T)
+        return warped
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_warped):
+        inv_depth, ref, K, refK, T = ctx.saved_tensors
+        d_inv, dT = ops.view_synthesis_backward(d_warped.contiguous(), inv_depth, ref, K, refK, T.detach())
+        return d_inv, None, None, None, dT
+
+
+def view_synthesis(inv_depth, ref, K, refK, T):
+    return ViewSynthesisFn.apply(inv_depth, ref, K, refK, T)
+
+
+REDUCE_MIN, REDUCE_MEAN = 0, 1
+
+
+class PhotometricFn(Function):
+    """mean over pixels of min/mean over candidates of (w*SSIM-loss + (1-w)*L1); scalar float32."""
+
+    @staticmethod
+    def forward(ctx, warped, ref, target, ssim_w, C1, C2, automask, reduce_op):
+        warped, ref, target = warped.contiguous(), ref.contiguous(), target.contiguous()
+        loss_sum, argmin = ops.photometric_forward(warped, ref, target, ssim_w, C1, C2, automask, reduce_op)
+        J, B, _, H, W = warped.shape
+        ctx.save_for_backward(warped, target, argmin)
+        ctx.meta = (ssim_w, C1, C2, automask, reduce_op, B * H * W)
+        return (loss_sum / float(B * H * W)).to(torch.float32).reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        warped, target, argmin = ctx.saved_tensors
+        ssim_w, C1, C2, automask, reduce_op, n = ctx.meta
+        d = ops.photometric_backward(warped, target, argmin, 1.0 / n, ssim_w, C1, C2, automask, reduce_op)
+        return d * g, None, None, None, None, None, None, None
+
+
+def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op):
+    return PhotometricFn.apply(warped, ref, target, ssim_w, C1, C2, automask, reduce_op)
+
+
+class SmoothnessFn(Function):
+    """mean|Sx| + mean|Sy| of the edge-aware first differences of a (mean-normalised) inverse depth map."""
+
+    @staticmethod
+    def forward(ctx, inv_norm, image):
+        inv_norm, image = inv_norm.contiguous(), image.contiguous()
+        B, _, H, W = image.shape
+        sums = ops.smoothness_forward(inv_norm, image)
+        ctx.save_for_backward(inv_norm, image)
+        nx, ny = float(B * H * (W - 1)), float(B * (H - 1) * W)
+        ctx.meta = (nx, ny)
+        return (sums[0] / nx + sums[1] / ny).to(torch.float32).reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        inv_norm, image = ctx.saved_tensors
+        nx, ny = ctx.meta
+        return ops.smoothness_backward(inv_norm, image, 1.0 / nx, 1.0 / ny) * g, None
+
+
+def smoothness(inv_norm, image):
+    return SmoothnessFn.apply(inv_norm, image)

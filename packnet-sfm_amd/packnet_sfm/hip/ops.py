@@ -1,0 +1,275 @@
+"""Tensor-level wrappers over the C ABI of libpnsfm_hip.so (no autograd here; see functional.py).
+
+Every wrapper validates dtype / contiguity / device, allocates outputs with torch (PyTorch is the device
+allocator and stream owner -- plumbing, not compute) and enqueues the HIP kernels on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else ctypes.c_void_p(0)
+
+
+def _chk(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if _lib.REQUIRE_CUDA and not t.is_cuda:
+            raise RuntimeError("packnet_sfm HIP op got a %s tensor: the HIP kernels run on MI355X only, "
+                               "there is no CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("packnet_sfm HIP op needs contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("packnet_sfm HIP op got tensors on different devices")
+
+
+def _f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("packnet_sfm HIP op needs float32 tensors, got %s" % t.dtype)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------------------------- conv2d
+def conv2d_packed_sizes(Cin, Cout, ks):
+    lib = _lib.get()
+    return (int(lib.pnsfm_conv2d_packed_elems_fwd(Cin, Cout, ks)), int(lib.pnsfm_conv2d_packed_elems_bwd(Cin, Cout, ks)))
+
+
+def conv2d_pack(w, wp_fwd=None, wp_bwd=None, want_fwd=True, want_bwd=True):
+    """w: [Cout, Cin, k, k] (reference layout) -> packed forward / backward-data weights."""
+    _chk(w, wp_fwd, wp_bwd); _f32(w)
+    Cout, Cin, ks, ks2 = w.shape
+    assert ks == ks2
+    nf, nb = conv2d_packed_sizes(Cin, Cout, ks)
+    if want_fwd and wp_fwd is None:
+        wp_fwd = torch.empty(nf, dtype=torch.float32, device=w.device)
+    if want_bwd and wp_bwd is None:
+        wp_bwd = torch.empty(nb, dtype=torch.float32, device=w.device)
+    rc = _lib.get().pnsfm_conv2d_pack_weights(_ptr(w), _ptr(wp_fwd if want_fwd else None),
+                                              _ptr(wp_bwd if want_bwd else None), Cin, Cout, ks, _stream(w))
+    _lib.check(rc, "conv2d_pack_weights")
+    return wp_fwd, wp_bwd
+
+
+def conv2d_forward(x, wp_fwd, bias, Cout, ks):
+    _chk(x, wp_fwd, bias); _f32(x, wp_fwd, bias)
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.get().pnsfm_conv2d_forward(_ptr(x), _ptr(wp_fwd), _ptr(bias), _ptr(y), B, Cin, Cout, H, W, ks, _stream(x))
+    _lib.check(rc, "conv2d_forward")
+    return y
+
+
+def conv2d_backward_data(dy, wp_bwd, Cin, ks):
+    _chk(dy, wp_bwd); _f32(dy, wp_bwd)
+    B, Cout, H, W = dy.shape
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    rc = _lib.get().pnsfm_conv2d_backward_data(_ptr(dy), _ptr(wp_bwd), _ptr(dx), B, Cin, Cout, H, W, ks, _stream(dy))
+    _lib.check(rc, "conv2d_backward_data")
+    return dx
+
+
+def conv2d_backward_weight(x, dy, ks, want_bias=True):
+    _chk(x, dy); _f32(x, dy)
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    rc = _lib.get().pnsfm_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, ks, _stream(x))
+    _lib.check(rc, "conv2d_backward_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------- groupnorm
+ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
+
+
+def groupnorm_act_forward(x, res, gamma, beta, G, eps, act):
+    _chk(x, res, gamma, beta); _f32(x, res, gamma, beta)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    mean = torch.empty((B * G,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((B * G,), dtype=torch.float32, device=x.device)
+    ws = torch.empty((2 * B * G,), dtype=torch.float64, device=x.device)
+    rc = _lib.get().pnsfm_groupnorm_act_forward(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                                _ptr(ws), B, C, HW, G, float(eps), act, _stream(x))
+    _lib.check(rc, "groupnorm_act_forward")
+    return y, mean, rstd
+
+
+def groupnorm_act_backward(dy, x, res, gamma, beta, mean, rstd, G, act):
+    _chk(dy, x, res, gamma, beta, mean, rstd); _f32(dy, x, res, gamma, beta, mean, rstd)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    ws = torch.empty((2 * B * C,), dtype=torch.float64, device=x.device)
+    rc = _lib.get().pnsfm_groupnorm_act_backward(_ptr(dy), _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                                                 _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, C, HW, G, act, _stream(x))
+    _lib.check(rc, "groupnorm_act_backward")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------ packing / conv3d
+def space_to_depth(x):
+    _chk(x); _f32(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, 4 * C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.get().pnsfm_space_to_depth(_ptr(x), _ptr(y), B, C, H, W, _stream(x)), "space_to_depth")
+    return y
+
+
+def depth_to_space(x):
+    _chk(x); _f32(x)
+    B, C4, H, W = x.shape
+    assert C4 % 4 == 0
+    C = C4 // 4
+    y = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.get().pnsfm_depth_to_space(_ptr(x), _ptr(y), B, C, H, W, _stream(x)), "depth_to_space")
+    return y
+
+
+def conv3d_forward(p, w3, b3):
+    _chk(p, w3, b3); _f32(p, w3, b3)
+    B, D, H, W = p.shape
+    out = torch.empty((B, 8 * D, H, W), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.get().pnsfm_conv3d_1to8_forward(_ptr(p), _ptr(w3), _ptr(b3), _ptr(out), B, D, H, W, _stream(p)),
+               "conv3d_forward")
+    return out
+
+
+def conv3d_backward_data(dout, w3):
+    _chk(dout, w3); _f32(dout, w3)
+    B, D8, H, W = dout.shape
+    D = D8 // 8
+    dp = torch.empty((B, D, H, W), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.get().pnsfm_conv3d_1to8_backward_data(_ptr(dout), _ptr(w3), _ptr(dp), B, D, H, W, _stream(dout)),
+               "conv3d_backward_data")
+    return dp
+
+
+def conv3d_backward_weight(p, dout):
+    _chk(p, dout); _f32(p, dout)
+    B, D, H, W = p.shape
+    dw3 = torch.empty((8, 1, 3, 3, 3), dtype=torch.float32, device=p.device)
+    db3 = torch.empty((8,), dtype=torch.float32, device=p.device)
+    ws = torch.empty((8 * 28,), dtype=torch.float64, device=p.device)
+    _lib.check(_lib.get().pnsfm_conv3d_1to8_backward_weight(_ptr(p), _ptr(dout), _ptr(dw3), _ptr(db3), _ptr(ws), B, D, H, W,
+                                                            _stream(p)), "conv3d_backward_weight")
+    return dw3, db3
+
+
+# ------------------------------------------------------------------------------------------ invdepth
+def invdepth_act_forward(x, min_depth):
+    _chk(x); _f32(x)
+    y = torch.empty_like(x)
+    _lib.check(_lib.get().pnsfm_invdepth_act_forward(_ptr(x), _ptr(y), x.numel(), float(min_depth), _stream(x)),
+               "invdepth_act_forward")
+    return y
+
+
+def invdepth_act_backward(dy, y, min_depth):
+    _chk(dy, y); _f32(dy, y)
+    dx = torch.empty_like(y)
+    _lib.check(_lib.get().pnsfm_invdepth_act_backward(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), float(min_depth), _stream(y)),
+               "invdepth_act_backward")
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def view_synthesis_forward(inv_depth, ref, K, refK, T):
+    """inv_depth [B,1,H,W]; ref [J,B,3,H,W]; K, refK [B,3,3]; T [J,B,4,4] -> warped [J,B,3,H,W]."""
+    _chk(inv_depth, ref, K, refK, T); _f32(inv_depth, ref, K, refK, T)
+    J, B, _, H, W = ref.shape
+    warped = torch.empty_like(ref)
+    _lib.check(_lib.get().pnsfm_view_synthesis_forward(_ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK), _ptr(T), _ptr(warped),
+                                                       J, B, H, W, _stream(ref)), "view_synthesis_forward")
+    return warped
+
+
+def view_synthesis_backward(d_warped, inv_depth, ref, K, refK, T):
+    _chk(d_warped, inv_depth, ref, K, refK, T); _f32(d_warped, inv_depth, ref, K, refK, T)
+    J, B, _, H, W = ref.shape
+    d_inv = torch.empty_like(inv_depth)
+    dT = torch.empty_like(T)
+    ws = torch.empty((J * B * 12,), dtype=torch.float64, device=ref.device)
+    _lib.check(_lib.get().pnsfm_view_synthesis_backward(_ptr(d_warped), _ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK), _ptr(T),
+                                                        _ptr(d_inv), _ptr(dT), _ptr(ws), J, B, H, W, _stream(ref)),
+               "view_synthesis_backward")
+    return d_inv, dT
+
+
+def photometric_forward(warped, ref, target, ssim_weight, C1, C2, automask, reduce_op):
+    """-> (loss_sum float64[1], argmin uint8[B,H,W])."""
+    _chk(warped, ref, target); _f32(warped, ref, target)
+    J, B, _, H, W = warped.shape
+    loss_sum = torch.empty((1,), dtype=torch.float64, device=warped.device)
+    argmin = torch.empty((B, H, W), dtype=torch.uint8, device=warped.device)
+    _lib.check(_lib.get().pnsfm_photometric_forward(_ptr(warped), _ptr(ref), _ptr(target), _ptr(loss_sum), _ptr(argmin), J, B, H,
+                                                    W, float(ssim_weight), float(C1), float(C2), int(automask), int(reduce_op),
+                                                    _stream(warped)), "photometric_forward")
+    return loss_sum, argmin
+
+
+def photometric_backward(warped, target, argmin, grad_scale, ssim_weight, C1, C2, automask, reduce_op):
+    _chk(warped, target, argmin); _f32(warped, target)
+    J, B, _, H, W = warped.shape
+    d_warped = torch.empty_like(warped)
+    _lib.check(_lib.get().pnsfm_photometric_backward(_ptr(warped), _ptr(target), _ptr(argmin), _ptr(d_warped), float(grad_scale),
+                                                     J, B, H, W, float(ssim_weight), float(C1), float(C2), int(automask),
+                                                     int(reduce_op), _stream(warped)), "photometric_backward")
+    return d_warped
+
+
+def smoothness_forward(inv_norm, image):
+    _chk(inv_norm, image); _f32(inv_norm, image)
+    B, _, H, W = image.shape
+    sums = torch.empty((2,), dtype=torch.float64, device=image.device)
+    _lib.check(_lib.get().pnsfm_smoothness_forward(_ptr(inv_norm), _ptr(image), _ptr(sums), B, H, W, _stream(image)),
+               "smoothness_forward")
+    return sums
+
+
+def smoothness_backward(inv_norm, image, gx, gy):
+    _chk(inv_norm, image); _f32(inv_norm, image)
+    B, _, H, W = image.shape
+    d = torch.empty_like(inv_norm)
+    _lib.check(_lib.get().pnsfm_smoothness_backward(_ptr(inv_norm), _ptr(image), _ptr(d), float(gx), float(gy), B, H, W,
+                                                    _stream(image)), "smoothness_backward")
+    return d
+
+
+# ---------------------------------------------------------------------------------------------- adam
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    _chk(param, grad, exp_avg, exp_avg_sq); _f32(param, grad, exp_avg, exp_avg_sq)
+    _lib.check(_lib.get().pnsfm_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                                          float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale),
+                                          int(step), _stream(param)), "adam_step")
+
+
+# ---------------------------------------------------------------------------------------------- prof
+def prof_enable(on):
+    _lib.get().pnsfm_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    _lib.get().pnsfm_prof_reset()
+
+
+def prof_collect(kind):
+    ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_longlong(0)
+    _lib.get().pnsfm_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+    return ms.value, fl.value, n.value

@@ -1,0 +1,93 @@
+"""PackNet01 (3D packing/unpacking encoder-decoder, CVPR'20) on hand-written MI355X kernels.
+
+Drop-in for the reference's packnet_sfm/networks/depth/PackNet01.py: resolved by name through
+`load_class('PackNet01', ['packnet_sfm.networks.depth'])`, constructed as `PackNet01(dropout=..., version='1A')`,
+called as `net(rgb=...)`, returns {'inv_depths': [4 scales]} in training and {'inv_depths': tensor} in eval
+(reference :178-185), and owns exactly the reference's 216 parameter tensors under the same names.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from packnet_sfm.networks.layers.packnet.layers01 import Conv2D, InvDepth, PackLayerConv3d, ResidualBlock, UnpackLayerConv3d
+
+
+class PackNet01(nn.Module):
+    """
+    Parameters
+    ----------
+    dropout : float
+        Dropout on the residual shortcuts (0/None disables it)
+    version : str
+        'XY': X unused, Y = 'A' (skip connections concatenated) or 'B' (added)
+    """
+
+    def __init__(self, dropout=None, version=None, **kwargs):
+        super().__init__()
+        if version is None or version[1:] not in ('A', 'B'):
+            raise ValueError('Unknown PackNet version {}'.format(version))
+        self.version = version[1:]
+        concat = self.version == 'A'
+        ni, no = 64, 1                          # stem width, inverse-depth channels
+        n = [64, 64, 128, 256, 512]             # encoder widths n1..n5
+        blocks = [2, 2, 3, 3]
+        pack_k = [5, 3, 3, 3, 3]
+        if concat:
+            dec_out = list(n)
+            dec_in = [n[0] + ni + no, n[1] + n[0] + no, n[2] + n[1] + no, n[3] + n[2], n[4] + n[3]]
+        else:
+            dec_out = [n[0], n[1], n[2] // 2, n[3] // 2, n[4] // 2]
+            dec_in = [n[0] + no, n[1] + no, n[2] // 2 + no, n[3] // 2, n[4] // 2]
+
+        # registration order follows the reference so that identical seeds give identical initial weights
+        self.pre_calc = Conv2D(3, ni, 5, 1)
+        for i in range(5):
+            setattr(self, 'pack%d' % (i + 1), PackLayerConv3d(n[i], pack_k[i]))
+        self.conv1 = Conv2D(ni, n[0], 7, 1)
+        for i in range(4):
+            setattr(self, 'conv%d' % (i + 2), ResidualBlock(n[i], n[i + 1], blocks[i], 1, dropout=dropout))
+        unpack_in = [n[1], n[2], n[3], n[4], n[4]]   # inputs of unpack1..unpack5
+        for i in (4, 3, 2, 1, 0):
+            setattr(self, 'unpack%d' % (i + 1), UnpackLayerConv3d(unpack_in[i], dec_out[i], 3))
+        for i in (4, 3, 2, 1, 0):
+            setattr(self, 'iconv%d' % (i + 1), Conv2D(dec_in[i], n[i], 3, 1))
+        for i in (3, 2, 1, 0):
+            setattr(self, 'disp%d_layer' % (i + 1), InvDepth(n[i], out_channels=no))
+        self.init_weights()
+
+    def init_weights(self):
+        """Xavier-uniform conv weights, zero conv biases (GroupNorm keeps (1, 0))."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+    def _merge(self, up, skip, disp=None):
+        feat = torch.cat((up, skip), 1) if self.version == 'A' else up + skip
+        if disp is not None:
+            feat = torch.cat((feat, F.interpolate(disp, scale_factor=2, mode='nearest')), 1)
+        return feat
+
+    def forward(self, rgb):
+        """Inverse depth maps: list of 4 scales (training) or the full-resolution map (eval)."""
+        x = self.pre_calc(rgb)
+        x1p = self.pack1(self.conv1(x))
+        x2p = self.pack2(self.conv2(x1p))
+        x3p = self.pack3(self.conv3(x2p))
+        x4p = self.pack4(self.conv4(x3p))
+        x5p = self.pack5(self.conv5(x4p))
+
+        iconv5 = self.iconv5(self._merge(self.unpack5(x5p), x4p))
+        iconv4 = self.iconv4(self._merge(self.unpack4(iconv5), x3p))
+        disp4 = self.disp4_layer(iconv4)
+        iconv3 = self.iconv3(self._merge(self.unpack3(iconv4), x2p, disp4))
+        disp3 = self.disp3_layer(iconv3)
+        iconv2 = self.iconv2(self._merge(self.unpack2(iconv3), x1p, disp3))
+        disp2 = self.disp2_layer(iconv2)
+        iconv1 = self.iconv1(self._merge(self.unpack1(iconv2), x, disp2))
+        disp1 = self.disp1_layer(iconv1)
+
+        if self.training:
+            return {'inv_depths': [disp1, disp2, disp3, disp4]}
+        return {'inv_depths': disp1}

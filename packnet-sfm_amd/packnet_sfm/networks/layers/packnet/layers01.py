@@ -1,0 +1,157 @@
+"""PackNet building blocks, MI355X edition.
+
+Same class names, constructor signatures and parameter (state-dict) names as the reference's
+packnet_sfm/networks/layers/packnet/layers01.py, so `PackNet01`, checkpoints and the dynamic loader keep working;
+but every `forward` is a sequence of hand-written gfx950 kernels (packnet_sfm.hip.functional) instead of ATen ops:
+
+    Conv2D            -> exact-fp32 MFMA implicit-GEMM conv  +  fused GroupNorm(16)+ELU          (ref :10-37)
+    ResidualConv      -> 3 convs + GroupNorm/ELU with the residual add folded into the norm      (ref :40-72)
+    InvDepth          -> conv + fused sigmoid/min_depth                                          (ref :98-122)
+    PackLayerConv3d   -> space_to_depth, Conv3d(1->8) stencil, conv, GroupNorm+ELU               (ref :213-247)
+    UnpackLayerConv3d -> conv, GroupNorm+ELU, Conv3d(1->8) stencil, depth_to_space               (ref :250-286)
+
+torch.nn.Conv2d / Conv3d / GroupNorm objects are kept purely as *parameter containers* (identical names, shapes
+and default initialisation order as the reference); their ATen forward is never called.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from packnet_sfm.hip import functional as HF
+from packnet_sfm.hip import ops as _ops
+
+
+class _HipConv2d(nn.Conv2d):
+    """nn.Conv2d parameters, HIP forward (stride 1, 'same' zero padding k//2)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1):
+        if stride != 1:
+            raise NotImplementedError('the gfx950 conv kernel implements stride 1 only (all PackNet01 convs)')
+        super().__init__(in_channels, out_channels, kernel_size=kernel_size, stride=stride)
+        self._packed = HF.PackedConvWeight()
+
+    def forward(self, x):
+        return HF.conv2d(x, self.weight, self.bias, self._packed)
+
+
+class Conv2D(nn.Module):
+    """2D convolution (zero 'same' padding) + GroupNorm(16) + ELU."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv_base = _HipConv2d(in_channels, out_channels, kernel_size, stride)
+        self.normalize = nn.GroupNorm(16, out_channels)
+
+    def forward(self, x):
+        y = self.conv_base(x)
+        return HF.groupnorm_act(y, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU)
+
+
+class ResidualConv(nn.Module):
+    """Two Conv2D blocks plus a 1x1 shortcut; ELU(GroupNorm(main + shortcut))."""
+
+    def __init__(self, in_channels, out_channels, stride, dropout=None):
+        super().__init__()
+        self.conv1 = Conv2D(in_channels, out_channels, 3, stride)
+        self.conv2 = Conv2D(out_channels, out_channels, 3, 1)
+        self.conv3 = _HipConv2d(in_channels, out_channels, 1, stride)
+        self.normalize = nn.GroupNorm(16, out_channels)
+        self.dropout = dropout if dropout else None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # reference checkpoints trained with dropout hold the shortcut as nn.Sequential(conv3, Dropout2d): conv3.0.*
+        for name in ('weight', 'bias'):
+            old = prefix + 'conv3.0.' + name
+            if old in state_dict:
+                state_dict[prefix + 'conv3.' + name] = state_dict.pop(old)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x):
+        main = self.conv2(self.conv1(x))
+        shortcut = self.conv3(x)
+        if self.dropout and self.training:
+            shortcut = F.dropout2d(shortcut, self.dropout, True)
+        return HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
+                                res=shortcut)
+
+
+def ResidualBlock(in_channels, out_channels, num_blocks, stride, dropout=None):
+    """`num_blocks` ResidualConv layers in sequence."""
+    blocks = [ResidualConv(in_channels if i == 0 else out_channels, out_channels, stride if i == 0 else 1, dropout=dropout)
+              for i in range(num_blocks)]
+    return nn.Sequential(*blocks)
+
+
+class InvDepth(nn.Module):
+    """3x3 conv to `out_channels` followed by sigmoid(x) / min_depth."""
+
+    def __init__(self, in_channels, out_channels=1, min_depth=0.5):
+        super().__init__()
+        self.min_depth = min_depth
+        self.conv1 = _HipConv2d(in_channels, out_channels, 3, 1)
+
+    def forward(self, x):
+        return HF.invdepth_act(self.conv1(x), self.min_depth)
+
+
+def packing(x, r=2):
+    """[B,C,H,W] -> [B,4C,H/2,W/2] space-to-depth (inverse of PixelShuffle(2))."""
+    if r != 2:
+        raise NotImplementedError('the gfx950 packing kernel implements r=2 only')
+    return HF.space_to_depth(x)
+
+
+class PackLayerConv2d(nn.Module):
+    """Packing followed by a Conv2D back to `in_channels`."""
+
+    def __init__(self, in_channels, kernel_size, r=2):
+        super().__init__()
+        self.r = r
+        self.conv = Conv2D(in_channels * (r ** 2), in_channels, kernel_size, 1)
+
+    def forward(self, x):
+        return self.conv(packing(x, self.r))
+
+
+class UnpackLayerConv2d(nn.Module):
+    """Conv2D to r^2 * out_channels followed by depth-to-space."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, r=2):
+        super().__init__()
+        if r != 2:
+            raise NotImplementedError('r=2 only')
+        self.conv = Conv2D(in_channels, out_channels * (r ** 2), kernel_size, 1)
+
+    def forward(self, x):
+        return HF.depth_to_space(self.conv(x))
+
+
+class PackLayerConv3d(nn.Module):
+    """3D packing: space-to-depth, Conv3d(1 -> d) over (channel, y, x), then Conv2D back to `in_channels`."""
+
+    def __init__(self, in_channels, kernel_size, r=2, d=8):
+        super().__init__()
+        if r != 2 or d != 8:
+            raise NotImplementedError('the gfx950 packing kernels implement r=2, d=8 (PackNet01)')
+        self.conv = Conv2D(in_channels * (r ** 2) * d, in_channels, kernel_size, 1)
+        self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
+
+    def forward(self, x):
+        feats = HF.conv3d_1to8(HF.space_to_depth(x), self.conv3d.weight, self.conv3d.bias)
+        return self.conv(feats)
+
+
+class UnpackLayerConv3d(nn.Module):
+    """3D unpacking: Conv2D to out*r^2/d channels, Conv3d(1 -> d), then depth-to-space."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, r=2, d=8):
+        super().__init__()
+        if r != 2 or d != 8:
+            raise NotImplementedError('the gfx950 unpacking kernels implement r=2, d=8 (PackNet01)')
+        self.conv = Conv2D(in_channels, out_channels * (r ** 2) // d, kernel_size, 1)
+        self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
+
+    def forward(self, x):
+        feats = HF.conv3d_1to8(self.conv(x), self.conv3d.weight, self.conv3d.bias)
+        return HF.depth_to_space(feats)

@@ -1,0 +1,39 @@
+"""TEST INFRASTRUCTURE: compile the kernels of packnet-sfm_amd/csrc for the HOST with tests/emu/hipemu.h.
+
+The resulting tests/emu/libpnsfm_emu.so exports the same C ABI as the product library but executes every
+kernel on CPU fibers (see hipemu.h).  It lets `pytest -m "not gpu"` check kernel index math / tiling / MFMA
+fragment mapping against the oracle in a container without a GPU.  It is never loaded by the product path
+(packnet_sfm.hip._lib only accepts a library whose pnsfm_build_target() is "gfx950").
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "packnet-sfm_amd", "csrc"))
+SOURCES = ["api.hip", "conv2d.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "loss.hip"]
+LIB = os.path.join(HERE, "libpnsfm_emu.so")
+
+
+def build_emu(force=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "pnsfm_common.h"), os.path.join(HERE, "hipemu.h"),
+                   os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(HERE, os.path.basename(s)[:-4] + ".emu.o")
+        objs.append(o)
+        cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DPNSFM_EMU", "-I", HERE, "-I", CSRC,
+               "-Wno-unused-value", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("emu compile failed: " + " ".join(cmd))
+    subprocess.check_call([cxx, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_emu(force=True))

@@ -54,13 +54,13 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
       g.PW = W + ks - 1;
     }
     long blocks = (long)B * g.tiles_per_img * m_tiles;
-    size_t smem = ((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float);
+    size_t smem = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
     if (NT == 2 && (blocks < 768 || smem > kMaxSmem)) continue;
     break;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
-  while (((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 2) g.CI /= 2;
-  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 2 * (size_t)g.CI * BM) * sizeof(float);
+  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 2) g.CI /= 2;
+  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
   g.nchunks = ceil_div(g.KP, g.CI);
   long blocks = (long)B * g.tiles_per_img * m_tiles;
   g.splitK = 1;
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   constexpr int BM = 32 * MT;
   const int PS = a.PH * a.PW;
   float* patch = smem;               // [CI][PS]
-  float* wbuf = smem + a.CI * PS;    // [2][CI][BM]
+  float* wbuf = smem + ((a.CI * PS + 3) & ~3);    // [2][CI][BM], 16-byte aligned for the float4 slab stores
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;

@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer averages gradients across ranks exactly like one
+process that saw the whole batch (what hvd.DistributedOptimizer guarantees the reference's trainer)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'packnet-sfm_amd'))
+    from packnet_sfm.rccl import hvd
+    hvd.init()
+    assert hvd.size() == world and hvd.rank() == rank
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    opt = hvd.DistributedOptimizer(torch.optim.Adam(net.parameters(), lr=1e-2), named_parameters=net.named_parameters(),
+                                   compression=hvd.Compression.none, bucket_bytes=300)   # tiny buckets -> several collectives
+    data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
+    target = torch.randn(8, 1, generator=torch.Generator().manual_seed(2))
+    shard = slice(rank * 4, rank * 4 + 4)
+    grads = None
+    for it in range(3):
+        opt.zero_grad()
+        loss = ((net(data[shard]) - target[shard]) ** 2).mean()
+        loss.backward()
+        opt.synchronize()
+        if it == 0:
+            grads = [p.grad.clone() for p in net.parameters()]
+        opt.step()
+    val = hvd.allreduce(torch.tensor([float(rank)]), average=True, name='x')
+    q.put((rank, [g.tolist() for g in grads], [p.detach().tolist() for p in net.parameters()], float(val)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_average():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the whole batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
+    target = torch.randn(8, 1, generator=torch.Generator().manual_seed(2))
+    ref_grads = None
+    for it in range(3):
+        opt.zero_grad()
+        ((net(data) - target) ** 2).mean().backward()
+        if it == 0:
+            ref_grads = [p.grad.clone() for p in net.parameters()]
+        opt.step()
+    for rank, grads, params, val in results:
+        assert abs(val - 0.5) < 1e-6
+        for g, r in zip(grads, ref_grads):
+            assert torch.allclose(torch.tensor(g), r, atol=1e-6), 'averaged gradient differs from the full-batch gradient'
+        for p, r in zip(params, net.parameters()):
+            assert torch.allclose(torch.tensor(p), r.detach(), atol=1e-5), 'replicas diverged from the full-batch run'
+    assert results[0][2] == results[1][2], 'replicas are not bit-identical'

@@ -1,0 +1,275 @@
+"""GPU (MI355X): the gfx950 kernels, called through the C ABI, against
+  (1) the REFERENCE's goldens (tests/golden/*.pt),
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (3) at BASELINE.json's full size (batch 4, 192x640): the oracle's math executed by stock PyTorch-ROCm ops on the same
+      device, plus size-independent properties (pack/unpack round trip, conv linearity, identity warp, SSIM(x,x)=1).
+Tolerances are fp32: 1e-4 of max for activations, 1e-3 for depth / gradients (north-star: depth within 1e-3 rel)."""
+import os
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from packnet_sfm.hip import _lib
+    assert _lib.get().pnsfm_build_target() == b'gfx950'      # the native library is what runs, or we fail loudly
+    assert _lib.REQUIRE_CUDA
+
+
+# ------------------------------------------------------------------------------------------- (1) reference goldens
+@pytest.mark.parametrize('name', ['conv2d_k3', 'conv2d_k5', 'conv2d_k7'])
+def test_conv2d_block_golden(name):
+    P.case_conv2d_block(name, DEV)
+
+
+def test_residual_conv_golden():
+    P.case_residual_conv(DEV)
+
+
+def test_packing_invdepth_golden():
+    P.case_packing(DEV)
+    P.case_invdepth(DEV)
+
+
+@pytest.mark.parametrize('name', ['pack_k3', 'pack_k5'])
+def test_pack_golden(name):
+    P.case_pack(name, DEV)
+
+
+def test_unpack_golden():
+    P.case_unpack(DEV)
+
+
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean'])
+def test_loss_golden(name):
+    P.case_loss(name, DEV)
+
+
+def test_packnet01_golden():
+    P.case_packnet01(DEV)
+
+
+def _selfsup(device, fx):
+    from oracle import packnet_oracle as O
+    from packnet_sfm.models.SelfSupModel import SelfSupModel
+    from packnet_sfm.networks.depth.PackNet01 import PackNet01
+    from packnet_sfm.networks.pose.PoseNet import PoseNet
+    sd = O.init_params(O.packnet01_param_shapes('1A'), seed=fx['depth_seed'])
+    psd = O.init_params(O.posenet_param_shapes(2), seed=fx['pose_seed'])
+    psd['pose_pred.bias'] = fx['pose_pred_bias'].clone()
+    model = SelfSupModel(**fx['loss_kwargs'], clip_loss=0.0, flip_lr_prob=1.0 if fx['flip'] else 0.0,
+                         upsample_depth_maps=True, rotation_mode='euler')
+    dn, pn = PackNet01(dropout=0.0, version='1A'), PoseNet(nb_ref_imgs=2)
+    dn.load_state_dict(sd)
+    pn.load_state_dict(psd)
+    model.add_depth_net(dn)
+    model.add_pose_net(pn)
+    return model.to(device).train(), dn, pn
+
+
+@pytest.mark.parametrize('key', ['step_flip0', 'step_flip1'])
+def test_training_step_golden(key):
+    """Full SelfSupModel step (PackNet01 + PoseNet + loss, fwd + bwd) vs the reference's loss and gradients."""
+    fx = P.golden('step')[key]
+    model, dn, pn = _selfsup(DEV, fx)
+    batch = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in fx['batch'].items()}
+    random.seed(0)
+    out = model(batch, progress=0.0)
+    P.check(out['loss'], fx['loss'], 1e-4, 'loss')
+    P.check(out['metrics']['smoothness_loss'], fx['smoothness_loss'], 1e-3, 'smoothness')
+    d = 1.0 / out['inv_depths'][0].clamp(min=1e-6)
+    dref = 1.0 / fx['inv_depth0'].clamp(min=1e-6)
+    P.check(d, dref, 1e-3, 'depth (north-star 1e-3 rel)')
+    out['loss'].backward()
+    named = [('depth_net.' + n, p) for n, p in dn.named_parameters()] + [('pose_net.' + n, p) for n, p in pn.named_parameters()]
+    gmax = max(fx['grad_norms'].values())
+    worst = 0.0
+    for n, p in named:
+        ref = fx['grad_norms'][n]
+        got = float(p.grad.norm())
+        # biases in front of a GroupNorm have zero true gradient: compare on the scale of the layer's real gradients
+        tol = 1e-2 * max(ref, 1e-4 * gmax)
+        assert abs(got - ref) <= tol, 'grad norm %s: %.6e vs reference %.6e' % (n, got, ref)
+        worst = max(worst, abs(got - ref) / max(ref, 1e-4 * gmax))
+    print('worst relative grad-norm deviation vs reference: %.2e' % worst)
+
+
+# ------------------------------------------------------------------------------------------- (2) CPU oracle, seeded
+CONV_SHAPES = [  # (B, Cin, Cout, H, W, k): real PackNet01 layer shapes at reduced batch / resolution
+    (1, 3, 64, 48, 160, 5),       # pre_calc
+    (1, 64, 64, 48, 160, 7),      # conv1
+    (1, 2048, 64, 24, 80, 5),     # pack1.conv   (W=80 -> linear tiles)
+    (2, 129, 64, 48, 160, 3),     # iconv1 (odd Cin)
+    (2, 193, 128, 12, 40, 3),     # iconv3
+    (1, 64, 32, 24, 80, 3),       # unpack1.conv (Cout 32)
+    (1, 256, 1, 24, 80, 3),       # disp4 head (Cout 1)
+    (2, 4096, 128, 6, 20, 3),     # pack3.conv at low res (split-K)
+    (4, 512, 512, 6, 20, 3),      # conv5 stage
+    (2, 256, 512, 12, 40, 1),     # residual shortcut 1x1
+]
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+def test_conv2d_vs_cpu_oracle(shape):
+    from packnet_sfm.hip import ops
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)          # the oracle's conv (oracle/packnet_oracle.py conv2d_gn_elu)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    wf, wb = ops.conv2d_pack(wd)
+    P.check(ops.conv2d_forward(xd, wf, bd, Cout, ks), yr, 2e-5, 'fwd')
+    P.check(ops.conv2d_backward_data(dyd, wb, Cin, ks), xr.grad, 2e-5, 'dgrad')
+    dw, db = ops.conv2d_backward_weight(xd, dyd, ks)
+    P.check(dw, wr.grad, 5e-5, 'wgrad')
+    P.check(db, br.grad, 5e-5, 'dbias')
+
+
+def test_groupnorm_vs_cpu_oracle():
+    from packnet_sfm.hip import functional as HF, ops
+    g = torch.Generator().manual_seed(5)
+    for (B, C, H, W, act) in [(2, 64, 48, 160, ops.ACT_ELU), (4, 512, 6, 20, ops.ACT_ELU), (2, 32, 24, 80, ops.ACT_RELU)]:
+        x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+        r = torch.randn(B, C, H, W, generator=g)
+        ga, be = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        dy = torch.randn(B, C, H, W, generator=g)
+        xr, rr, gr, br = (t.clone().requires_grad_(True) for t in (x, r, ga, be))
+        z = F.group_norm(xr + rr, 16, gr, br, eps=1e-5)
+        yr = F.elu(z) if act == ops.ACT_ELU else F.relu(z)
+        yr.backward(dy)
+        xd, rd, gd, bd = (t.to(DEV).requires_grad_(True) for t in (x, r, ga, be))
+        y = HF.groupnorm_act(xd, gd, bd, 16, 1e-5, act, res=rd)
+        y.backward(dy.to(DEV))
+        P.check(y, yr, 2e-5, 'gn fwd')
+        P.check(xd.grad, xr.grad, 2e-4, 'gn dx')
+        P.check(rd.grad, rr.grad, 2e-4, 'gn dres')
+        P.check(gd.grad, gr.grad, 2e-4, 'gn dgamma')
+        P.check(bd.grad, br.grad, 2e-4, 'gn dbeta')
+
+
+def test_conv3d_vs_cpu_oracle():
+    from oracle import packnet_oracle as O
+    from packnet_sfm.hip import functional as HF
+    g = torch.Generator().manual_seed(6)
+    for (B, D, H, W) in [(2, 256, 24, 80), (1, 2048, 6, 20), (2, 32, 48, 160)]:
+        p = torch.randn(B, D, H, W, generator=g)
+        w3 = 0.3 * torch.randn(8, 1, 3, 3, 3, generator=g)
+        b3 = torch.randn(8, generator=g)
+        pr, wr, br = (t.clone().requires_grad_(True) for t in (p, w3, b3))
+        yr = O.conv3d_1to8(pr, wr, br)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        pd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (p, w3, b3))
+        y = HF.conv3d_1to8(pd, wd, bd)
+        y.backward(dy.to(DEV))
+        P.check(y, yr, 1e-5, 'conv3d fwd')
+        P.check(pd.grad, pr.grad, 1e-5, 'conv3d dgrad')
+        P.check(wd.grad, wr.grad, 1e-4, 'conv3d wgrad')
+        P.check(bd.grad, br.grad, 1e-4, 'conv3d dbias')
+
+
+def test_adam_vs_torch():
+    from packnet_sfm.hip import ops
+    g = torch.Generator().manual_seed(3)
+    n = 1 << 20
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=2e-4)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        p_ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(p, (grad * 8.0).to(DEV), m, v, 2e-4, 0.9, 0.999, 1e-8, 0.0, 0.125, step)
+    P.check(p, p_ref, 1e-6, 'adam')
+
+
+# ------------------------------------------------------------------------------------------- (3) full size
+def _full_batch(B=4, H=192, W=640, seed=1234):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    import bench
+    return bench.synthetic_batch(B, H, W, seed, DEV)
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] size (batch 4, 192x640): properties that need no CPU oracle."""
+    from packnet_sfm.hip import functional as HF, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 64, 192, 640, generator=g).to(DEV)
+    # pack / unpack data movement round trip, and equality with the torch definition of packing
+    s = ops.space_to_depth(x)
+    assert torch.equal(ops.depth_to_space(s), x)
+    assert torch.equal(s, F.pixel_unshuffle(x, 2))
+    # conv linearity: conv(a*x1 + x2) == a*conv(x1) + conv(x2)  (bias off)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    wf, _ = ops.conv2d_pack(w, want_bwd=False)
+    x2 = torch.randn(4, 64, 192, 640, generator=g).to(DEV)
+    lhs = ops.conv2d_forward(1.5 * x + x2, wf, None, 64, 3)
+    rhs = 1.5 * ops.conv2d_forward(x, wf, None, 64, 3) + ops.conv2d_forward(x2, wf, None, 64, 3)
+    P.check(lhs, rhs, 1e-5, 'conv linearity')
+    # identity pose => the warp returns the context image itself; SSIM(x, x) = 1 => zero photometric loss
+    batch = _full_batch()
+    img = batch['rgb']
+    K = batch['intrinsics'].float()
+    inv = (0.05 + torch.rand(4, 1, 192, 640, generator=g)).to(DEV)
+    T = torch.eye(4, device=DEV).repeat(1, 4, 1, 1)
+    warped = HF.view_synthesis(inv, img.unsqueeze(0), K, K, T)
+    P.check(warped[0], img, 2e-5, 'identity warp')
+    loss = HF.photometric(warped, img.unsqueeze(0), img, 0.85, 1e-4, 9e-4, False, HF.REDUCE_MIN)
+    assert float(loss) < 1e-5
+    assert float(HF.smoothness(torch.ones_like(inv), img)) == 0.0
+
+
+def test_full_size_step_vs_same_device_reference():
+    """Batch 4, 192x640 training step through the HIP kernels vs the oracle's math run by stock PyTorch-ROCm ops on the
+    same MI355X (loss, depth, gradient norms)."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.models.SelfSupModel import SelfSupModel
+    from packnet_sfm.networks.depth.PackNet01 import PackNet01
+    from packnet_sfm.networks.pose.PoseNet import PoseNet
+    import bench
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    batch = _full_batch()
+    sd = O.init_params(O.packnet01_param_shapes('1A'), seed=42)
+    psd = O.init_params(O.posenet_param_shapes(2), seed=43)
+    psd['pose_pred.bias'] = torch.tensor([2., 0.5, -1., 0.3, -0.2, 0.1, -2., -0.5, 1., -0.3, 0.2, -0.1])
+    kw = {k: bench.LOSS_DEFAULTS[k] for k in ('num_scales', 'ssim_loss_weight', 'smooth_loss_weight', 'C1', 'C2',
+                                               'photometric_reduce_op', 'automask_loss')}
+    model = SelfSupModel(**{**bench.LOSS_DEFAULTS, 'flip_lr_prob': 0.0})
+    dn, pn = PackNet01(dropout=0.0, version='1A'), PoseNet(nb_ref_imgs=2)
+    dn.load_state_dict(sd)
+    pn.load_state_dict(psd)
+    model.add_depth_net(dn)
+    model.add_pose_net(pn)
+    model = model.to(DEV).train()
+    out = model(batch, progress=0.0)
+    out['loss'].backward()
+    # same-device reference
+    sdd = {k: v.to(DEV).requires_grad_(True) for k, v in sd.items()}
+    psdd = {k: v.to(DEV).requires_grad_(True) for k, v in psd.items()}
+    ref = O.selfsup_forward(sdd, psdd, batch, flip=False, **kw)
+    ref['loss'].sum().backward()
+    P.check(out['loss'], ref['loss'], 2e-4, 'loss')
+    P.check(1.0 / out['inv_depths'][0].clamp(min=1e-6), 1.0 / ref['inv_depths'][0].clamp(min=1e-6), 1e-3, 'depth')
+    gmax = max(float(v.grad.norm()) for v in sdd.values())
+    for n, p in dn.named_parameters():
+        r = float(sdd[n].grad.norm())
+        got = float(p.grad.norm())
+        assert abs(got - r) <= 2e-2 * max(r, 1e-4 * gmax), 'grad norm %s: %.6e vs %.6e' % (n, got, r)
+    assert torch.isfinite(out['loss']).all()

@@ -216,7 +216,16 @@ def case_network(gen):
     with torch.no_grad():
         d_eval = net(rgb)['inv_depths']
     assert torch.is_tensor(d_eval)
+    # the same REFERENCE module evaluated in float64: tells how much of a deviation is the fp32 CPU backend's own
+    # round-off (oneDNN's fp32 weight-gradient of the K=147456 pack5 conv is 2.5e-3 away from the fp64 value)
+    net64 = RefPackNet01(dropout=0.0, version='1A').double()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    net64.train()
+    disps64 = net64(rgb.double())['inv_depths']
+    g64 = grads_of(sum((d * dy.double()).sum() for d, dy in zip(disps64, dys)), list(net64.parameters()))
     fx['packnet01'] = dict(seed=1234, rgb=rgb, disps=[d.detach() for d in disps], dys=dys, disp_eval=d_eval,
+                           disps_f64=[d.detach() for d in disps64],
+                           grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},
                            grad_norms={n: float(t.norm()) for n, t in zip(names, g)},
                            grad_samples={n: t.flatten()[:: max(1, t.numel() // 16)][:16].clone() for n, t in zip(names, g)})
     # PoseNet

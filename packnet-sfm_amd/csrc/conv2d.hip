@@ -309,6 +309,7 @@ struct WgradArgs {
   float* dw;        // [Cout][Cin*KK]
   int B, Cin, Cout, H, W, KS;
   int PT, mode, tiles_x, tiles_per_img, PH, PW, NCI, total_tiles, tiles_per_split, splitP;
+  int cstride;  // true H*W (channel stride); H, W above are the TILING dims (k=1 flattens the image to 32-wide rows)
   float invPW;
 };
 
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
   const int P = a.KS >> 1, KK = a.KS * a.KS;
-  const int H = a.H, W = a.W, HW = H * W;
+  const int H = a.H, W = a.W, HW = a.cstride;
   const int N = a.Cin * KK;
 
   const int n0 = blockIdx.x * 128;
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       const int m = e / PT, p = e - m * PT;
       int yy, xx;
       bool ok;
-      if (a.mode == 0) { yy = y0 + (p >> 5); xx = x0 + (p & 31); ok = yy < H; }
+      if (a.mode == 0) { yy = y0 + (p >> 5); xx = x0 + (p & 31); ok = yy < H && yy * W + xx < HW; }
       else { const int pn = pn0 + p; ok = pn < HW; yy = ok ? pn / W : 0; xx = ok ? pn - yy * W : 0; }
       const int co = co0 + m;
       float v = 0.f;
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
         const int cc = e - r * a.PW;
         const int yy = py0 + r, xx = px0 + cc;
         float v = 0.f;
-        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xc[yy * W + xx];
+        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W && yy * W + xx < HW) v = xc[yy * W + xx];
         patch[cil * PS + e] = v;
       }
     }
@@ -501,6 +502,11 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
+  a.cstride = HW;
+  if (ks == 1) {  // no halo: any pixel order works, so tile the flattened image as 32-wide rows
+    a.W = W = 32;
+    a.H = H = ceil_div(HW, 32);
+  }
   const int MT = conv_pick_MT(Cout), BM = 32 * MT;
   a.mode = (W % 32 == 0) ? 0 : 1;
   a.NCI = 127 / KK + 2;

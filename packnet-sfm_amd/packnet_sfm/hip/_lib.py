@@ -6,6 +6,9 @@ build) importing any HIP-backed module fails loudly here.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST come first: it loads PyTorch-ROCm's own libamdhip64.so.7, which this library then
+#                              shares; loading ours first would pull a second HIP runtime (/opt/rocm) into the process
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.abspath(os.path.join(_HERE, "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libpnsfm_hip.so")

@@ -33,7 +33,7 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
   const int BM = 32 * g.MT;
   g.MP = conv_pack_MP(Cout);
   g.KP = conv_pack_KP(Cin);
-  g.CI = g.KP < 16 ? g.KP : 16;
+  g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
   g.mode = (W % 32 == 0) ? 0 : 1;
   const int m_tiles = g.MP / BM;
   const int HW = H * W;
@@ -59,13 +59,13 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
     break;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
-  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 2) g.CI /= 2;
+  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
   g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
   g.nchunks = ceil_div(g.KP, g.CI);
   long blocks = (long)B * g.tiles_per_img * m_tiles;
   g.splitK = 1;
-  if (blocks < 512 && g.nchunks > 1) {
-    int want = (int)((1024 + blocks - 1) / blocks);
+  if (blocks < 1024 && g.nchunks > 1) {
+    int want = (int)((1536 + blocks - 1) / blocks);
     if (want > g.nchunks) want = g.nchunks;
     int cps = ceil_div(g.nchunks, want);
     g.splitK = ceil_div(g.nchunks, cps);
@@ -80,7 +80,7 @@ struct ConvArgs {
   float* y;           // [B][Cout][H][W]
   int B, Cin, Cout, H, W, KS;
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
-  float invPW;
+  float invPW, invPS;
 };
 
 template <int MT, int NT>
@@ -150,48 +150,70 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 
   for (int c = c_begin; c < c_end; ++c) {
     const int ci0 = c * a.CI;
-    int cnt = a.KP - ci0;
-    if (cnt > a.CI) cnt = a.CI;
     __syncthreads();  // all waves are done with the previous chunk's patch / weight buffers
-    // ---- stage the halo patch of `cnt` input channels (zero padding by predication)
-    for (int cil = 0; cil < cnt; ++cil) {
-      const int ci = ci0 + cil;
-      const float* xc = xb + (size_t)ci * HW;
-      const bool cok = ci < a.Cin;
-      for (int e = tid; e < PS; e += 256) {
-        const int r = (int)(((float)e + 0.5f) * a.invPW);
-        const int cc = e - r * a.PW;
-        const int yy = py0 + r, xx = px0 + cc;
-        float v = 0.f;
-        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xc[yy * W + xx];
-        patch[cil * PS + e] = v;
+    // ---- stage the halo patch of `cnt` input channels (zero padding by predication).
+    // Branch-free and batched: 8 independent global loads are in flight per thread before the first LDS store
+    // (a guarded `if (ok) v = x[..]` makes hipcc branch around every load and wait vmcnt(0) per element).
+    {
+      const int total = a.CI * PS;   // channels past Cin (last chunk) are staged as zeros
+      for (int base = tid; base < total; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * 256;
+          const int cil = (int)(((float)idx + 0.5f) * a.invPS);
+          const int e = idx - cil * PS;
+          const int r = (int)(((float)e + 0.5f) * a.invPW);
+          const int cc = e - r * a.PW;
+          const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
+          const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const size_t off = ok ? ((size_t)ci * HW + yy * W + xx) : 0;
+          const float t = xb[off];
+          v[u] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * 256;
+          if (idx < total) patch[idx] = v[u];
+        }
       }
     }
-    // ---- tap 0 weight slab
-    const bool wact = wrow < cnt;
-    float4 wreg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wact) wreg = *reinterpret_cast<const float4*>(a.wp + ((size_t)(0 * a.KP + ci0 + wrow)) * a.MP + co0 + wc4 * 4);
+    // ---- tap 0 weight slab (rows past the packed K extent are zero)
+    const bool wact = wrow < a.CI;
+    const bool wok = wact && (ci0 + wrow) < a.KP;
+    const float* wsrc = a.wp + ((size_t)(ci0 + (wok ? wrow : 0))) * a.MP + co0 + wc4 * 4;
+    const size_t tap_stride = (size_t)a.KP * a.MP;
+    float4 wreg = *reinterpret_cast<const float4*>(wsrc);
+    if (!wok) wreg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wact) *reinterpret_cast<float4*>(wbuf + wrow * BM + wc4 * 4) = wreg;
     __syncthreads();
 
-    const int ksteps = cnt >> 1;
+    const int ksteps = a.CI >> 1;
     for (int tap = 0; tap < KK; ++tap) {
       const int cur = tap & 1;
-      if (tap + 1 < KK && wact)
-        wreg = *reinterpret_cast<const float4*>(a.wp + ((size_t)((tap + 1) * a.KP + ci0 + wrow)) * a.MP + co0 + wc4 * 4);
+      if (tap + 1 < KK) {
+        wreg = *reinterpret_cast<const float4*>(wsrc + (size_t)(tap + 1) * tap_stride);
+        if (!wok) wreg = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       const int ky = tap / a.KS, kx = tap - ky * a.KS;
       const float* wb = wbuf + cur * a.CI * BM + half * BM + l32;
       const float* pb = patch + half * PS + ky * a.PW + kx;
-      for (int kk = 0; kk < ksteps; ++kk) {
-        float av[MT], bv[NT];
+      // batches of 4 k-steps (8 channels): 4*(MT+NT) LDS reads issued up front, then 4*MT*NT MFMAs back to back
+      for (int kb = 0; kb < ksteps; kb += 4) {
+        float av[4][MT], bv[4][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = wb[kk * 2 * BM + mt * 32];
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = pb[kk * 2 * PS + boff[nt]];
+          for (int mt = 0; mt < MT; ++mt) av[j][mt] = wb[(kb + j) * 2 * BM + mt * 32];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int nt = 0; nt < NT; ++nt) bv[j][nt] = pb[(kb + j) * 2 * PS + boff[nt]];
+        }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[mt], bv[nt], acc[mt][nt]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[j][mt], bv[j][nt], acc[mt][nt]);
       }
       if (tap + 1 < KK && wact) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
       __syncthreads();
@@ -234,6 +256,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   a.PH = g.PH; a.PW = g.PW; a.KP = g.KP; a.MP = g.MP; a.nchunks = g.nchunks;
   a.chunks_per_split = ceil_div(g.nchunks, g.splitK); a.splitK = g.splitK;
   a.invPW = 1.0f / (float)g.PW;
+  a.invPS = 1.0f / (float)(g.PH * g.PW);
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }
@@ -310,7 +333,8 @@ struct WgradArgs {
   int B, Cin, Cout, H, W, KS;
   int PT, mode, tiles_x, tiles_per_img, PH, PW, NCI, total_tiles, tiles_per_split, splitP;
   int cstride;  // true H*W (channel stride); H, W above are the TILING dims (k=1 flattens the image to 32-wide rows)
-  float invPW;
+  int vec4, PTlog;
+  float invPW, invPS;
 };
 
 template <int MT>
@@ -368,18 +392,57 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       px0 = -P;
     }
     __syncthreads();  // previous tile fully consumed
-    // ---- dY tile [BM][PT] (zero for channels / pixels outside the tensor)
+    // ---- dY tile [BM][PT] (zero for channels / pixels outside the tensor); branch-free, batched loads
     const float* dyb = a.dy + (size_t)b * a.Cout * HW;
-    for (int e = tid; e < BM * PT; e += 256) {
-      const int m = e / PT, p = e - m * PT;
-      int yy, xx;
-      bool ok;
-      if (a.mode == 0) { yy = y0 + (p >> 5); xx = x0 + (p & 31); ok = yy < H && yy * W + xx < HW; }
-      else { const int pn = pn0 + p; ok = pn < HW; yy = ok ? pn / W : 0; xx = ok ? pn - yy * W : 0; }
-      const int co = co0 + m;
-      float v = 0.f;
-      if (ok && co < a.Cout) v = dyb[(size_t)co * HW + yy * W + xx];
-      dys[m * DS + p] = v;
+    if (a.vec4) {
+      // rows of the tile are contiguous in memory (32-pixel row segments in 2-D mode, the whole run in linear mode)
+      const int q4 = PT >> 2, q4log = a.PTlog - 2;
+      for (int base = tid; base < BM * q4; base += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int g = base + u * 256;
+          const int m = g >> q4log, p = (g & (q4 - 1)) << 2;
+          int gidx;
+          bool ok;
+          if (a.mode == 0) { const int yy = y0 + (p >> 5); gidx = yy * W + x0 + (p & 31); ok = yy < H && gidx + 3 < HW; }
+          else { gidx = pn0 + p; ok = gidx + 3 < HW; }
+          ok = ok && g < BM * q4 && (co0 + m) < a.Cout;
+          const size_t off = ok ? ((size_t)(co0 + m) * HW + gidx) : 0;
+          const float4 t = *reinterpret_cast<const float4*>(dyb + off);
+          v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int g = base + u * 256;
+          if (g < BM * q4) {
+            float* d = dys + (g >> q4log) * DS + ((g & (q4 - 1)) << 2);
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+          }
+        }
+      }
+    } else {
+      for (int base = tid; base < BM * PT; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = base + u * 256;
+          const int m = e >> a.PTlog, p = e & (PT - 1);
+          int gidx;
+          bool ok;
+          if (a.mode == 0) { const int yy = y0 + (p >> 5); gidx = yy * W + x0 + (p & 31); ok = yy < H && gidx < HW; }
+          else { gidx = pn0 + p; ok = gidx < HW; }
+          ok = ok && e < BM * PT && (co0 + m) < a.Cout;
+          const size_t off = ok ? ((size_t)(co0 + m) * HW + gidx) : 0;
+          const float t = dyb[off];
+          v[u] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = base + u * 256;
+          if (e < BM * PT) dys[(e >> a.PTlog) * DS + (e & (PT - 1))] = v[u];
+        }
+      }
     }
     // ---- pixel -> patch offset table
     if (tid < PT) {
@@ -389,29 +452,57 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       else { const int pn = pn0 + p; const bool ok = pn < HW; const int yy = ok ? pn / W : r0; const int xx = ok ? pn - yy * W : 0; off = (yy - r0) * a.PW + xx; }
       poff[p] = off;
     }
-    // ---- input halo patch for channels ci_lo .. ci_lo+NCI-1
+    // ---- input halo patch for channels ci_lo .. ci_lo+NCI-1 (branch-free, batched)
     const float* xb = a.x + (size_t)b * a.Cin * HW;
-    for (int cil = 0; cil < a.NCI; ++cil) {
-      const int ci = ci_lo + cil;
-      const bool cok = ci < a.Cin;
-      const float* xc = xb + (size_t)ci * HW;
-      for (int e = tid; e < PS; e += 256) {
-        const int r = (int)(((float)e + 0.5f) * a.invPW);
-        const int cc = e - r * a.PW;
-        const int yy = py0 + r, xx = px0 + cc;
-        float v = 0.f;
-        if (cok && yy >= 0 && yy < H && xx >= 0 && xx < W && yy * W + xx < HW) v = xc[yy * W + xx];
-        patch[cil * PS + e] = v;
+    {
+      const int total = a.NCI * PS;
+      for (int base = tid; base < total; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * 256;
+          const int cil = (int)(((float)idx + 0.5f) * a.invPS);
+          const int e = idx - cil * PS;
+          const int r = (int)(((float)e + 0.5f) * a.invPW);
+          const int cc = e - r * a.PW;
+          const int yy = py0 + r, xx = px0 + cc, ci = ci_lo + cil;
+          const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W && yy * W + xx < HW;
+          const size_t off = ok ? ((size_t)ci * HW + yy * W + xx) : 0;
+          const float t = xb[off];
+          v[u] = ok ? t : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * 256;
+          if (idx < total) patch[idx] = v[u];
+        }
       }
     }
     __syncthreads();
+    // ---- K loop over the tile's pixels, 4 k-steps (8 pixels) per batch; the offset-table reads of the NEXT batch
+    //      are issued before this batch's MFMAs so the poff -> patch dependent LDS chain is off the critical path
     const float* ab = dys + l32 * DS + half;
     const float* bb = patch + lane_b;
-    const int ksteps = PT >> 1;
-    for (int kk = 0; kk < ksteps; ++kk) {
-      const float bv = bb[poff[2 * kk + half]];
+    const int nbatch = PT >> 3;
+    int o[4];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = pnsfm_mfma_32x32x2(ab[mt * 32 * DS + 2 * kk], bv, acc[mt]);
+    for (int j = 0; j < 4; ++j) o[j] = poff[2 * j + half];
+    for (int bt = 0; bt < nbatch; ++bt) {
+      float bv[4], av[4][MT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bv[j] = bb[o[j]];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[j][mt] = ab[mt * 32 * DS + 2 * (4 * bt + j)];
+      }
+      if (bt + 1 < nbatch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = poff[2 * (4 * (bt + 1) + j) + half];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = pnsfm_mfma_32x32x2(av[j][mt], bv[j], acc[mt]);
     }
   }
 
@@ -532,6 +623,9 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   }
   if (smem > kMaxSmem) { set_error("backward_weight: image too wide for the LDS halo patch (W=%d)", W); return -1; }
   a.invPW = 1.0f / (float)a.PW;
+  a.invPS = 1.0f / (float)(a.PH * a.PW);
+  a.vec4 = (HW % 4 == 0) ? 1 : 0;
+  a.PTlog = a.PT == 128 ? 7 : (a.PT == 64 ? 6 : 5);
   a.total_tiles = B * a.tiles_per_img;
   const int n_tiles = ceil_div(N, 128), m_tiles = ceil_div(Cout, BM);
   int want = ceil_div(1536, n_tiles * m_tiles);

@@ -47,134 +47,156 @@ __global__ void __launch_bounds__(256) d2s_kernel(const float* __restrict__ x, f
 }
 
 // out[b][f*D+d][y][x] = b3[f] + sum_{dz,dy,dx} w3[f][dz][dy][dx] * p[b][d+dz-1][y+dy-1][x+dx-1]
+// grid: (ceil(HW/256), D, B): one thread per (d, y, x) produces all 8 features; 27 branch-free neighbour loads
+// (L1/L2 serve the 9x/3x overlap between neighbouring threads and planes), 216 FMAs, 8 coalesced stores.
 __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w3,
                                                           const float* __restrict__ b3, float* __restrict__ out,
-                                                          int D, int H, int W, size_t total) {
+                                                          int D, int H, int W) {
   __shared__ float ws[8 * 27 + 8];
   for (int i = threadIdx.x; i < 8 * 27 + 8; i += 256) ws[i] = i < 216 ? w3[i] : b3[i - 216];
   __syncthreads();
-  const size_t HW = (size_t)H * W;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int x = (int)(idx % W);
-    size_t r = idx / W;
-    const int y = (int)(r % H);
-    r /= H;
-    const int d = (int)(r % D);
-    const int b = (int)(r / D);
-    const float* pb = p + (size_t)b * D * HW;
-    float acc[8];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y, b = blockIdx.z;
+  const bool active = pix < HW;
+  const int y = active ? pix / W : 0, x = active ? pix - y * W : 0;
+  const float* pb = p + (size_t)b * D * HW;
+  float v[27];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = ws[216 + f];
+  for (int dz = 0; dz < 3; ++dz) {
+    const int dd = d + dz - 1;
+    const bool dok = dd >= 0 && dd < D;            // block-uniform
 #pragma unroll
-    for (int dz = 0; dz < 3; ++dz) {
-      const int dd = d + dz - 1;
-      if (dd < 0 || dd >= D) continue;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
-        if (yy < 0 || yy >= H) continue;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = x + dx - 1;
-          if (xx < 0 || xx >= W) continue;
-          const float v = pb[(size_t)dd * HW + (size_t)yy * W + xx];
-          const int tap = dz * 9 + dy * 3 + dx;
-#pragma unroll
-          for (int f = 0; f < 8; ++f) acc[f] = fmaf(ws[f * 27 + tap], v, acc[f]);
-        }
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x + dx - 1;
+        const bool ok = active && dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
+        const float t = pb[off];
+        v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
       }
     }
-    float* ob = out + (size_t)b * 8 * D * HW + (size_t)d * HW + (size_t)y * W + x;
+  }
+  float acc[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) acc[f] = ws[216 + f];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = fmaf(ws[f * 27 + tap], v[tap], acc[f]);
+  if (active) {
+    float* ob = out + ((size_t)b * 8 * D + d) * HW + pix;
 #pragma unroll
     for (int f = 0; f < 8; ++f) ob[(size_t)f * D * HW] = acc[f];
   }
 }
 
 // dp[b][d][y][x] = sum_{f,dz,dy,dx} w3[f][dz][dy][dx] * dout[b][f*D + d-dz+1][y-dy+1][x-dx+1]
+// same thread mapping; the 8x9 loads of one dz slab are issued together (branch-free) before they are consumed.
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
-                                                            float* __restrict__ dp, int D, int H, int W, size_t total) {
+                                                            float* __restrict__ dp, int D, int H, int W) {
   __shared__ float ws[8 * 27];
   for (int i = threadIdx.x; i < 8 * 27; i += 256) ws[i] = w3[i];
   __syncthreads();
-  const size_t HW = (size_t)H * W;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int x = (int)(idx % W);
-    size_t r = idx / W;
-    const int y = (int)(r % H);
-    r /= H;
-    const int d = (int)(r % D);
-    const int b = (int)(r / D);
-    const float* gb = dout + (size_t)b * 8 * D * HW;
-    float acc = 0.f;
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int d = blockIdx.y, b = blockIdx.z;
+  const bool active = pix < HW;
+  const int y = active ? pix / W : 0, x = active ? pix - y * W : 0;
+  const float* gb = dout + (size_t)b * 8 * D * HW;
+  float acc = 0.f;
 #pragma unroll
-    for (int dz = 0; dz < 3; ++dz) {
-      const int dd = d - dz + 1;
-      if (dd < 0 || dd >= D) continue;
+  for (int dz = 0; dz < 3; ++dz) {
+    const int dd = d - dz + 1;
+    if (dd < 0 || dd >= D) continue;                // block-uniform
+    float g[8][9];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y - dy + 1;
-        if (yy < 0 || yy >= H) continue;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y - dy + 1;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = x - dx + 1;
-          if (xx < 0 || xx >= W) continue;
-          const int tap = dz * 9 + dy * 3 + dx;
-          const float* g = gb + (size_t)dd * HW + (size_t)yy * W + xx;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x - dx + 1;
+        const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
 #pragma unroll
-          for (int f = 0; f < 8; ++f) acc = fmaf(ws[f * 27 + tap], g[(size_t)f * D * HW], acc);
+        for (int f = 0; f < 8; ++f) {
+          const float t = gb[(size_t)f * D * HW + off];
+          g[f][dy * 3 + dx] = ok ? t : 0.f;
         }
       }
     }
-    dp[idx] = acc;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(ws[f * 27 + dz * 9 + t], g[f][t], acc);
   }
+  if (active) dp[((size_t)b * D + d) * HW + pix] = acc;
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
-// grid: (nblk, 8 features). ws: double[8*28] zeroed by the caller, accumulated with atomics.
+// grid: (nblk, 2): blockIdx.y picks 4 of the 8 features, so the 27 neighbours of a position are loaded twice (not 8x);
+// each block walks whole (b, d) planes. 4*28 register accumulators per thread -> wave shuffle -> LDS -> fp64 atomics.
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
-                                                            double* __restrict__ ws, int D, int H, int W, size_t total) {
-  __shared__ double red[4];
-  const int f = blockIdx.y;
-  const size_t HW = (size_t)H * W;
-  float acc[28];
+                                                            double* __restrict__ ws, int B, int D, int H, int W) {
+  __shared__ float red[4][112];
+  const int f0 = blockIdx.y * 4;
+  const int HW = H * W;
+  float acc[4][28];
 #pragma unroll
-  for (int t = 0; t < 28; ++t) acc[t] = 0.f;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int x = (int)(idx % W);
-    size_t r = idx / W;
-    const int y = (int)(r % H);
-    r /= H;
-    const int d = (int)(r % D);
-    const int b = (int)(r / D);
-    const float g = dout[((size_t)b * 8 * D + (size_t)f * D + d) * HW + (size_t)y * W + x];
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < 28; ++t) acc[f][t] = 0.f;
+  for (int plane = blockIdx.x; plane < B * D; plane += gridDim.x) {
+    const int b = plane / D, d = plane - b * D;
     const float* pb = p + (size_t)b * D * HW;
-    acc[27] += g;
+    const float* gb = dout + ((size_t)b * 8 * D + d) * HW;
+    for (int pix = threadIdx.x; pix < HW; pix += 256) {
+      const int y = pix / W, x = pix - y * W;
+      float g[4];
 #pragma unroll
-    for (int dz = 0; dz < 3; ++dz) {
-      const int dd = d + dz - 1;
-      if (dd < 0 || dd >= D) continue;
+      for (int f = 0; f < 4; ++f) g[f] = gb[(size_t)(f0 + f) * D * HW + pix];
+      float v[27];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
-        if (yy < 0 || yy >= H) continue;
+      for (int dz = 0; dz < 3; ++dz) {
+        const int dd = d + dz - 1;
+        const bool dok = dd >= 0 && dd < D;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = x + dx - 1;
-          if (xx < 0 || xx >= W) continue;
-          acc[dz * 9 + dy * 3 + dx] = fmaf(g, pb[(size_t)dd * HW + (size_t)yy * W + xx], acc[dz * 9 + dy * 3 + dx]);
+        for (int dy = 0; dy < 3; ++dy) {
+          const int yy = y + dy - 1;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int xx = x + dx - 1;
+            const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
+            const float t = pb[off];
+            v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
+          }
         }
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[f][t] = fmaf(g[f], v[t], acc[f][t]);
+        acc[f][27] += g[f];
       }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int t = 0; t < 28; ++t) {
-    double v = (double)acc[t];
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&ws[f * 28 + t], red[0] + red[1] + red[2] + red[3]);
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < 28; ++t) {
+      float v = acc[f][t];
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+      if (lane == 0) red[wave][f * 28 + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 112) {
+    const int i = threadIdx.x;
+    const double s = (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i];
+    atomicAdd(&ws[f0 * 28 + i], s);
   }
 }
 
@@ -214,14 +236,12 @@ int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, v
 
 int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W,
                               void* stream) {
-  const size_t total = (size_t)B * D * H * W;
-  PNSFM_LAUNCH(conv3d_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W, total);
+  PNSFM_LAUNCH(conv3d_fwd_kernel, dim3(ceil_div(H * W, 256), D, B), dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
   return check_launch("conv3d_forward");
 }
 
 int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
-  const size_t total = (size_t)B * D * H * W;
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, total);
+  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(H * W, 256), D, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
   return check_launch("conv3d_backward_data");
 }
 
@@ -230,10 +250,9 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
   if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
-  const size_t total = (size_t)B * D * H * W;
-  int nblk = grid_for(total);
-  if (nblk > 512) nblk = 512;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk, 8), dim3(256), 0, s, p, dout, ws, D, H, W, total);
+  int nblk = B * D;
+  if (nblk > 1024) nblk = 1024;
+  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk, 2), dim3(256), 0, s, p, dout, ws, B, D, H, W);
   e = check_launch("conv3d_backward_weight");
   if (e) return e;
   PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3);

@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with events')
+    ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the timed region here')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -154,6 +155,8 @@ def main():
         elapsed = float(t.item())
     loss_val = float(loss.detach().float().item())
 
+    if rank == 0 and args.layer_table and not args.no_prof:
+        ops.prof_dump(args.layer_table)
     if rank == 0:
         images = B * world * args.steps
         value = images / elapsed

@@ -141,6 +141,8 @@ int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int pnsfm_prof_enable(int on);
 int pnsfm_prof_reset(void);
 int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long long* launches);
+/* per-launch table (shape, grid, ms, TFLOP/s) of everything recorded since the last reset, as CSV */
+int pnsfm_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

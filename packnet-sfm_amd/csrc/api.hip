@@ -32,7 +32,7 @@ int check_launch(const char* what) {
 // stream the kernel is launched on.  When enabled, each profiled launch records a (start, stop)
 // event pair; collect() synchronises on them and adds up hipEventElapsedTime.
 #ifndef PNSFM_EMU
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int meta[8]; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;
@@ -45,13 +45,14 @@ static hipEvent_t get_event() {
   return e;
 }
 
-void prof_begin(int kind, double flops, hipStream_t stream) {
+void prof_begin(int kind, double flops, hipStream_t stream, const int* meta) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.a = get_event();
   r.b = get_event();
   r.flops = flops;
+  for (int i = 0; i < 8; ++i) r.meta[i] = meta ? meta[i] : 0;
   hipEventRecord(r.a, stream);
   g_recs[kind].push_back(r);
 }
@@ -63,7 +64,7 @@ void prof_end(int kind, hipStream_t stream) {
   hipEventRecord(g_recs[kind].back().b, stream);
 }
 #else
-void prof_begin(int, double, hipStream_t) {}
+void prof_begin(int, double, hipStream_t, const int*) {}
 void prof_end(int, hipStream_t) {}
 #endif
 
@@ -123,6 +124,27 @@ int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long lon
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
+  return 0;
+}
+
+int pnsfm_prof_dump(const char* path) {
+#ifndef PNSFM_EMU
+  std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);
+  FILE* f = fopen(path, "w");
+  if (!f) { pnsfm::set_error("prof_dump: cannot open %s", path); return -1; }
+  fprintf(f, "kind,B,Cin,Cout,H,W,ks,split,blocks,ms,gflop,tflops\n");
+  for (int k = 0; k < 2; ++k)
+    for (auto& r : pnsfm::g_recs[k]) {
+      hipEventSynchronize(r.b);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+      fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.2f\n", k, r.meta[0], r.meta[1], r.meta[2], r.meta[3], r.meta[4],
+              r.meta[5], r.meta[6], r.meta[7], t, r.flops * 1e-9, t > 0 ? r.flops / (t * 1e-3) * 1e-12 : 0.0);
+    }
+  fclose(f);
+#else
+  (void)path;
+#endif
   return 0;
 }
 

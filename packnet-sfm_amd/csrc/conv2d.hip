@@ -263,7 +263,8 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
-  prof_begin(0, flops, stream);
+  const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(grid.x * grid.y * grid.z)};
+  prof_begin(0, flops, stream, meta);
   if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a);
   else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a);
   else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a);
@@ -639,7 +640,8 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   }
   dim3 grid(n_tiles, m_tiles, a.splitP);
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
-  prof_begin(1, flops, s);
+  const int meta[8] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(grid.x * grid.y * grid.z)};
+  prof_begin(1, flops, s, meta);
   if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, a);
   else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, a);
   prof_end(1, s);

@@ -59,7 +59,7 @@ int conv_pack_MP(int Mc);
 int conv_pick_MT(int Mc);
 
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
-void prof_begin(int kind, double flops, hipStream_t stream);
+void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);
 void prof_end(int kind, hipStream_t stream);
 
 }  // namespace pnsfm

@@ -49,6 +49,7 @@ SIGNATURES = {
     "pnsfm_prof_reset": (_i, []),
     "pnsfm_prof_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_longlong)]),
+    "pnsfm_prof_dump": (_i, [ctypes.c_char_p]),
 }
 
 

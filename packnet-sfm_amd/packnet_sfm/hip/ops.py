@@ -273,3 +273,7 @@ def prof_collect(kind):
     ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_longlong(0)
     _lib.get().pnsfm_prof_collect(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
     return ms.value, fl.value, n.value
+
+
+def prof_dump(path):
+    _lib.check(_lib.get().pnsfm_prof_dump(path.encode()), "prof_dump")

@@ -70,6 +70,25 @@ def pack_layer_conv3d(x, sd, p, k):
     return conv2d_gn_elu(y, sd, p + '.conv', k)
 
 
+def compose_pack_weight(W2, W3):
+    """Algebra behind the MI355X collapsed packing block (not a reference function):
+    conv2d(conv3d_1to8(x)) has no non-linearity in between (layers01.py:243-246), so in the image interior it equals
+    one (k+2)x(k+2) conv over the D packed channels with
+        W_eff[co, ci, U, V] = sum_{f,dz,dy,dx} W3[f,0,dz,dy,dx] * W2[co, f*D + (ci-dz+1), U-dy, V-dx]."""
+    C, D8, k, _ = W2.shape
+    D = D8 // 8
+    W2v = W2.reshape(C, 8, D, k, k)
+    Weff = W2.new_zeros(C, D, k + 2, k + 2)
+    for dz in range(3):
+        lo, hi = max(0, dz - 1), min(D, D + dz - 1)          # ci range with d = ci-dz+1 in [0, D)
+        for dy in range(3):
+            for dx in range(3):
+                w = W3[:, 0, dz, dy, dx].view(1, 8, 1, 1, 1)
+                contrib = (W2v[:, :, lo - dz + 1:hi - dz + 1] * w).sum(1)          # [C, hi-lo, k, k]
+                Weff[:, lo:hi, dy:dy + k, dx:dx + k] += contrib
+    return Weff
+
+
 def unpack_layer_conv3d(x, sd, p, k):
     """UnpackLayerConv3d: Conv2D(k) -> Conv3d(1->8) -> view -> PixelShuffle(2).  layers01.py:250-286"""
     y = conv2d_gn_elu(x, sd, p + '.conv', k)

@@ -25,14 +25,20 @@ class PackedConvWeight:
     backward pass of the same step reuse the buffers.  Cost when stale: one read + two writes of the weight.
     """
 
-    def __init__(self):
+    def __init__(self, volatile=False):
         self.wp_fwd = None
         self.wp_bwd = None
         self.key_fwd = None
         self.key_bwd = None
+        self.volatile = volatile      # weight is a freshly computed tensor every call (e.g. a composed kernel): always repack
+        self._serial = 0
 
     def get(self, weight, need_bwd):
-        key = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
+        if self.volatile:
+            self._serial += 1
+            key = ('volatile', self._serial)
+        else:
+            key = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
         do_f = self.key_fwd != key
         do_b = need_bwd and self.key_bwd != key
         if do_f or do_b:
@@ -165,6 +171,40 @@ class Conv3d1to8Fn(Function):
 
 def conv3d_1to8(p, w3, b3):
     return Conv3d1to8Fn.apply(p, w3, b3)
+
+
+class ComposePackWeightFn(Function):
+    """W_eff = Conv3d(1->8) composed with the Conv2d that follows it inside PackLayerConv3d (no non-linearity between
+    them, reference layers01.py:243-246):
+
+        W_eff[co, ci, U, V] = sum_{f,dz,dy,dx} W3[f,dz,dy,dx] * W2[co, f*D + (ci-dz+1), U-dy, V-dx]       (k -> k+2 taps)
+
+    which is exactly the backward-data stencil of the Conv3d applied to the zero-ring-padded W2, so the gfx950 conv3d
+    kernels do the composition and its two gradients (dW2 = forward stencil of dW_eff, dW3 = weight-gradient stencil)."""
+
+    @staticmethod
+    def forward(ctx, W2, W3):
+        W2pad = torch.nn.functional.pad(W2.detach(), (1, 1, 1, 1)).contiguous()      # [C, 8D, k+2, k+2]
+        w3 = W3.detach().contiguous()
+        Weff = ops.conv3d_backward_data(W2pad, w3)                                    # [C, D, k+2, k+2]
+        ctx.save_for_backward(W2pad, w3)
+        return Weff
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        W2pad, w3 = ctx.saved_tensors
+        g = g.contiguous()
+        dW2 = dW3 = None
+        if ctx.needs_input_grad[0]:
+            dW2 = ops.conv3d_forward(g, w3, torch.zeros(8, device=g.device, dtype=g.dtype))[:, :, 1:-1, 1:-1].contiguous()
+        if ctx.needs_input_grad[1]:
+            dW3, _ = ops.conv3d_backward_weight(g, W2pad)
+        return dW2, dW3
+
+
+def compose_pack_weight(W2, W3):
+    return ComposePackWeightFn.apply(W2, W3)
 
 
 class InvDepthActFn(Function):

@@ -128,7 +128,18 @@ class UnpackLayerConv2d(nn.Module):
 
 
 class PackLayerConv3d(nn.Module):
-    """3D packing: space-to-depth, Conv3d(1 -> d) over (channel, y, x), then Conv2D back to `in_channels`."""
+    """3D packing: space-to-depth, Conv3d(1 -> d) over (channel, y, x), then Conv2D back to `in_channels`.
+
+    MI355X design: the reference materialises the 8x-expanded Conv3d output (pack1: 252 MB per image) and convolves it
+    with a [C, 32C, k, k] kernel.  There is no non-linearity between the Conv3d and that Conv2d, so away from the image
+    border the pair is ONE (k+2)x(k+2) convolution over the 4C packed channels with a composed kernel
+    (functional.ComposePackWeightFn): 4.1x fewer flops for pack1, and the 8x tensor never exists.  Within k//2 pixels of
+    the border the two differ (the reference zero-pads the Conv3d *output*), so that frame is computed with the
+    original formula on four thin strips and stitched in -- the result equals the reference's up to fp32 summation order.
+    `collapse`: 'auto' (use the composed kernel when it saves >= 30 % of the flops), True, or False.
+    """
+
+    collapse = 'auto'
 
     def __init__(self, in_channels, kernel_size, r=2, d=8):
         super().__init__()
@@ -136,10 +147,55 @@ class PackLayerConv3d(nn.Module):
             raise NotImplementedError('the gfx950 packing kernels implement r=2, d=8 (PackNet01)')
         self.conv = Conv2D(in_channels * (r ** 2) * d, in_channels, kernel_size, 1)
         self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
+        self._eff_packed = HF.PackedConvWeight(volatile=True)
+
+    def _use_collapsed(self, h, w):
+        k = self.conv.kernel_size
+        r = k // 2
+        if h < 2 * r + 1 or w < 2 * r + 1 or self.collapse is False:
+            return False
+        if self.collapse is True:
+            return True
+        orig = 8.0 * k * k * h * w
+        strips = 8.0 * k * k * (2 * (2 * r) * w + 2 * h * (2 * r))
+        return (k + 2) ** 2 * h * w + strips <= 0.7 * orig
+
+    def _conv_reference_form(self, P):
+        """conv_base(Conv3d(P)) exactly as the reference composes it (materialises the 8x tensor)."""
+        feats = HF.conv3d_1to8(P, self.conv3d.weight, self.conv3d.bias)
+        return self.conv.conv_base(feats)
+
+    def _conv_collapsed(self, P):
+        base = self.conv.conv_base
+        W2, b2, W3, b3 = base.weight, base.bias, self.conv3d.weight, self.conv3d.bias
+        C = W2.shape[0]
+        k = self.conv.kernel_size
+        r, S = k // 2, 2 * (k // 2) + 1
+        B, _, h, w = P.shape
+        # interior: one (k+2)x(k+2) conv with the composed kernel; its bias is b2 + sum over ALL taps of W2 * b3
+        W_eff = HF.compose_pack_weight(W2, W3)
+        bias_eff = b2 + (W2.reshape(C, 8, -1).sum(2) * b3.view(1, 8)).sum(1)
+        y = HF.conv2d(P, W_eff, bias_eff, self._eff_packed)
+        # border frame (r pixels): original formula on strips of 2r+1 packed rows / columns (top+bottom and left+right
+        # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept
+        tb = torch.cat((P[:, :, :S], P[:, :, h - S:]), 0).contiguous()
+        z = HF.conv3d_1to8(tb, W3, b3)
+        z = torch.cat((z[:B, :, :2 * r], z[B:, :, 1:]), 0)
+        o = base(z)
+        top, bot = o[:B, :, :r], o[B:, :, r:]
+        lr = torch.cat((P[:, :, :, :S], P[:, :, :, w - S:]), 0).contiguous()
+        z = HF.conv3d_1to8(lr, W3, b3)
+        z = torch.cat((z[:B, :, :, :2 * r], z[B:, :, :, 1:]), 0)
+        o = base(z)
+        left, right = o[:B, :, r:h - r, :r], o[B:, :, r:h - r, r:]
+        mid = torch.cat((left, y[:, :, r:h - r, r:w - r], right), 3)
+        return torch.cat((top, mid, bot), 2)
 
     def forward(self, x):
-        feats = HF.conv3d_1to8(HF.space_to_depth(x), self.conv3d.weight, self.conv3d.bias)
-        return self.conv(feats)
+        P = HF.space_to_depth(x)
+        y = self._conv_collapsed(P) if self._use_collapsed(P.shape[2], P.shape[3]) else self._conv_reference_form(P)
+        norm = self.conv.normalize
+        return HF.groupnorm_act(y, norm.weight, norm.bias, 16, norm.eps, _ops.ACT_ELU)
 
 
 class UnpackLayerConv3d(nn.Module):

@@ -41,8 +41,9 @@ def test_packing_invdepth_golden():
 
 
 @pytest.mark.parametrize('name', ['pack_k3', 'pack_k5'])
-def test_pack_golden(name):
-    P.case_pack(name, DEV)
+@pytest.mark.parametrize('collapse', [False, True])
+def test_pack_golden(name, collapse):
+    P.case_pack(name, DEV, collapse=collapse)
 
 
 def test_unpack_golden():

@@ -29,6 +29,33 @@ def test_pack_k3(emulated_kernels):
     P.case_pack('pack_k3', 'cpu')
 
 
+def test_compose_pack_weight(emulated_kernels):
+    """Kernel composition used by the collapsed packing block (and its gradients) vs the oracle's formula.
+    (The full collapsed block is checked against the reference golden in the -m gpu tests; too slow to emulate.)"""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.hip import functional as HF
+    g = torch.Generator().manual_seed(9)
+    C, D, k = 3, 6, 3
+    W2 = torch.randn(C, 8 * D, k, k, generator=g)
+    W3 = torch.randn(8, 1, 3, 3, 3, generator=g)
+    a, b = W2.clone().requires_grad_(True), W3.clone().requires_grad_(True)
+    ar, br = W2.clone().requires_grad_(True), W3.clone().requires_grad_(True)
+    We = HF.compose_pack_weight(a, b)
+    Wr = O.compose_pack_weight(ar, br)
+    P.check(We, Wr, 1e-5, 'W_eff')
+    go = torch.randn(Wr.shape, generator=g)
+    We.backward(go)
+    Wr.backward(go)
+    P.check(a.grad, ar.grad, 1e-5, 'dW2')
+    P.check(b.grad, br.grad, 1e-5, 'dW3')
+    # the composed kernel reproduces conv2d(conv3d(x)) away from the border (bias-free)
+    x = torch.randn(1, D, 9, 10, generator=g)
+    ref = torch.nn.functional.conv2d(O.conv3d_1to8(x, W3, torch.zeros(8)), W2, padding=k // 2)
+    col = torch.nn.functional.conv2d(x, Wr.detach(), padding=k // 2 + 1)
+    r = k // 2
+    P.check(col[:, :, r:-r, r:-r], ref[:, :, r:-r, r:-r], 1e-5, 'interior equality')
+
+
 @pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean'])
 def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')

@@ -27,18 +27,43 @@ int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 
 static const size_t kMaxSmem = 64 * 1024;
 
+// Blocks resident per CU for a (MT, NT) variant: LDS (160 KiB / block footprint) and the VGPR+AGPR budget
+// (-Rpass-analysis=kernel-resource-usage: <2,2> 141 regs -> 3 waves/SIMD, <2,1>/<1,2> ~75 -> 6, <1,1> ~64 -> 7).
+static int conv_occupancy(int MT, int NT, size_t smem) {
+  int by_regs = (MT == 2 && NT == 2) ? 3 : ((MT == 1 && NT == 1) ? 7 : 6);
+  int by_lds = (int)((160 * 1024) / (smem + 512));
+  int occ = by_regs < by_lds ? by_regs : by_lds;
+  if (occ > 8) occ = 8;
+  if (occ < 1) occ = 1;
+  return occ;
+}
+
+// Relative cost of running `blocks` equal blocks on `slots` concurrently resident block slots: the grid executes in
+// ceil(blocks/slots) rounds and the last one is partially empty ("wave quantisation": 1920 blocks on 768 slots take
+// 3 rounds for 2.5 rounds of work = 83 %).  Split-K multiplies the block count (finer granularity) at the price of
+// atomics + a zero-fill of the output.
+static double quantisation_cost(long blocks, int split, int slots) {
+  const double work = (double)blocks * split / slots;
+  const double rounds = (double)((blocks * split + slots - 1) / slots);
+  double cost = rounds / work;                       // >= 1
+  if (split > 1) cost *= 1.03 + 0.004 * split;       // atomics, memset, shorter K loops
+  return cost;
+}
+
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
-  ConvGeom g;
-  g.MT = conv_pick_MT(Cout);
-  const int BM = 32 * g.MT;
-  g.MP = conv_pack_MP(Cout);
-  g.KP = conv_pack_KP(Cin);
-  g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
-  g.mode = (W % 32 == 0) ? 0 : 1;
-  const int m_tiles = g.MP / BM;
+  ConvGeom best;
+  double best_cost = 1e30;
   const int HW = H * W;
   for (int NT = 2; NT >= 1; --NT) {
+    ConvGeom g;
+    g.MT = conv_pick_MT(Cout);
+    const int BM = 32 * g.MT;
+    g.MP = conv_pack_MP(Cout);
+    g.KP = conv_pack_KP(Cin);
+    g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
+    g.mode = (W % 32 == 0) ? 0 : 1;
     g.NT = NT;
+    const int m_tiles = g.MP / BM;
     if (g.mode == 0) {
       g.tiles_x = W / 32;
       g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
@@ -53,24 +78,28 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
       g.PH = rows + ks - 1;
       g.PW = W + ks - 1;
     }
-    long blocks = (long)B * g.tiles_per_img * m_tiles;
-    size_t smem = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
-    if (NT == 2 && (blocks < 768 || smem > kMaxSmem)) continue;
-    break;
+    // shrink the channel chunk if the halo patch of a very wide image does not fit
+    while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
+    g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
+    if (g.smem_bytes > kMaxSmem) { if (NT == 1) { g.nchunks = ceil_div(g.KP, g.CI); g.splitK = 1; return g; } continue; }
+    g.nchunks = ceil_div(g.KP, g.CI);
+    const long blocks = (long)B * g.tiles_per_img * m_tiles;
+    const int slots = 256 * conv_occupancy(g.MT, NT, g.smem_bytes);
+    // useful pixels / computed pixels of this tiling (partial tiles at the image edge are wasted MFMAs)
+    const double fill = (double)HW / ((double)g.tiles_per_img * 128 * NT);
+    int max_split = g.nchunks < 32 ? g.nchunks : 32;
+    for (int want = 1; want <= max_split; ++want) {
+      const int cps = ceil_div(g.nchunks, want);
+      const int split = ceil_div(g.nchunks, cps);
+      if (split != want) continue;   // not a new configuration
+      // uneven chunk counts per split: the slowest split has `cps` chunks, the average nchunks/split
+      const double imbalance = (double)cps * split / g.nchunks;
+      double cost = quantisation_cost(blocks, split, slots) * imbalance / fill;
+      if (NT == 1) cost *= 1.06;     // one pixel tile per wave: fewer MFMAs per LDS read / barrier
+      if (cost < best_cost) { best_cost = cost; best = g; best.splitK = split; }
+    }
   }
-  // shrink the channel chunk if the halo patch of a very wide image does not fit
-  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
-  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
-  g.nchunks = ceil_div(g.KP, g.CI);
-  long blocks = (long)B * g.tiles_per_img * m_tiles;
-  g.splitK = 1;
-  if (blocks < 1024 && g.nchunks > 1) {
-    int want = (int)((1536 + blocks - 1) / blocks);
-    if (want > g.nchunks) want = g.nchunks;
-    int cps = ceil_div(g.nchunks, want);
-    g.splitK = ceil_div(g.nchunks, cps);
-  }
-  return g;
+  return best;
 }
 
 struct ConvArgs {
@@ -331,6 +360,7 @@ struct WgradArgs {
   const float* x;   // [B][Cin][H][W]
   const float* dy;  // [B][Cout][H][W]
   float* dw;        // [Cout][Cin*KK]
+  float* dbias;     // [Cout] or null: bias gradient (row sums of dY), accumulated by the n-tile-0 blocks
   int B, Cin, Cout, H, W, KS;
   int PT, mode, tiles_x, tiles_per_img, PH, PW, NCI, total_tiles, tiles_per_split, splitP;
   int cstride;  // true H*W (channel stride); H, W above are the TILING dims (k=1 flattens the image to 32-wide rows)
@@ -375,6 +405,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
   const int t_begin = blockIdx.z * a.tiles_per_split;
   int t_end = t_begin + a.tiles_per_split;
   if (t_end > a.total_tiles) t_end = a.total_tiles;
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;
+  float bsum = 0.f;
 
   for (int tt = t_begin; tt < t_end; ++tt) {
     const int b = tt / a.tiles_per_img;
@@ -480,6 +512,15 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
+    if (do_bias) {  // bias gradient rides along: 4 threads per dY row, PT/4 pixels each (tile already in LDS)
+      const int m = tid >> 2, q = tid & 3, span = PT >> 2;
+      if (m < BM) {
+        const float* row = dys + m * DS + q * span;
+        float sacc = 0.f;
+        for (int j = 0; j < span; ++j) sacc += row[j];
+        bsum += sacc;
+      }
+    }
     // ---- K loop over the tile's pixels, 4 k-steps (8 pixels) per batch; the offset-table reads of the NEXT batch
     //      are issued before this batch's MFMAs so the poff -> patch dependent LDS chain is off the critical path
     const float* ab = dys + l32 * DS + half;
@@ -518,29 +559,12 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       }
     }
   }
-}
-
-// per-channel sum over (batch, pixels): dbias[c] = sum dy[b][c][:]
-__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ out,
-                                                           int B, int C, int HW, int nsplit) {
-  __shared__ double red[4];
-  const int c = blockIdx.x;
-  const int s = blockIdx.y;
-  const long total = (long)B * HW;
-  const long per = (total + nsplit - 1) / nsplit;
-  const long beg = s * per;
-  long end = beg + per;
-  if (end > total) end = total;
-  double acc = 0.0;
-  for (long i = beg + threadIdx.x; i < end; i += 256) {
-    const long b = i / HW, p = i - b * HW;
-    acc += (double)dy[((size_t)b * C + c) * HW + p];
+  if (do_bias) {
+    bsum += __shfl_down(bsum, 2);
+    bsum += __shfl_down(bsum, 1);
+    const int m = tid >> 2;
+    if ((tid & 3) == 0 && m < BM && co0 + m < a.Cout) atomicAdd(&a.dbias[co0 + m], bsum);
   }
-  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) red[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&out[c], (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
 }  // namespace pnsfm
@@ -592,7 +616,7 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   hipStream_t s = (hipStream_t)stream;
   const int KK = ks * ks, N = Cin * KK, HW = H * W;
   WgradArgs a;
-  a.x = x; a.dy = dy; a.dw = dw;
+  a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.cstride = HW;
   if (ks == 1) {  // no halo: any pixel order works, so tile the flattened image as 32-wide rows
@@ -629,13 +653,33 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   a.PTlog = a.PT == 128 ? 7 : (a.PT == 64 ? 6 : 5);
   a.total_tiles = B * a.tiles_per_img;
   const int n_tiles = ceil_div(N, 128), m_tiles = ceil_div(Cout, BM);
-  int want = ceil_div(1536, n_tiles * m_tiles);
-  if (want < 1) want = 1;
-  if (want > a.total_tiles) want = a.total_tiles;
-  a.tiles_per_split = ceil_div(a.total_tiles, want);
-  a.splitP = ceil_div(a.total_tiles, a.tiles_per_split);
+  // pixel-tile split: minimise  rounds(blocks / resident slots) x (tiles per block + fixed per-block cost)
+  {
+    int occ = (int)((160 * 1024) / (smem + 512));
+    if (occ > 4) occ = 4;                       // 67 VGPR + 32 AGPR -> 4 waves/SIMD
+    if (occ < 1) occ = 1;
+    const long slots = 256L * occ, base = (long)n_tiles * m_tiles;
+    double best = 1e30;
+    a.splitP = 1;
+    a.tiles_per_split = a.total_tiles;
+    int prev_tps = -1;
+    for (int want = 1; want <= a.total_tiles && want <= 4096; ++want) {
+      const int tps = ceil_div(a.total_tiles, want);
+      if (tps == prev_tps) continue;
+      prev_tps = tps;
+      const int split = ceil_div(a.total_tiles, tps);
+      const double rounds = (double)((base * split + slots - 1) / slots);
+      const double cost = rounds * ((double)tps + 0.75) * (split > 1 ? 1.02 : 1.0);
+      if (cost < best) { best = cost; a.splitP = split; a.tiles_per_split = tps; }
+      if (base * split > 64 * slots) break;
+    }
+  }
   if (a.splitP > 1) {
     int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * N * sizeof(float), s);
+    if (e) { set_error("backward_weight: memset failed"); return e; }
+  }
+  if (dbias) {
+    int e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
     if (e) { set_error("backward_weight: memset failed"); return e; }
   }
   dim3 grid(n_tiles, m_tiles, a.splitP);
@@ -645,19 +689,7 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, a);
   else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, a);
   prof_end(1, s);
-  int e = check_launch("conv2d_backward_weight");
-  if (e) return e;
-  if (dbias) {
-    e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-    if (e) { set_error("backward_weight: memset failed"); return e; }
-    int nsplit = ceil_div(512, Cout);
-    long total = (long)B * HW;
-    if (nsplit > (int)((total + 1023) / 1024)) nsplit = (int)((total + 1023) / 1024);
-    if (nsplit < 1) nsplit = 1;
-    PNSFM_LAUNCH(channel_sum_kernel, dim3(Cout, nsplit), dim3(256), 0, s, dy, dbias, B, Cout, HW, nsplit);
-    e = check_launch("channel_sum");
-  }
-  return e;
+  return check_launch("conv2d_backward_weight");
 }
 
 }  // extern "C"

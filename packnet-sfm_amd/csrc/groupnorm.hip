@@ -20,7 +20,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// stats[(b*G+g)*2 + {0,1}] += {sum, sumsq} over a slice of the group's contiguous (C/G)*HW elements
+// stats[((b*G+g)*nsplit + s)*2 + {0,1}] = {sum, sumsq} over slice s of the group's contiguous (C/G)*HW elements
+// (one slot per block: no zero-fill, no atomics, deterministic; the consumer adds the <= 64 partials)
 __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         double* __restrict__ stats, long n_per_group, int nsplit) {
   __shared__ double red[4];
@@ -41,8 +42,8 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[bg * 2 + 0], s1);
-    atomicAdd(&stats[bg * 2 + 1], s2);
+    stats[((size_t)bg * nsplit + s) * 2 + 0] = s1;
+    stats[((size_t)bg * nsplit + s) * 2 + 1] = s2;
   }
 }
 
@@ -62,13 +63,18 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const double* __restrict__ stats, float* __restrict__ y,
                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                        int C, int HW, int G, float eps, int act, int chunk) {
+                                                        int C, int HW, int G, float eps, int act, int chunk, int nsplit) {
   const int bc = blockIdx.x;
   const int b = bc / C, c = bc - b * C;
   const int cpg = C / G, g = c / cpg;
   const double n = (double)cpg * (double)HW;
-  const double m = stats[(b * G + g) * 2 + 0] / n;
-  double var = stats[(b * G + g) * 2 + 1] / n - m * m;
+  double t1 = 0.0, t2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    t1 += stats[((size_t)(b * G + g) * nsplit + k) * 2 + 0];
+    t2 += stats[((size_t)(b * G + g) * nsplit + k) * 2 + 1];
+  }
+  const double m = t1 / n;
+  double var = t2 / n - m * m;
   if (var < 0.0) var = 0.0;
   const float mean = (float)m;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -89,7 +95,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   }
 }
 
-// red[(b*C+c)*2 + {0,1}] += { sum dz, sum dz * xhat } over a chunk of HW;  dz = dy * act'(z)
+// red[((b*C+c)*nchunk + chunk)*2 + {0,1}] = { sum dz, sum dz * xhat } over one chunk of HW;  dz = dy * act'(z)
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ res, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ mean,
@@ -117,8 +123,8 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
   if (threadIdx.x == 0) {
-    atomicAdd(&red_ws[(size_t)bc * 2 + 0], s1);
-    atomicAdd(&red_ws[(size_t)bc * 2 + 1], s2);
+    red_ws[((size_t)bc * gridDim.y + blockIdx.y) * 2 + 0] = s1;
+    red_ws[((size_t)bc * gridDim.y + blockIdx.y) * 2 + 1] = s2;
   }
 }
 
@@ -132,11 +138,17 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   const int b = bc / C, c = bc - b * C;
   const int cpg = C / G, g = c / cpg;
   double A = 0.0, Bq = 0.0;
+  const int nchunk = gridDim.y;
   for (int k = 0; k < cpg; ++k) {
     const int cc = g * cpg + k;
     const double gk = (double)gamma[cc];
-    A += gk * red_ws[((size_t)b * C + cc) * 2 + 0];
-    Bq += gk * red_ws[((size_t)b * C + cc) * 2 + 1];
+    double r1 = 0.0, r2 = 0.0;
+    for (int j = 0; j < nchunk; ++j) {
+      r1 += red_ws[(((size_t)b * C + cc) * nchunk + j) * 2 + 0];
+      r2 += red_ws[(((size_t)b * C + cc) * nchunk + j) * 2 + 1];
+    }
+    A += gk * r1;
+    Bq += gk * r2;
   }
   const double n = (double)cpg * (double)HW;
   const float mA = (float)(A / n), mB = (float)(Bq / n);
@@ -156,14 +168,15 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
 }
 
 __global__ void __launch_bounds__(256) gn_bwd_params_kernel(const double* __restrict__ red_ws, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int B, int C) {
+                                                             float* __restrict__ dbeta, int B, int C, int nchunk) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    s1 += red_ws[((size_t)b * C + c) * 2 + 0];
-    s2 += red_ws[((size_t)b * C + c) * 2 + 1];
-  }
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < nchunk; ++j) {
+      s1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
+      s2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
+    }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
 }
@@ -172,6 +185,7 @@ static int pick_chunk(int HW, int rows) {
   // aim for >= ~1024 blocks overall, chunks a multiple of 256 elements, at least 1024 elements each
   int want = ceil_div(1024, rows);
   if (want < 1) want = 1;
+  if (want > PNSFM_GN_MAX_SPLIT) want = PNSFM_GN_MAX_SPLIT;
   int chunk = ceil_div(HW, want);
   if (chunk < 1024) chunk = 1024;
   chunk = round_up(chunk, 256);
@@ -189,19 +203,18 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
                                 int act, void* stream) {
   if (C % G != 0 || B <= 0 || HW <= 0) { set_error("groupnorm_forward: bad shape C=%d G=%d", C, G); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(stats_ws, 0, (size_t)2 * B * G * sizeof(double), s);
-  if (e) { set_error("groupnorm_forward: memset failed"); return e; }
   const long npg = (long)(C / G) * HW;
   int nsplit = ceil_div(1024, B * G);
   const int max_split = (int)((npg + 2047) / 2048);
   if (nsplit > max_split) nsplit = max_split;
+  if (nsplit > PNSFM_GN_MAX_SPLIT) nsplit = PNSFM_GN_MAX_SPLIT;
   if (nsplit < 1) nsplit = 1;
   PNSFM_LAUNCH(gn_stats_kernel, dim3(B * G, nsplit), dim3(256), 0, s, x, res, stats_ws, npg, nsplit);
-  e = check_launch("gn_stats");
+  int e = check_launch("gn_stats");
   if (e) return e;
   const int chunk = pick_chunk(HW, B * C);
   PNSFM_LAUNCH(gn_apply_kernel, dim3(B * C, ceil_div(HW, chunk)), dim3(256), 0, s, x, res, gamma, beta,
-               (const double*)stats_ws, y, mean, rstd, C, HW, G, eps, act, chunk);
+               (const double*)stats_ws, y, mean, rstd, C, HW, G, eps, act, chunk, nsplit);
   return check_launch("gn_apply");
 }
 
@@ -210,10 +223,10 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
                                  float* dbeta, double* red_ws, int B, int C, int HW, int G, int act, void* stream) {
   if (C % G != 0 || B <= 0 || HW <= 0) { set_error("groupnorm_backward: bad shape C=%d G=%d", C, G); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(red_ws, 0, (size_t)2 * B * C * sizeof(double), s);
-  if (e) { set_error("groupnorm_backward: memset failed"); return e; }
+  int e = 0;
   const int chunk = pick_chunk(HW, B * C);
   dim3 grid(B * C, ceil_div(HW, chunk));
+  if ((int)grid.y > PNSFM_GN_MAX_SPLIT) { set_error("groupnorm_backward: too many chunks"); return -1; }
   PNSFM_LAUNCH(gn_bwd_reduce_kernel, grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, C, HW, G, act, chunk);
   e = check_launch("gn_bwd_reduce");
   if (e) return e;
@@ -221,7 +234,7 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
                C, HW, G, act, chunk);
   e = check_launch("gn_bwd_apply");
   if (e) return e;
-  PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)red_ws, dgamma, dbeta, B, C);
+  PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)red_ws, dgamma, dbeta, B, C, (int)grid.y);
   return check_launch("gn_bwd_params");
 }
 

@@ -47,33 +47,35 @@ __global__ void __launch_bounds__(256) d2s_kernel(const float* __restrict__ x, f
 }
 
 // out[b][f*D+d][y][x] = b3[f] + sum_{dz,dy,dx} w3[f][dz][dy][dx] * p[b][d+dz-1][y+dy-1][x+dx-1]
-// grid: (ceil(HW/256), D, B): one thread per (d, y, x) produces all 8 features; 27 branch-free neighbour loads
-// (L1/L2 serve the 9x/3x overlap between neighbouring threads and planes), 216 FMAs, 8 coalesced stores.
+// grid: (ceil(D*HW/256), 1, B): one thread per voxel (d, y, x) -- flattened so that small planes (the 7x7 / 5x5 weight
+// volumes of the kernel composition, or 6x20 feature maps) still fill every lane -- produces all 8 features;
+// 27 branch-free neighbour loads (L1/L2 serve the overlap between neighbouring threads), 216 FMAs, 8 stores.
 __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w3,
                                                           const float* __restrict__ b3, float* __restrict__ out,
                                                           int D, int H, int W) {
   __shared__ float ws[8 * 27 + 8];
   for (int i = threadIdx.x; i < 8 * 27 + 8; i += 256) ws[i] = i < 216 ? w3[i] : b3[i - 216];
   __syncthreads();
-  const int HW = H * W;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  const int d = blockIdx.y, b = blockIdx.z;
-  const bool active = pix < HW;
-  const int y = active ? pix / W : 0, x = active ? pix - y * W : 0;
-  const float* pb = p + (size_t)b * D * HW;
+  const int HW = H * W, DHW = D * HW;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.z;
+  const bool active = vox < DHW;
+  const int d = active ? vox / HW : 0;
+  const int pix = active ? vox - d * HW : 0;
+  const int y = pix / W, x = pix - y * W;
+  const float* pb = p + (size_t)b * DHW;
   float v[27];
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz) {
     const int dd = d + dz - 1;
-    const bool dok = dd >= 0 && dd < D;            // block-uniform
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y + dy - 1;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int xx = x + dx - 1;
-        const bool ok = active && dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
+        const bool ok = active && dd >= 0 && dd < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int off = ok ? (dd * HW + yy * W + xx) : 0;
         const float t = pb[off];
         v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
       }
@@ -87,9 +89,9 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int f = 0; f < 8; ++f) acc[f] = fmaf(ws[f * 27 + tap], v[tap], acc[f]);
   if (active) {
-    float* ob = out + ((size_t)b * 8 * D + d) * HW + pix;
+    float* ob = out + (size_t)b * 8 * DHW + vox;
 #pragma unroll
-    for (int f = 0; f < 8; ++f) ob[(size_t)f * D * HW] = acc[f];
+    for (int f = 0; f < 8; ++f) ob[(size_t)f * DHW] = acc[f];
   }
 }
 
@@ -100,17 +102,19 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
   __shared__ float ws[8 * 27];
   for (int i = threadIdx.x; i < 8 * 27; i += 256) ws[i] = w3[i];
   __syncthreads();
-  const int HW = H * W;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  const int d = blockIdx.y, b = blockIdx.z;
-  const bool active = pix < HW;
-  const int y = active ? pix / W : 0, x = active ? pix - y * W : 0;
-  const float* gb = dout + (size_t)b * 8 * D * HW;
+  const int HW = H * W, DHW = D * HW;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.z;
+  const bool active = vox < DHW;
+  const int d = active ? vox / HW : 0;
+  const int pix = active ? vox - d * HW : 0;
+  const int y = pix / W, x = pix - y * W;
+  const float* gb = dout + (size_t)b * 8 * DHW;
   float acc = 0.f;
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz) {
     const int dd = d - dz + 1;
-    if (dd < 0 || dd >= D) continue;                // block-uniform
+    const bool dok = active && dd >= 0 && dd < D;
     float g[8][9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -118,11 +122,11 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int xx = x - dx + 1;
-        const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
+        const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int off = ok ? (dd * HW + yy * W + xx) : 0;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-          const float t = gb[(size_t)f * D * HW + off];
+          const float t = gb[(size_t)f * DHW + off];
           g[f][dy * 3 + dx] = ok ? t : 0.f;
         }
       }
@@ -132,55 +136,58 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc = fmaf(ws[f * 27 + dz * 9 + t], g[f][t], acc);
   }
-  if (active) dp[((size_t)b * D + d) * HW + pix] = acc;
+  if (active) dp[(size_t)b * DHW + vox] = acc;
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
-// grid: (nblk, 2): blockIdx.y picks 4 of the 8 features, so the 27 neighbours of a position are loaded twice (not 8x);
-// each block walks whole (b, d) planes. 4*28 register accumulators per thread -> wave shuffle -> LDS -> fp64 atomics.
+// grid: (nblk, 2): blockIdx.y picks 4 of the 8 features, so the 27 neighbours of a voxel are loaded twice (not 8x);
+// blocks grid-stride over the flattened (b, d, y, x) volume in units of 256 voxels.
+// 4*28 register accumulators per thread -> wave shuffle -> LDS -> fp64 atomics.
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
                                                             double* __restrict__ ws, int B, int D, int H, int W) {
   __shared__ float red[4][112];
   const int f0 = blockIdx.y * 4;
-  const int HW = H * W;
+  const int HW = H * W, DHW = D * HW;
+  const int chunks_per_b = (DHW + 255) / 256;
   float acc[4][28];
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
     for (int t = 0; t < 28; ++t) acc[f][t] = 0.f;
-  for (int plane = blockIdx.x; plane < B * D; plane += gridDim.x) {
-    const int b = plane / D, d = plane - b * D;
-    const float* pb = p + (size_t)b * D * HW;
-    const float* gb = dout + ((size_t)b * 8 * D + d) * HW;
-    for (int pix = threadIdx.x; pix < HW; pix += 256) {
-      const int y = pix / W, x = pix - y * W;
-      float g[4];
+  for (int c = blockIdx.x; c < B * chunks_per_b; c += gridDim.x) {
+    const int b = c / chunks_per_b;
+    const int vox = (c - b * chunks_per_b) * 256 + threadIdx.x;
+    const bool active = vox < DHW;
+    const int d = active ? vox / HW : 0;
+    const int pix = active ? vox - d * HW : 0;
+    const int y = pix / W, x = pix - y * W;
+    const float* pb = p + (size_t)b * DHW;
+    const float* gb = dout + (size_t)b * 8 * DHW + (active ? vox : 0);
+    float g[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) g[f] = gb[(size_t)(f0 + f) * D * HW + pix];
-      float v[27];
+    for (int f = 0; f < 4; ++f) { const float t = gb[(size_t)(f0 + f) * DHW]; g[f] = active ? t : 0.f; }
+    float v[27];
 #pragma unroll
-      for (int dz = 0; dz < 3; ++dz) {
-        const int dd = d + dz - 1;
-        const bool dok = dd >= 0 && dd < D;
+    for (int dz = 0; dz < 3; ++dz) {
+      const int dd = d + dz - 1;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int yy = y + dy - 1;
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int xx = x + dx - 1;
-            const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t off = ok ? ((size_t)dd * HW + yy * W + xx) : 0;
-            const float t = pb[off];
-            v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
-          }
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xx = x + dx - 1;
+          const bool ok = active && dd >= 0 && dd < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const int off = ok ? (dd * HW + yy * W + xx) : 0;
+          const float t = pb[off];
+          v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
         }
       }
+    }
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < 4; ++f) {
 #pragma unroll
-        for (int t = 0; t < 27; ++t) acc[f][t] = fmaf(g[f], v[t], acc[f][t]);
-        acc[f][27] += g[f];
-      }
+      for (int t = 0; t < 27; ++t) acc[f][t] = fmaf(g[f], v[t], acc[f][t]);
+      acc[f][27] += g[f];
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,12 +243,12 @@ int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, v
 
 int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W,
                               void* stream) {
-  PNSFM_LAUNCH(conv3d_fwd_kernel, dim3(ceil_div(H * W, 256), D, B), dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
+  PNSFM_LAUNCH(conv3d_fwd_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
   return check_launch("conv3d_forward");
 }
 
 int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(H * W, 256), D, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
+  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
   return check_launch("conv3d_backward_data");
 }
 
@@ -250,8 +257,8 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
   if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
-  int nblk = B * D;
-  if (nblk > 1024) nblk = 1024;
+  int nblk = B * ceil_div(D * H * W, 256);
+  if (nblk > 2048) nblk = 2048;
   PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk, 2), dim3(256), 0, s, p, dout, ws, B, D, H, W);
   e = check_launch("conv3d_backward_weight");
   if (e) return e;

@@ -46,6 +46,11 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
                                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 
+/* Runtime autotuning of the conv kernels' tiling / split factors (default on; env PNSFM_AUTOTUNE=0 turns it off).
+ * The first call for a new shape times the candidate configurations on the caller's stream (it synchronises), like
+ * `torch.backends.cudnn.benchmark = True` in the reference (trainers/horovod_trainer.py:19). */
+int pnsfm_set_autotune(int on);
+
 /* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the
  * residual form `activ(normalize(x_out + shortcut))`: layers01.py:61-62,72.

@@ -19,6 +19,11 @@
 #include "pnsfm_common.h"
 #include "../../include/pnsfm.h"
 
+#include <array>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
 namespace pnsfm {
 
 int conv_pick_MT(int Mc) { return (round_up(Mc, 64) == round_up(Mc, 32)) ? 2 : 1; }
@@ -27,79 +32,78 @@ int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 
 static const size_t kMaxSmem = 64 * 1024;
 
-// Blocks resident per CU for a (MT, NT) variant: LDS (160 KiB / block footprint) and the VGPR+AGPR budget
-// (-Rpass-analysis=kernel-resource-usage: <2,2> 141 regs -> 3 waves/SIMD, <2,1>/<1,2> ~75 -> 6, <1,1> ~64 -> 7).
-static int conv_occupancy(int MT, int NT, size_t smem) {
-  int by_regs = (MT == 2 && NT == 2) ? 3 : ((MT == 1 && NT == 1) ? 7 : 6);
-  int by_lds = (int)((160 * 1024) / (smem + 512));
-  int occ = by_regs < by_lds ? by_regs : by_lds;
-  if (occ > 8) occ = 8;
-  if (occ < 1) occ = 1;
-  return occ;
-}
-
-// Relative cost of running `blocks` equal blocks on `slots` concurrently resident block slots: the grid executes in
-// ceil(blocks/slots) rounds and the last one is partially empty ("wave quantisation": 1920 blocks on 768 slots take
-// 3 rounds for 2.5 rounds of work = 83 %).  Split-K multiplies the block count (finer granularity) at the price of
-// atomics + a zero-fill of the output.
-static double quantisation_cost(long blocks, int split, int slots) {
-  const double work = (double)blocks * split / slots;
-  const double rounds = (double)((blocks * split + slots - 1) / slots);
-  double cost = rounds / work;                       // >= 1
-  if (split > 1) cost *= 1.03 + 0.004 * split;       // atomics, memset, shorter K loops
-  return cost;
-}
-
-ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
-  ConvGeom best;
-  double best_cost = 1e30;
+// Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
+static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g) {
   const int HW = H * W;
-  for (int NT = 2; NT >= 1; --NT) {
-    ConvGeom g;
-    g.MT = conv_pick_MT(Cout);
-    const int BM = 32 * g.MT;
-    g.MP = conv_pack_MP(Cout);
-    g.KP = conv_pack_KP(Cin);
-    g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
-    g.mode = (W % 32 == 0) ? 0 : 1;
-    g.NT = NT;
-    const int m_tiles = g.MP / BM;
-    if (g.mode == 0) {
-      g.tiles_x = W / 32;
-      g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
-      g.PH = 4 * NT + ks - 1;
-      g.PW = 32 + ks - 1;
-    } else {
-      const int tile_px = 128 * NT;
-      g.tiles_x = 0;
-      g.tiles_per_img = ceil_div(HW, tile_px);
-      int rows = (tile_px + W - 2) / W + 1;
-      if (rows > H) rows = H;
-      g.PH = rows + ks - 1;
-      g.PW = W + ks - 1;
-    }
-    // shrink the channel chunk if the halo patch of a very wide image does not fit
-    while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
-    g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
-    if (g.smem_bytes > kMaxSmem) { if (NT == 1) { g.nchunks = ceil_div(g.KP, g.CI); g.splitK = 1; return g; } continue; }
-    g.nchunks = ceil_div(g.KP, g.CI);
-    const long blocks = (long)B * g.tiles_per_img * m_tiles;
-    const int slots = 256 * conv_occupancy(g.MT, NT, g.smem_bytes);
-    // useful pixels / computed pixels of this tiling (partial tiles at the image edge are wasted MFMAs)
-    const double fill = (double)HW / ((double)g.tiles_per_img * 128 * NT);
-    int max_split = g.nchunks < 32 ? g.nchunks : 32;
-    for (int want = 1; want <= max_split; ++want) {
-      const int cps = ceil_div(g.nchunks, want);
-      const int split = ceil_div(g.nchunks, cps);
-      if (split != want) continue;   // not a new configuration
-      // uneven chunk counts per split: the slowest split has `cps` chunks, the average nchunks/split
-      const double imbalance = (double)cps * split / g.nchunks;
-      double cost = quantisation_cost(blocks, split, slots) * imbalance / fill;
-      if (NT == 1) cost *= 1.06;     // one pixel tile per wave: fewer MFMAs per LDS read / barrier
-      if (cost < best_cost) { best_cost = cost; best = g; best.splitK = split; }
-    }
+  g.MT = conv_pick_MT(Cout);
+  const int BM = 32 * g.MT;
+  g.MP = conv_pack_MP(Cout);
+  g.KP = conv_pack_KP(Cin);
+  g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
+  g.mode = (W % 32 == 0) ? 0 : 1;
+  g.NT = NT;
+  if (g.mode == 0) {
+    g.tiles_x = W / 32;
+    g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
+    g.PH = 4 * NT + ks - 1;
+    g.PW = 32 + ks - 1;
+  } else {
+    const int tile_px = 128 * NT;
+    g.tiles_x = 0;
+    g.tiles_per_img = ceil_div(HW, tile_px);
+    int rows = (tile_px + W - 2) / W + 1;
+    if (rows > H) rows = H;
+    g.PH = rows + ks - 1;
+    g.PW = W + ks - 1;
   }
-  return best;
+  // shrink the channel chunk if the halo patch of a very wide image does not fit
+  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
+  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
+  g.nchunks = ceil_div(g.KP, g.CI);
+  if (want_split < 1) want_split = 1;
+  if (want_split > g.nchunks) want_split = g.nchunks;
+  const int cps = ceil_div(g.nchunks, want_split);
+  g.splitK = ceil_div(g.nchunks, cps);
+  return g.smem_bytes <= kMaxSmem;
+}
+
+// Default (un-tuned) choice: two pixel tiles per wave when that still gives >= 4 blocks per CU; split K only when the
+// grid cannot give every CU ~6 blocks and each split keeps >= 2 channel chunks.  The runtime autotuner below
+// (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
+ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
+  ConvGeom g;
+  int NT = 2;
+  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g) ||
+      (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
+  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g);
+  const long blocks = (long)B * g.tiles_per_img * (g.MP / (32 * g.MT));
+  int split = 1;
+  if (blocks < 4 * 256 && g.nchunks >= 4) {
+    split = (int)((6 * 256 + blocks - 1) / blocks);
+    if (split > g.nchunks / 2) split = g.nchunks / 2;
+    if (split < 1) split = 1;
+  }
+  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g);
+  return g;
+}
+
+// ---- runtime autotuning ---------------------------------------------------------------------------------------------
+// First call for a new (kind, shape): time the candidate (NT, split) configurations on the caller's stream with
+// hipEvents (this synchronises -- it happens during warm-up only) and remember the fastest.  PNSFM_AUTOTUNE=0 disables.
+static int g_autotune = -1;
+static std::map<std::array<int, 7>, std::array<int, 2>> g_tuned;
+static std::mutex g_tune_mu;
+
+static bool autotune_enabled() {
+#ifdef PNSFM_EMU
+  return false;
+#else
+  if (g_autotune < 0) {
+    const char* e = getenv("PNSFM_AUTOTUNE");
+    g_autotune = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_autotune == 1;
+#endif
 }
 
 struct ConvArgs {
@@ -272,12 +276,8 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   }
 }
 
-static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
-                       int H, int W, int ks, hipStream_t stream, const char* what) {
-  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
-  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
-  ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks);
-  if (g.smem_bytes > kMaxSmem) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
+static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
+                        int Cout, int H, int W, int ks, hipStream_t stream, const char* what) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.y = y;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
@@ -291,15 +291,69 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     if (e) { set_error("%s: memset failed", what); return e; }
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
-  const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
-  const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(grid.x * grid.y * grid.z)};
-  prof_begin(0, flops, stream, meta);
   if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a);
   else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a);
   else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a);
   else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a);
-  prof_end(0, stream);
   return check_launch(what);
+}
+
+#ifndef PNSFM_EMU
+// time `reps` back-to-back executions of fn() on `stream`; returns ms per execution (or < 0 on error)
+template <class F>
+static float time_on_stream(hipStream_t stream, int reps, F fn) {
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!e0) { if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f; }
+  if (fn() != 0) return -1.f;                     // warm-up (also faults in code objects)
+  if (hipEventRecord(e0, stream) != hipSuccess) return -1.f;
+  for (int i = 0; i < reps; ++i) if (fn() != 0) return -1.f;
+  if (hipEventRecord(e1, stream) != hipSuccess) return -1.f;
+  if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+  return ms / reps;
+}
+#endif
+
+static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
+                       int H, int W, int ks, hipStream_t stream, const char* what, int kind_tag) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
+  ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks);
+  if (g.smem_bytes > kMaxSmem) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
+#ifndef PNSFM_EMU
+  if (autotune_enabled()) {
+    const std::array<int, 7> key = {kind_tag, B, Cin, Cout, H, W, ks};
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it == g_tuned.end()) {
+      static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+      float best_ms = 1e30f;
+      std::array<int, 2> best = {g.NT, g.splitK};
+      for (int NT = 2; NT >= 1; --NT) {
+        int last_split = -1;
+        for (int want : kSplits) {
+          ConvGeom c;
+          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c)) break;
+          if (c.splitK == last_split) continue;
+          last_split = c.splitK;
+          const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
+          if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
+          const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what); });
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT, c.splitK}; }
+        }
+      }
+      it = g_tuned.emplace(key, best).first;
+    }
+    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0], it->second[1], g);
+  }
+#endif
+  const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
+  const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
+  prof_begin(0, flops, stream, meta);
+  const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what);
+  prof_end(0, stream);
+  return rc;
 }
 
 // ---- weight packers -----------------------------------------------------------------------------
@@ -601,13 +655,13 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
 
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin, int Cout,
                          int H, int W, int ks, void* stream) {
-  return launch_conv(x, wp_fwd, bias, y, B, Cin, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward");
+  return launch_conv(x, wp_fwd, bias, y, B, Cin, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward", 0);
 }
 
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx, int B, int Cin, int Cout, int H,
                                int W, int ks, void* stream) {
   // dX = conv(dY, flipped/transposed W): K-channels = Cout, M-channels = Cin
-  return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data");
+  return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data", 1);
 }
 
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
@@ -674,22 +728,58 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
       if (base * split > 64 * slots) break;
     }
   }
-  if (a.splitP > 1) {
-    int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * N * sizeof(float), s);
-    if (e) { set_error("backward_weight: memset failed"); return e; }
+  auto enqueue = [&](int split) -> int {
+    WgradArgs c = a;
+    c.tiles_per_split = ceil_div(a.total_tiles, split);
+    c.splitP = ceil_div(a.total_tiles, c.tiles_per_split);
+    if (c.splitP > 1) {
+      int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * N * sizeof(float), s);
+      if (e) { set_error("backward_weight: memset failed"); return e; }
+    }
+    if (dbias) {
+      int e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+      if (e) { set_error("backward_weight: memset failed"); return e; }
+    }
+    dim3 grid(n_tiles, m_tiles, c.splitP);
+    if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, c);
+    else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, c);
+    return check_launch("conv2d_backward_weight");
+  };
+#ifndef PNSFM_EMU
+  if (autotune_enabled()) {
+    const std::array<int, 7> key = {2, B, Cin, Cout, a.cstride, W, ks};
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it == g_tuned.end()) {
+      float best_ms = 1e30f;
+      int best_split = a.splitP, prev_tps = -1;
+      const long base = (long)n_tiles * m_tiles;
+      for (int want = 1; want <= a.total_tiles; want = want < 8 ? want + 1 : (want * 3 + 1) / 2) {
+        const int tps = ceil_div(a.total_tiles, want);
+        if (tps == prev_tps) continue;
+        prev_tps = tps;
+        const int split = ceil_div(a.total_tiles, tps);
+        if (base * split < 192 && split < a.total_tiles) continue;   // cannot fill the chip: not worth timing
+        if (base * split > 40L * 256 && split > 1) break;
+        const float ms = time_on_stream(s, 2, [&]() { return enqueue(split); });
+        if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; }
+      }
+      it = g_tuned.emplace(key, std::array<int, 2>{best_split, 0}).first;
+    }
+    a.splitP = it->second[0];
   }
-  if (dbias) {
-    int e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-    if (e) { set_error("backward_weight: memset failed"); return e; }
-  }
-  dim3 grid(n_tiles, m_tiles, a.splitP);
+#endif
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
-  const int meta[8] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(grid.x * grid.y * grid.z)};
+  const int meta[8] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(n_tiles * m_tiles * a.splitP)};
   prof_begin(1, flops, s, meta);
-  if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, a);
-  else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, a);
+  const int rc = enqueue(a.splitP);
   prof_end(1, s);
-  return check_launch("conv2d_backward_weight");
+  return rc;
+}
+
+int pnsfm_set_autotune(int on) {
+  g_autotune = on ? 1 : 0;
+  return 0;
 }
 
 }  // extern "C"

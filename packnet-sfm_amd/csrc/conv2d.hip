@@ -33,7 +33,8 @@ int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 static const size_t kMaxSmem = 64 * 1024;
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
-static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g) {
+static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DA = 1) {
+  g.DA = DA;
   const int HW = H * W;
   g.MT = conv_pick_MT(Cout);
   const int BM = 32 * g.MT;
@@ -57,8 +58,10 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.PW = W + ks - 1;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
-  while (((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
-  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + 2 * (size_t)g.CI * BM) * sizeof(float);
+  const size_t wslab = DA ? 0 : 2 * (size_t)16 * BM;
+  while (((size_t)g.CI * g.PH * g.PW + 4 + (DA ? 0 : 2 * (size_t)g.CI * BM)) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
+  (void)wslab;
+  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + (DA ? 0 : 2 * (size_t)g.CI * BM)) * sizeof(float);
   g.nchunks = ceil_div(g.KP, g.CI);
   if (want_split < 1) want_split = 1;
   if (want_split > g.nchunks) want_split = g.nchunks;
@@ -70,12 +73,15 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
 // Default (un-tuned) choice: two pixel tiles per wave when that still gives >= 4 blocks per CU; split K only when the
 // grid cannot give every CU ~6 blocks and each split keeps >= 2 channel chunks.  The runtime autotuner below
 // (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
+static int g_default_da = 1;   // un-tuned default: direct-A variant (see pnsfm_set_conv_variant)
+
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
   ConvGeom g;
   int NT = 2;
-  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g) ||
+  const int DA = g_default_da;
+  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA) ||
       (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
-  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g);
+  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA);
   const long blocks = (long)B * g.tiles_per_img * (g.MP / (32 * g.MT));
   int split = 1;
   if (blocks < 4 * 256 && g.nchunks >= 4) {
@@ -83,7 +89,7 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
     if (split > g.nchunks / 2) split = g.nchunks / 2;
     if (split < 1) split = 1;
   }
-  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g);
+  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, DA);
   return g;
 }
 
@@ -116,7 +122,11 @@ struct ConvArgs {
   float invPW, invPS;
 };
 
-template <int MT, int NT>
+// DA = "direct A": each wave fetches its MFMA A fragments (weights) straight from global/L2 into registers, one tap
+// ahead, instead of sharing a per-tap LDS slab.  The four waves of a block then run the whole k*k tap loop of a channel
+// chunk WITHOUT barriers (2 barriers per chunk instead of k*k+1) and the LDS holds only the input patch; the price is
+// that the same 4 KB slab is read by four waves (coalesced 128-B rows, L1/L2-resident: ~8 B/clk/CU).
+template <int MT, int NT, bool DA>
 __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   PNSFM_DYN_SMEM(float, smem);
   constexpr int BM = 32 * MT;
@@ -211,6 +221,52 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
         }
       }
     }
+    const int ksteps = a.CI >> 1;
+    if constexpr (DA) {
+      __syncthreads();   // patch staged
+      const float* abase = a.wp + co0 + l32;
+      const size_t tap_stride = (size_t)a.KP * a.MP;
+      float A0[8][MT], A1[8][MT];
+      auto loadA = [&](int tap, float (&dst)[8][MT]) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int row = ci0 + 2 * kk + half;
+          const bool ok = kk < ksteps && row < a.KP;
+          const float* src = abase + (ok ? (size_t)tap * tap_stride + (size_t)row * a.MP : 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) { const float t = src[mt * 32]; dst[kk][mt] = ok ? t : 0.f; }
+        }
+      };
+      auto compute = [&](int tap, const float (&A)[8][MT]) {
+        const int ky = tap / a.KS, kx = tap - ky * a.KS;
+        const float* pb = patch + half * PS + ky * a.PW + kx;
+#pragma unroll
+        for (int kb = 0; kb < 8; kb += 4) {
+          if (kb < ksteps) {
+            float bv[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) bv[j][nt] = pb[(kb + j) * 2 * PS + boff[nt]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(A[kb + j][mt], bv[j][nt], acc[mt][nt]);
+          }
+        }
+      };
+      loadA(0, A0);
+      int tap = 0;
+      for (; tap + 1 < KK; tap += 2) {
+        loadA(tap + 1, A1);
+        compute(tap, A0);
+        if (tap + 2 < KK) loadA(tap + 2, A0);
+        compute(tap + 1, A1);
+      }
+      if (tap < KK) compute(tap, A0);
+    } else {
     // ---- tap 0 weight slab (rows past the packed K extent are zero)
     const bool wact = wrow < a.CI;
     const bool wok = wact && (ci0 + wrow) < a.KP;
@@ -221,7 +277,6 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if (wact) *reinterpret_cast<float4*>(wbuf + wrow * BM + wc4 * 4) = wreg;
     __syncthreads();
 
-    const int ksteps = a.CI >> 1;
     for (int tap = 0; tap < KK; ++tap) {
       const int cur = tap & 1;
       if (tap + 1 < KK) {
@@ -250,6 +305,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
       }
       if (tap + 1 < KK && wact) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
       __syncthreads();
+    }
     }
   }
 
@@ -291,10 +347,17 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     if (e) { set_error("%s: memset failed", what); return e; }
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
-  if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a);
-  else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a);
-  else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a);
-  else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a);
+  if (g.DA) {
+    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, true>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, true>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, true>), grid, dim3(256), g.smem_bytes, stream, a);
+    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, true>), grid, dim3(256), g.smem_bytes, stream, a);
+  } else {
+    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, false>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, false>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, false>), grid, dim3(256), g.smem_bytes, stream, a);
+    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, false>), grid, dim3(256), g.smem_bytes, stream, a);
+  }
   return check_launch(what);
 }
 
@@ -329,23 +392,24 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     if (it == g_tuned.end()) {
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
-      std::array<int, 2> best = {g.NT, g.splitK};
-      for (int NT = 2; NT >= 1; --NT) {
+      std::array<int, 2> best = {g.NT | (g.DA << 4), g.splitK};
+      for (int cfg = 0; cfg < 4; ++cfg) {
+        const int NT = 2 - (cfg & 1), DA = 1 - (cfg >> 1);
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
-          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c)) break;
+          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA)) break;
           if (c.splitK == last_split) continue;
           last_split = c.splitK;
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
           const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what); });
-          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT, c.splitK}; }
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4), c.splitK}; }
         }
       }
       it = g_tuned.emplace(key, best).first;
     }
-    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0], it->second[1], g);
+    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, it->second[0] >> 4);
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
@@ -779,6 +843,13 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
 
 int pnsfm_set_autotune(int on) {
   g_autotune = on ? 1 : 0;
+  return 0;
+}
+
+int pnsfm_set_conv_variant(int direct_a) {
+  g_default_da = direct_a ? 1 : 0;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tuned.clear();
   return 0;
 }
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pnsfm_smoothness_backward": (_i, [_p, _p, _p, _f, _f, _i, _i, _i, _p]),
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),
     "pnsfm_set_autotune": (_i, [_i]),
+    "pnsfm_set_conv_variant": (_i, [_i]),
     "pnsfm_prof_enable": (_i, [_i]),
     "pnsfm_prof_reset": (_i, []),
     "pnsfm_prof_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

@@ -58,10 +58,13 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.PW = W + ks - 1;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
-  const size_t wslab = DA ? 0 : 2 * (size_t)16 * BM;
-  while (((size_t)g.CI * g.PH * g.PW + 4 + (DA ? 0 : 2 * (size_t)g.CI * BM)) * sizeof(float) > kMaxSmem && g.CI > 8) g.CI /= 2;
-  (void)wslab;
-  g.smem_bytes = ((size_t)g.CI * g.PH * g.PW + 4 + (DA ? 0 : 2 * (size_t)g.CI * BM)) * sizeof(float);
+  auto smem_for = [&](int CI) -> size_t {
+    const size_t patch = (size_t)CI * g.PH * g.PW;
+    if (DA == 2) return 2 * (size_t)round_up((int)patch, 64) * sizeof(float);
+    return (patch + 4 + (DA ? 0 : 2 * (size_t)CI * BM)) * sizeof(float);
+  };
+  while (smem_for(g.CI) > kMaxSmem && g.CI > 8) g.CI /= 2;
+  g.smem_bytes = smem_for(g.CI);
   g.nchunks = ceil_div(g.KP, g.CI);
   if (want_split < 1) want_split = 1;
   if (want_split > g.nchunks) want_split = g.nchunks;
@@ -73,7 +76,7 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
 // Default (un-tuned) choice: two pixel tiles per wave when that still gives >= 4 blocks per CU; split K only when the
 // grid cannot give every CU ~6 blocks and each split keeps >= 2 channel chunks.  The runtime autotuner below
 // (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
-static int g_default_da = 1;   // un-tuned default: direct-A variant (see pnsfm_set_conv_variant)
+static int g_default_da = 2;   // un-tuned default: direct-A + LDS-DMA patch (see pnsfm_set_conv_variant)
 
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
   ConvGeom g;
@@ -119,6 +122,7 @@ struct ConvArgs {
   float* y;           // [B][Cout][H][W]
   int B, Cin, Cout, H, W, KS;
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
+  int pstride;   // DMA variant: floats between the two patch buffers
   float invPW, invPS;
 };
 
@@ -126,12 +130,18 @@ struct ConvArgs {
 // ahead, instead of sharing a per-tap LDS slab.  The four waves of a block then run the whole k*k tap loop of a channel
 // chunk WITHOUT barriers (2 barriers per chunk instead of k*k+1) and the LDS holds only the input patch; the price is
 // that the same 4 KB slab is read by four waves (coalesced 128-B rows, L1/L2-resident: ~8 B/clk/CU).
-template <int MT, int NT, bool DA>
+// DMA (with DA): the input halo patch is double-buffered in LDS and the NEXT chunk's patch is fetched with
+// global_load_lds (LDS-DMA: no VGPR staging, no ds_write pass), issued in slices between the taps of the CURRENT chunk
+// so that address generation interleaves with the MFMAs; one barrier per chunk.  Out-of-image / padded elements read
+// a zero page.
+__device__ float pnsfm_zero_page[64];
+
+template <int MT, int NT, bool DA, bool DMA>
 __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   PNSFM_DYN_SMEM(float, smem);
   constexpr int BM = 32 * MT;
   const int PS = a.PH * a.PW;
-  float* patch = smem;               // [CI][PS]
+  float* patch = smem;               // [CI][PS]  (DMA: two buffers of a.pstride floats)
   float* wbuf = smem + ((a.CI * PS + 3) & ~3);    // [2][CI][BM], 16-byte aligned for the float4 slab stores
 
   const int tid = threadIdx.x;
@@ -191,9 +201,32 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   // weight slab loader geometry: slab = [cnt][BM] floats, one float4 per thread
   const int wrow = tid / (BM / 4), wc4 = tid - wrow * (BM / 4);
 
+  // element `idx` of a chunk's patch -> (global source address or the zero page)
+  auto patch_src = [&](int ci0, int idx, int total) -> const float* {
+    const int cil = (int)(((float)idx + 0.5f) * a.invPS);
+    const int e = idx - cil * PS;
+    const int r = (int)(((float)e + 0.5f) * a.invPW);
+    const int cc = e - r * a.PW;
+    const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
+    const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    return ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
+  };
+  const int ptotal = a.CI * PS;
+  const int nld = (ptotal + 255) >> 8;           // DMA groups of 256 elements (64 per wave)
+  int dma_cur = 0;
+  if constexpr (DMA) {
+    for (int ld = 0; ld < nld; ++ld) {
+      const int idx = ld * 256 + tid;
+      const float* src = patch_src(c_begin * a.CI, idx, ptotal);
+      if (idx < ptotal) pnsfm_glds4(src, smem + ld * 256 + wave * 64);
+    }
+  }
+
   for (int c = c_begin; c < c_end; ++c) {
     const int ci0 = c * a.CI;
-    __syncthreads();  // all waves are done with the previous chunk's patch / weight buffers
+    __syncthreads();  // all waves are done with the previous chunk's buffers (DMA: and this chunk's patch has landed)
+    if constexpr (DMA) patch = smem + dma_cur * a.pstride;
+    if constexpr (!DMA) {
     // ---- stage the halo patch of `cnt` input channels (zero padding by predication).
     // Branch-free and batched: 8 independent global loads are in flight per thread before the first LDS store
     // (a guarded `if (ok) v = x[..]` makes hipcc branch around every load and wait vmcnt(0) per element).
@@ -221,9 +254,29 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
         }
       }
     }
+    }
     const int ksteps = a.CI >> 1;
     if constexpr (DA) {
-      __syncthreads();   // patch staged
+      if constexpr (!DMA) __syncthreads();   // patch staged
+      // DMA: slices of the NEXT chunk's patch are issued after each tap into the other buffer
+      const bool dma_next = DMA && (c + 1 < c_end);
+      float* dma_dst = smem + (dma_cur ^ 1) * a.pstride;
+      const int per_tap = (nld + KK - 1) / KK;
+      int ld_next = 0;
+      auto dma_slice = [&]() {
+        if constexpr (DMA) {
+          if (dma_next) {
+            for (int i = 0; i < per_tap; ++i) {
+              if (ld_next < nld) {
+                const int idx = ld_next * 256 + tid;
+                const float* src = patch_src(ci0 + a.CI, idx, ptotal);
+                if (idx < ptotal) pnsfm_glds4(src, dma_dst + ld_next * 256 + wave * 64);
+                ++ld_next;
+              }
+            }
+          }
+        }
+      };
       const float* abase = a.wp + co0 + l32;
       const size_t tap_stride = (size_t)a.KP * a.MP;
       float A0[8][MT], A1[8][MT];
@@ -262,10 +315,13 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
       for (; tap + 1 < KK; tap += 2) {
         loadA(tap + 1, A1);
         compute(tap, A0);
+        dma_slice();
         if (tap + 2 < KK) loadA(tap + 2, A0);
         compute(tap + 1, A1);
+        dma_slice();
       }
-      if (tap < KK) compute(tap, A0);
+      if (tap < KK) { compute(tap, A0); dma_slice(); }
+      if constexpr (DMA) dma_cur ^= 1;
     } else {
     // ---- tap 0 weight slab (rows past the packed K extent are zero)
     const bool wact = wrow < a.CI;
@@ -342,22 +398,23 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.chunks_per_split = ceil_div(g.nchunks, g.splitK); a.splitK = g.splitK;
   a.invPW = 1.0f / (float)g.PW;
   a.invPS = 1.0f / (float)(g.PH * g.PW);
+  a.pstride = round_up(g.CI * g.PH * g.PW, 64);
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
-  if (g.DA) {
-    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, true>), grid, dim3(256), g.smem_bytes, stream, a);
-    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, true>), grid, dim3(256), g.smem_bytes, stream, a);
-    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, true>), grid, dim3(256), g.smem_bytes, stream, a);
-    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, true>), grid, dim3(256), g.smem_bytes, stream, a);
-  } else {
-    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, false>), grid, dim3(256), g.smem_bytes, stream, a);
-    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, false>), grid, dim3(256), g.smem_bytes, stream, a);
-    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, false>), grid, dim3(256), g.smem_bytes, stream, a);
-    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, false>), grid, dim3(256), g.smem_bytes, stream, a);
-  }
+#define PNSFM_CONV_DISPATCH(DAv, DMAv)                                                                                   \
+  do {                                                                                                                   \
+    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);      \
+    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
+    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
+    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);                  \
+  } while (0)
+  if (g.DA == 2) PNSFM_CONV_DISPATCH(true, true);
+  else if (g.DA == 1) PNSFM_CONV_DISPATCH(true, false);
+  else PNSFM_CONV_DISPATCH(false, false);
+#undef PNSFM_CONV_DISPATCH
   return check_launch(what);
 }
 
@@ -393,8 +450,8 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DA << 4), g.splitK};
-      for (int cfg = 0; cfg < 4; ++cfg) {
-        const int NT = 2 - (cfg & 1), DA = 1 - (cfg >> 1);
+      for (int cfg = 0; cfg < 6; ++cfg) {
+        const int NT = 2 - (cfg & 1), DA = 2 - (cfg >> 1);
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -847,7 +904,7 @@ int pnsfm_set_autotune(int on) {
 }
 
 int pnsfm_set_conv_variant(int direct_a) {
-  g_default_da = direct_a ? 1 : 0;
+  g_default_da = direct_a < 0 ? 0 : (direct_a > 2 ? 2 : direct_a);
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned.clear();
   return 0;

@@ -13,6 +13,8 @@
   hipemu::launch((grid), (block), (shmem), [=]() { (kern)(__VA_ARGS__); })
 typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
+// LDS-DMA: lane l of the wave copies 4 bytes from its own global address to lds_wave_base[l] (emulated synchronously)
+static inline void pnsfm_glds4(const float* src, float* lds_wave_base) { lds_wave_base[hipemu::my_lane()] = *src; }
 #else
 #include <hip/hip_runtime.h>
 #define PNSFM_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
@@ -23,6 +25,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA, 64 cycles/SIMD, D(32x32) += A(32x2) * B(2x32).
 __device__ __forceinline__ f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// global_load_lds_dword: asynchronous global -> LDS copy that bypasses the VGPRs.  Every active lane supplies its own
+// global address; the LDS destination is wave-uniform base (M0) + lane*4.  Completion is tracked by vmcnt; a
+// __syncthreads() drains it.
+__device__ __forceinline__ void pnsfm_glds4(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 #endif
 

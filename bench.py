@@ -99,6 +99,8 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with events')
+    ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
+                    help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
     ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the timed region here')
     args = ap.parse_args()
 
@@ -119,7 +121,11 @@ def main():
     batch = synthetic_batch(B, H, W, 1234 + rank, device)
     groups = [{'name': 'Depth', 'params': list(model.depth_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0},
               {'name': 'Pose', 'params': list(model.pose_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0}]
-    optimizer = torch.optim.Adam(groups, fused=True)
+    if args.optimizer == 'flat':
+        from packnet_sfm.rccl.flat_adam import FlatAdam
+        optimizer = FlatAdam(groups)
+    else:
+        optimizer = torch.optim.Adam(groups, fused=True)
     if world > 1:
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                              compression=hvd.Compression.none)

@@ -81,6 +81,7 @@ static int g_default_da = 2;   // un-tuned default: direct-A + LDS-DMA patch (se
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
   ConvGeom g;
   int NT = 2;
+  { static bool once = false; if (!once) { once = true; const char* e = getenv("PNSFM_CONV_VARIANT"); if (e) g_default_da = atoi(e); } }
   const int DA = g_default_da;
   if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA) ||
       (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
@@ -123,6 +124,8 @@ struct ConvArgs {
   int B, Cin, Cout, H, W, KS;
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
   int pstride;   // DMA variant: floats between the two patch buffers
+  int dbg;       // ablation switches for tools/conv_micro.py (env PNSFM_CONV_DBG): 1 skip patch staging after the first chunk,
+                 // 2 skip weight reloads after the first tap, 4 skip the epilogue stores.  0 in production.
   float invPW, invPS;
 };
 
@@ -227,6 +230,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     __syncthreads();  // all waves are done with the previous chunk's buffers (DMA: and this chunk's patch has landed)
     if constexpr (DMA) patch = smem + dma_cur * a.pstride;
     if constexpr (!DMA) {
+    if (!((a.dbg & 1) && c > c_begin))
     // ---- stage the halo patch of `cnt` input channels (zero padding by predication).
     // Branch-free and batched: 8 independent global loads are in flight per thread before the first LDS store
     // (a guarded `if (ok) v = x[..]` makes hipcc branch around every load and wait vmcnt(0) per element).
@@ -259,7 +263,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if constexpr (DA) {
       if constexpr (!DMA) __syncthreads();   // patch staged
       // DMA: slices of the NEXT chunk's patch are issued after each tap into the other buffer
-      const bool dma_next = DMA && (c + 1 < c_end);
+      const bool dma_next = DMA && (c + 1 < c_end) && !(a.dbg & 1);
       float* dma_dst = smem + (dma_cur ^ 1) * a.pstride;
       const int per_tap = (nld + KK - 1) / KK;
       int ld_next = 0;
@@ -311,12 +315,13 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
         }
       };
       loadA(0, A0);
+      if (a.dbg & 2) loadA(0, A1);
       int tap = 0;
       for (; tap + 1 < KK; tap += 2) {
-        loadA(tap + 1, A1);
+        if (!(a.dbg & 2)) loadA(tap + 1, A1);
         compute(tap, A0);
         dma_slice();
-        if (tap + 2 < KK) loadA(tap + 2, A0);
+        if (tap + 2 < KK && !(a.dbg & 2)) loadA(tap + 2, A0);
         compute(tap + 1, A1);
         dma_slice();
       }
@@ -368,6 +373,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l32
   float* yb = a.y + (size_t)b * a.Cout * HW;
   const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
+  if ((a.dbg & 4) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -399,6 +405,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.invPW = 1.0f / (float)g.PW;
   a.invPS = 1.0f / (float)(g.PH * g.PW);
   a.pstride = round_up(g.CI * g.PH * g.PW, 64);
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PNSFM_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
                                                                   const float* __restrict__ refK, const float* __restrict__ T,
                                                                   float* __restrict__ d_inv_depth, double* __restrict__ ws,
                                                                   int J, int B, int H, int W) {
-  __shared__ double red[4];
+  __shared__ float redT[4][12];
   const int HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
@@ -183,10 +183,22 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
       }
       if (rho >= 1e-6f) g_rho += -gd * q.d * q.d;
     }
+    // 12 pose-gradient partials: wave shuffles (fp32), one LDS stage across the 4 waves, then 12 fp64 atomics per block
+    {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const double s = block_sum_256d((double)gT[i], red);
-      if (threadIdx.x == 0) atomicAdd(&ws[((size_t)j * B + b) * 12 + i], s);
+      for (int i = 0; i < 12; ++i) {
+        float v = gT[i];
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+        if (lane == 0) redT[wave][i] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < 12) {
+        const int i = threadIdx.x;
+        const double s = (double)redT[0][i] + (double)redT[1][i] + (double)redT[2][i] + (double)redT[3][i];
+        atomicAdd(&ws[((size_t)j * B + b) * 12 + i], s);
+      }
+      __syncthreads();
     }
   }
   if (active) d_inv_depth[(size_t)b * HW + pix] = g_rho;

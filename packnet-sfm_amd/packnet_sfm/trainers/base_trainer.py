@@ -1,0 +1,63 @@
+"""Trainer base: device transfer of a batch and the progress/checkpoint hooks (API of the reference's
+packnet_sfm/trainers/base_trainer.py)."""
+import torch
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    tqdm = None
+
+
+def sample_to_cuda(data, dtype=None):
+    """Recursively move a batch (dict / list / tensor; strings pass through) to the current HIP device.
+    Only floating-point tensors are cast to `dtype`."""
+    if isinstance(data, str):
+        return data
+    if isinstance(data, dict):
+        return {key: sample_to_cuda(val, dtype) for key, val in data.items()}
+    if isinstance(data, (list, tuple)):
+        return [sample_to_cuda(val, dtype) for val in data]
+    return data.to('cuda', dtype=dtype if torch.is_floating_point(data) else None, non_blocking=True)
+
+
+class BaseTrainer:
+    def __init__(self, min_epochs=0, max_epochs=50, validate_first=False, checkpoint=None, **kwargs):
+        self.min_epochs = min_epochs
+        self.max_epochs = max_epochs
+        self.validate_first = validate_first
+        self.checkpoint = checkpoint
+        self.module = None
+
+    @property
+    def proc_rank(self):
+        raise NotImplementedError('Not implemented for BaseTrainer')
+
+    @property
+    def world_size(self):
+        raise NotImplementedError('Not implemented for BaseTrainer')
+
+    @property
+    def is_rank_0(self):
+        return self.proc_rank == 0
+
+    def check_and_save(self, module, output):
+        if self.checkpoint:
+            self.checkpoint.check_and_save(module, output)
+
+    def _bar(self, dataloader, config, desc=None, ncols=120):
+        batch = getattr(config, 'batch_size', 1)
+        if isinstance(batch, (list, tuple)):
+            batch = batch[0]
+        if tqdm is None:
+            return enumerate(dataloader, 0)
+        return tqdm(enumerate(dataloader, 0), unit=' images', unit_scale=self.world_size * batch, total=len(dataloader),
+                    smoothing=0, disable=not self.is_rank_0, ncols=ncols, desc=desc)
+
+    def train_progress_bar(self, dataloader, config, ncols=120):
+        return self._bar(dataloader, config, ncols=ncols)
+
+    def val_progress_bar(self, dataloader, config, n=0, ncols=120):
+        return self._bar(dataloader, config, desc='val[%d]' % n, ncols=ncols)
+
+    def test_progress_bar(self, dataloader, config, n=0, ncols=120):
+        return self._bar(dataloader, config, desc='test[%d]' % n, ncols=ncols)

@@ -213,6 +213,62 @@ def test_adam_vs_torch():
     P.check(p, p_ref, 1e-6, 'adam')
 
 
+def test_flat_adam_and_trainer_loop():
+    """HorovodTrainer.fit (RCCL facade, world size 1) driving FlatAdam on a toy module: parameters follow torch.optim.Adam."""
+    import types
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    from packnet_sfm.trainers.horovod_trainer import HorovodTrainer
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.net = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+            self.current_epoch = 0
+            self.config = types.SimpleNamespace(datasets=types.SimpleNamespace(
+                train=types.SimpleNamespace(batch_size=4), validation=types.SimpleNamespace(batch_size=4)))
+            g = torch.Generator().manual_seed(1)
+            self.data = [{'x': torch.randn(4, 6, generator=g), 'y': torch.randn(4, 1, generator=g), 'name': 'a'} for _ in range(5)]
+            self.losses = []
+
+        def configure_optimizers(self):
+            self.optimizer = FlatAdam([{'params': list(self.net.parameters()), 'lr': 1e-2}])
+            self.scheduler = types.SimpleNamespace(step=lambda: None)
+
+        def train_dataloader(self):
+            return types.SimpleNamespace(sampler=None, __iter__=None, data=self.data)
+
+        def val_dataloader(self):
+            return []
+
+        def training_step(self, batch, i):
+            return {'loss': ((self.net(batch['x']) - batch['y']) ** 2).mean().unsqueeze(0)}
+
+        def training_epoch_end(self, outputs):
+            self.losses.append(float(torch.stack([o['loss'] for o in outputs]).mean()))
+
+        def validation_epoch_end(self, outputs):
+            return {}
+
+    class Loader(list):
+        sampler = None
+
+    toy = Toy()
+    toy.train_dataloader = lambda: Loader(toy.data)
+    ref = Toy()
+    ref_opt = torch.optim.Adam(ref.net.parameters(), lr=1e-2)
+    trainer = HorovodTrainer(max_epochs=3)
+    trainer.fit(toy)
+    for _ in range(3):
+        for b in ref.data:
+            ref_opt.zero_grad()
+            ((ref.net(b['x']) - b['y']) ** 2).mean().backward()
+            ref_opt.step()
+    for a, b in zip(toy.net.parameters(), ref.net.parameters()):
+        P.check(a, b, 1e-4, 'trainer+FlatAdam parameter')
+    assert toy.losses[-1] < toy.losses[0]
+
+
 # ------------------------------------------------------------------------------------------- (3) full size
 def _full_batch(B=4, H=192, W=640, seed=1234):
     import sys

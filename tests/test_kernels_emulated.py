@@ -100,3 +100,25 @@ def test_adam_matches_torch(emulated_kernels):
         opt.step()
         ops.adam_step(p, grad * 2.0, m, v, 2e-4, 0.9, 0.999, 1e-8, 0.0, 0.5, step)
     P.check(p, p_ref, 1e-6, 'adam')
+
+
+def test_flat_adam_matches_torch_adam(emulated_kernels):
+    """FlatAdam (one adam_kernel launch per group on a flat buffer) == torch.optim.Adam, two groups with different lr."""
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+    net_b = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+    net_b.load_state_dict(net_a.state_dict())
+    ref = torch.optim.Adam([{'params': net_a[0].parameters(), 'lr': 1e-2}, {'params': net_a[2].parameters(), 'lr': 3e-3}])
+    opt = FlatAdam([{'params': list(net_b[0].parameters()), 'lr': 1e-2}, {'params': list(net_b[2].parameters()), 'lr': 3e-3}])
+    x = torch.randn(5, 6)
+    for _ in range(4):
+        ref.zero_grad()
+        opt.zero_grad()
+        net_a(x).pow(2).sum().backward()
+        net_b(x).pow(2).sum().backward()
+        ref.step()
+        opt.step()
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        P.check(pb, pa, 1e-5, 'flat adam parameter')
+    assert set(net_b.state_dict().keys()) == set(net_a.state_dict().keys())

@@ -89,6 +89,21 @@ def cpu_baseline(H, W, seconds_budget=30.0):
                       '1 warm-up + %d timed steps, best' % (H, W, len(times))}
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json;
+    PMC counters cannot be collected from inside this process).  None if no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))['pnsfm::conv2d_mfma_kernel']
+        return {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
+                round(d.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,7 +114,7 @@ def main():
     ap.add_argument('--batch', type=int, default=4, help='images per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with events')
-    ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
+    ap.add_argument('--optimizer', default='torch', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
     ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the timed region here')
     args = ap.parse_args()
@@ -176,7 +191,7 @@ def main():
                 roofline = {
                     'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)',
                     'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                    'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': measured_traffic(),
                     'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4),
                     'flop_per_launch_avg': round(fl0 / n0, 1),
                     'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,

@@ -141,9 +141,10 @@ def main():
         optimizer = FlatAdam(groups)
     else:
         optimizer = torch.optim.Adam(groups, fused=True)
-    if world > 1:
+    force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
+    if world > 1 or force_ddp:
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
-                                             compression=hvd.Compression.none)
+                                             compression=hvd.Compression.none, force_collectives=force_ddp)
 
     def step():
         optimizer.zero_grad()
@@ -153,7 +154,7 @@ def main():
         return out['loss']
 
     def fence():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -211,7 +212,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -339,8 +339,8 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     __syncthreads();
 
     for (int tap = 0; tap < KK; ++tap) {
-      const int cur = tap & 1;
-      if (tap + 1 < KK) {
+      const int cur = (a.dbg & 2) ? 0 : (tap & 1);
+      if (tap + 1 < KK && !(a.dbg & 2)) {
         wreg = *reinterpret_cast<const float4*>(wsrc + (size_t)(tap + 1) * tap_stride);
         if (!wok) wreg = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[j][mt], bv[j][nt], acc[mt][nt]);
       }
-      if (tap + 1 < KK && wact) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
-      __syncthreads();
+      if (tap + 1 < KK && wact && !(a.dbg & 2)) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
+      if (!(a.dbg & 8)) __syncthreads();
     }
     }
   }

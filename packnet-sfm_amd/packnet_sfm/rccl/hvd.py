@@ -63,10 +63,12 @@ class DistributedOptimizer:
     """optimizer.zero_grad() / backward() / optimizer.step() with gradient averaging across ranks in between.
     Gradients are reduced bucket-by-bucket on a side stream while backward is still running."""
 
-    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=128 << 20):
+    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=128 << 20,
+                 force_collectives=False):
         self._opt = optimizer
         params = [p for g in optimizer.param_groups for p in g['params']]
-        self._reducer = GradBucketReducer(params, bucket_bytes=bucket_bytes, average=True)
+        self._reducer = GradBucketReducer(params, bucket_bytes=bucket_bytes, average=True,
+                                          force_collectives=force_collectives)
 
     def zero_grad(self, set_to_none=False):
         self._reducer.zero_grad()

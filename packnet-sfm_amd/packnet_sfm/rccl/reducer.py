@@ -27,7 +27,7 @@ def init_process_group(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('PNSFM_FORCE_DDP') == '1') and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -66,9 +66,11 @@ class GradBucketReducer:
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
-    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True):
+    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, force_collectives=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
+        self.force = bool(force_collectives) and dist.is_initialized()
         self.average = average
         params = [p for p in params if p.requires_grad]
         if not params:
@@ -115,7 +117,7 @@ class GradBucketReducer:
 
     def _launch(self, bucket):
         self._launched += 1
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.side_stream is not None:
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -139,13 +141,13 @@ class GradBucketReducer:
         """Block the compute stream until every bucket is reduced; buckets whose hooks never all fired (unused
         parameters) are reduced now.  Applies the averaging."""
         for b in self.buckets:
-            if b.pending != 0 and self.world > 1 and b.work is None:
+            if b.pending != 0 and (self.world > 1 or self.force) and b.work is None:
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-        if self.side_stream is not None and self.world > 1:
+        if self.side_stream is not None and (self.world > 1 or self.force):
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         if self.average and self.world > 1:
             scale = 1.0 / self.world

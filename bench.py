@@ -205,7 +205,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'PackNet01(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
-                                   'KITTI-shaped %dx%d triplets, batch %d/GPU (BASELINE.json configs[1])' % (H, W, B),
+                                   'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (
+                                       H, W, B, 'BASELINE.json configs[1]' if (H, W, B) == (192, 640, 4) else
+                                       ('BASELINE.json configs[2] shape' if (H, W, B) == (384, 1280, 2) else 'custom shape')),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 6)},
             'roofline': roofline,
         }

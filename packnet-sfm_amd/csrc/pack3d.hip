@@ -96,114 +96,115 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
 }
 
 // dp[b][d][y][x] = sum_{f,dz,dy,dx} w3[f][dz][dy][dx] * dout[b][f*D + d-dz+1][y-dy+1][x-dx+1]
-// same thread mapping; the 8x9 loads of one dz slab are issued together (branch-free) before they are consumed.
+// grid: (ceil(D*H*ceil(W/4)/256), 1, B): one thread per run of 4 consecutive x -- the 6 values dout[..][x0-1 .. x0+4] of
+// each (f, dz, dy) row feed 3 taps x 4 outputs, halving the loads per voxel (108 instead of 216); all loads of one
+// (dz, dy) slab (8 features x 6) are issued branch-free before use.
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
                                                             float* __restrict__ dp, int D, int H, int W) {
   __shared__ float ws[8 * 27];
   for (int i = threadIdx.x; i < 8 * 27; i += 256) ws[i] = w3[i];
   __syncthreads();
-  const int HW = H * W, DHW = D * HW;
-  const int vox = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W, DHW = D * HW, W4 = (W + 3) >> 2;
+  const int grp = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.z;
-  const bool active = vox < DHW;
-  const int d = active ? vox / HW : 0;
-  const int pix = active ? vox - d * HW : 0;
-  const int y = pix / W, x = pix - y * W;
+  const bool active = grp < D * H * W4;
+  const int d = active ? grp / (H * W4) : 0;
+  const int rem = active ? grp - d * (H * W4) : 0;
+  const int y = rem / W4, x0 = (rem - y * W4) << 2;
   const float* gb = dout + (size_t)b * 8 * DHW;
-  float acc = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int dz = 0; dz < 3; ++dz) {
     const int dd = d - dz + 1;
     const bool dok = active && dd >= 0 && dd < D;
-    float g[8][9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y - dy + 1;
+      const bool rok = dok && yy >= 0 && yy < H;
+      const int rowoff = rok ? (dd * HW + yy * W) : 0;
+      float v[8][6];
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x - dx + 1;
-        const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const int off = ok ? (dd * HW + yy * W + xx) : 0;
+      for (int i = 0; i < 6; ++i) {
+        const int xx = x0 - 1 + i;
+        const bool ok = rok && xx >= 0 && xx < W;
+        const int off = ok ? rowoff + xx : 0;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
           const float t = gb[(size_t)f * DHW + off];
-          g[f][dy * 3 + dx] = ok ? t : 0.f;
+          v[f][i] = ok ? t : 0.f;
         }
       }
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float wv = ws[f * 27 + dz * 9 + dy * 3 + dx];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = fmaf(wv, v[f][o - dx + 2], acc[o]);
+        }
     }
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc = fmaf(ws[f * 27 + dz * 9 + t], g[f][t], acc);
   }
-  if (active) dp[(size_t)b * DHW + vox] = acc;
+  if (active) {
+    float* out = dp + (size_t)b * DHW + (size_t)d * HW + y * W + x0;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (x0 + o < W) out[o] = acc[o];
+  }
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
-// grid: (nblk, 2): blockIdx.y picks 4 of the 8 features, so the 27 neighbours of a voxel are loaded twice (not 8x);
-// blocks grid-stride over the flattened (b, d, y, x) volume in units of 256 voxels.
-// 4*28 register accumulators per thread -> wave shuffle -> LDS -> fp64 atomics.
+// A reduction of 8 x 28 numbers over every voxel -- done on the matrix cores: per v_mfma_f32_32x32x2_f32,
+//   A[m = feature f (8 of 32 rows used)][k = 2 consecutive voxels]  = dout[f][voxel]
+//   B[k][n = tap (27 of 32 columns) | n = 27: a column of ones]     = p[voxel + offset(tap)]  (zero outside the volume)
+// so D[f][tap] accumulates dw3 and D[f][27] accumulates db3.  Operands come straight from global/L1 (neighbouring voxels
+// share cache lines); each wave walks whole (b, d, y) rows so no index division sits in the x loop.  No LDS staging, no
+// barriers; one LDS reduction over the block's 4 waves at the end, then 224 fp64 atomics per block.
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
                                                             double* __restrict__ ws, int B, int D, int H, int W) {
-  __shared__ float red[4][112];
-  const int f0 = blockIdx.y * 4;
-  const int HW = H * W, DHW = D * HW;
-  const int chunks_per_b = (DHW + 255) / 256;
-  float acc[4][28];
+  __shared__ float red[4][8 * 28];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int HW = H * W;
+  const bool fa = l32 < 8;                  // A row = feature
+  const bool tb = l32 < 27, ones = l32 == 27;   // B column = tap / ones column
+  const int dz = l32 / 9, dy = (l32 - dz * 9) / 3, dx = l32 - dz * 9 - dy * 3;
+  f32x16 acc;
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const long rows = (long)B * D * H;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int y = (int)(row % H);
+    const long bd = row / H;
+    const int d = (int)(bd % D), b = (int)(bd / D);
+    const float* grow = dout + (((size_t)b * 8 + (fa ? l32 : 0)) * D + d) * HW + (size_t)y * W;
+    const int dd = d + dz - 1, yy = y + dy - 1;
+    const bool rowok = tb && dd >= 0 && dd < D && yy >= 0 && yy < H;
+    const float* prow = p + ((size_t)b * D + (rowok ? dd : 0)) * HW + (size_t)(rowok ? yy : 0) * W;
+    for (int x0 = 0; x0 < W; x0 += 8) {
+      float av[4], bv[4];
 #pragma unroll
-    for (int t = 0; t < 28; ++t) acc[f][t] = 0.f;
-  for (int c = blockIdx.x; c < B * chunks_per_b; c += gridDim.x) {
-    const int b = c / chunks_per_b;
-    const int vox = (c - b * chunks_per_b) * 256 + threadIdx.x;
-    const bool active = vox < DHW;
-    const int d = active ? vox / HW : 0;
-    const int pix = active ? vox - d * HW : 0;
-    const int y = pix / W, x = pix - y * W;
-    const float* pb = p + (size_t)b * DHW;
-    const float* gb = dout + (size_t)b * 8 * DHW + (active ? vox : 0);
-    float g[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) { const float t = gb[(size_t)(f0 + f) * DHW]; g[f] = active ? t : 0.f; }
-    float v[27];
-#pragma unroll
-    for (int dz = 0; dz < 3; ++dz) {
-      const int dd = d + dz - 1;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int xx = x + dx - 1;
-          const bool ok = active && dd >= 0 && dd < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          const int off = ok ? (dd * HW + yy * W + xx) : 0;
-          const float t = pb[off];
-          v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int x = x0 + 2 * u + half;
+        const bool okx = x < W;
+        const float ta = grow[okx ? x : 0];
+        av[u] = (fa && okx) ? ta : 0.f;
+        const int xx = x + dx - 1;
+        const bool okb = rowok && okx && xx >= 0 && xx < W;
+        const float t = prow[okb ? xx : 0];
+        bv[u] = okb ? t : ((ones && okx) ? 1.f : 0.f);
       }
-    }
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-#pragma unroll
-      for (int t = 0; t < 27; ++t) acc[f][t] = fmaf(g[f], v[t], acc[f][t]);
-      acc[f][27] += g[f];
+      for (int u = 0; u < 4; ++u) acc = pnsfm_mfma_32x32x2(av[u], bv[u], acc);
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // D row = (r&3) + 8*(r>>2) + 4*half: rows 0..7 live in r = 0..3 -> feature f = r + 4*half; column = l32 (tap, 27 = bias)
+  if (l32 < 28) {
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int t = 0; t < 28; ++t) {
-      float v = acc[f][t];
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-      if (lane == 0) red[wave][f * 28 + t] = v;
-    }
+    for (int r = 0; r < 4; ++r) red[wave][(r + 4 * half) * 28 + l32] = acc[r];
+  }
   __syncthreads();
-  if (threadIdx.x < 112) {
-    const int i = threadIdx.x;
-    const double s = (double)red[0][i] + (double)red[1][i] + (double)red[2][i] + (double)red[3][i];
-    atomicAdd(&ws[f0 * 28 + i], s);
+  if (tid < 8 * 28) {
+    const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+    atomicAdd(&ws[tid], s);
   }
 }
 
@@ -248,7 +249,7 @@ int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, 
 }
 
 int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
+  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * ((W + 3) / 4), 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
   return check_launch("conv3d_backward_data");
 }
 
@@ -257,9 +258,11 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
   if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
-  int nblk = B * ceil_div(D * H * W, 256);
+  long nrows = (long)B * D * H;
+  int nblk = (int)((nrows + 3) / 4);
   if (nblk > 2048) nblk = 2048;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk, 2), dim3(256), 0, s, p, dout, ws, B, D, H, W);
+  if (nblk < 1) nblk = 1;
+  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk), dim3(256), 0, s, p, dout, ws, B, D, H, W);
   e = check_launch("conv3d_backward_weight");
   if (e) return e;
   PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3);

@@ -113,11 +113,12 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
   const int y = rem / W4, x0 = (rem - y * W4) << 2;
   const float* gb = dout + (size_t)b * 8 * DHW;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+  // the 9 (dz, dy) slabs stay a real loop: fully unrolled, hipcc hoists all 432 loads and spills
+#pragma unroll 1
   for (int dz = 0; dz < 3; ++dz) {
     const int dd = d - dz + 1;
     const bool dok = active && dd >= 0 && dd < D;
-#pragma unroll
+#pragma unroll 1
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y - dy + 1;
       const bool rok = dok && yy >= 0 && yy < H;

@@ -137,7 +137,7 @@ struct ConvArgs {
 // global_load_lds (LDS-DMA: no VGPR staging, no ds_write pass), issued in slices between the taps of the CURRENT chunk
 // so that address generation interleaves with the MFMAs; one barrier per chunk.  Out-of-image / padded elements read
 // a zero page.
-__device__ float pnsfm_zero_page[64];
+__device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 
 template <int MT, int NT, bool DA, bool DMA>
 __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
@@ -247,9 +247,10 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
           const int cc = e - r * a.PW;
           const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
           const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          const size_t off = ok ? ((size_t)ci * HW + yy * W + xx) : 0;
-          const float t = xb[off];
-          v[u] = ok ? t : 0.f;
+          // pointer select, not value select: hipcc turns `ok ? x[off] : 0` into a branch around the load plus a
+          // vmcnt(0) per element; an unconditional load from (address | zero page) keeps all 8 loads in flight
+          const float* src = ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
+          v[u] = *src;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -289,9 +290,9 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
         for (int kk = 0; kk < 8; ++kk) {
           const int row = ci0 + 2 * kk + half;
           const bool ok = kk < ksteps && row < a.KP;
-          const float* src = abase + (ok ? (size_t)tap * tap_stride + (size_t)row * a.MP : 0);
+          const float* src = ok ? abase + ((size_t)tap * tap_stride + (size_t)row * a.MP) : pnsfm_zero_page;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) { const float t = src[mt * 32]; dst[kk][mt] = ok ? t : 0.f; }
+          for (int mt = 0; mt < MT; ++mt) dst[kk][mt] = src[ok ? mt * 32 : 0];
         }
       };
       auto compute = [&](int tap, const float (&A)[8][MT]) {
@@ -641,9 +642,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
           if (a.mode == 0) { const int yy = y0 + (p >> 5); gidx = yy * W + x0 + (p & 31); ok = yy < H && gidx + 3 < HW; }
           else { gidx = pn0 + p; ok = gidx + 3 < HW; }
           ok = ok && g < BM * q4 && (co0 + m) < a.Cout;
-          const size_t off = ok ? ((size_t)(co0 + m) * HW + gidx) : 0;
-          const float4 t = *reinterpret_cast<const float4*>(dyb + off);
-          v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float* src = ok ? dyb + ((size_t)(co0 + m) * HW + gidx) : pnsfm_zero_page;
+          v[u] = *reinterpret_cast<const float4*>(src);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -666,9 +666,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
           if (a.mode == 0) { const int yy = y0 + (p >> 5); gidx = yy * W + x0 + (p & 31); ok = yy < H && gidx < HW; }
           else { gidx = pn0 + p; ok = gidx < HW; }
           ok = ok && e < BM * PT && (co0 + m) < a.Cout;
-          const size_t off = ok ? ((size_t)(co0 + m) * HW + gidx) : 0;
-          const float t = dyb[off];
-          v[u] = ok ? t : 0.f;
+          const float* src = ok ? dyb + ((size_t)(co0 + m) * HW + gidx) : pnsfm_zero_page;
+          v[u] = *src;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -700,9 +699,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
           const int cc = e - r * a.PW;
           const int yy = py0 + r, xx = px0 + cc, ci = ci_lo + cil;
           const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W && yy * W + xx < HW;
-          const size_t off = ok ? ((size_t)ci * HW + yy * W + xx) : 0;
-          const float t = xb[off];
-          v[u] = ok ? t : 0.f;
+          const float* src = ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
+          v[u] = *src;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

@@ -12,6 +12,9 @@
 
 namespace pnsfm {
 
+// out-of-volume neighbours are read from here (pointer select keeps the loads unconditional, see conv2d.hip)
+__device__ __attribute__((aligned(16))) float pnsfm_zero_page3[64];
+
 // y[b][4c+2i+j][h][w] = x[b][c][2h+i][2w+j]; one thread per input 2x2 quad column pair
 __global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                    int C, int H, int W, size_t total) {
@@ -75,9 +78,8 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
       for (int dx = 0; dx < 3; ++dx) {
         const int xx = x + dx - 1;
         const bool ok = active && dd >= 0 && dd < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const int off = ok ? (dd * HW + yy * W + xx) : 0;
-        const float t = pb[off];
-        v[dz * 9 + dy * 3 + dx] = ok ? t : 0.f;
+        const float* src = ok ? pb + (dd * HW + yy * W + xx) : pnsfm_zero_page3;
+        v[dz * 9 + dy * 3 + dx] = *src;
       }
     }
   }
@@ -128,12 +130,10 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
       for (int i = 0; i < 6; ++i) {
         const int xx = x0 - 1 + i;
         const bool ok = rok && xx >= 0 && xx < W;
-        const int off = ok ? rowoff + xx : 0;
+        const float* src = ok ? gb + (rowoff + xx) : pnsfm_zero_page3;
+        const size_t fstride = ok ? (size_t)DHW : 0;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          const float t = gb[(size_t)f * DHW + off];
-          v[f][i] = ok ? t : 0.f;
-        }
+        for (int f = 0; f < 8; ++f) v[f][i] = src[f * fstride];
       }
 #pragma unroll
       for (int f = 0; f < 8; ++f)
@@ -186,12 +186,13 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restri
       for (int u = 0; u < 4; ++u) {
         const int x = x0 + 2 * u + half;
         const bool okx = x < W;
-        const float ta = grow[okx ? x : 0];
-        av[u] = (fa && okx) ? ta : 0.f;
+        const float* sa = (fa && okx) ? grow + x : pnsfm_zero_page3;
+        av[u] = *sa;
         const int xx = x + dx - 1;
         const bool okb = rowok && okx && xx >= 0 && xx < W;
-        const float t = prow[okb ? xx : 0];
-        bv[u] = okb ? t : ((ones && okx) ? 1.f : 0.f);
+        const float* sb = okb ? prow + xx : pnsfm_zero_page3;
+        const float t = *sb;
+        bv[u] = (ones && okx) ? 1.f : t;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = pnsfm_mfma_32x32x2(av[u], bv[u], acc);

@@ -50,10 +50,10 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
  * The first call for a new shape times the candidate configurations on the caller's stream (it synchronises), like
  * `torch.backends.cudnn.benchmark = True` in the reference (trainers/horovod_trainer.py:19). */
 int pnsfm_set_autotune(int on);
-/* Un-tuned default of the forward/backward-data kernel: 0 = per-tap LDS weight slab; 1 = weights fetched per wave into
- * registers (barrier-free tap loop); 2 = 1 + double-buffered input patch fetched by LDS-DMA (global_load_lds) in slices
- * between the taps.  The autotuner times all three; this switch exists for tests. Clears the tuning cache. */
-int pnsfm_set_conv_variant(int direct_a);
+/* Un-tuned default of the forward/backward-data kernel's patch staging: 0 = through registers, 1 = double-buffered
+ * LDS-DMA (global_load_lds) issued in slices between the taps.  The autotuner times both; this switch exists for tests.
+ * Clears the tuning cache. */
+int pnsfm_set_conv_variant(int lds_dma);
 
 /* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the

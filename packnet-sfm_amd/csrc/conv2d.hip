@@ -33,8 +33,8 @@ int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 static const size_t kMaxSmem = 64 * 1024;
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
-static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DA = 1) {
-  g.DA = DA;
+static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0) {
+  g.DMA = DMA;
   const int HW = H * W;
   g.MT = conv_pick_MT(Cout);
   const int BM = 32 * g.MT;
@@ -60,8 +60,9 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   // shrink the channel chunk if the halo patch of a very wide image does not fit
   auto smem_for = [&](int CI) -> size_t {
     const size_t patch = (size_t)CI * g.PH * g.PW;
-    if (DA == 2) return 2 * (size_t)round_up((int)patch, 64) * sizeof(float);
-    return (patch + 4 + (DA ? 0 : 2 * (size_t)CI * BM)) * sizeof(float);
+    const size_t slabs = 2 * (size_t)CI * BM;
+    if (DMA) return (2 * (size_t)round_up((int)patch, 64) + slabs) * sizeof(float);
+    return (patch + 4 + slabs) * sizeof(float);
   };
   while (smem_for(g.CI) > kMaxSmem && g.CI > 8) g.CI /= 2;
   g.smem_bytes = smem_for(g.CI);
@@ -76,13 +77,12 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
 // Default (un-tuned) choice: two pixel tiles per wave when that still gives >= 4 blocks per CU; split K only when the
 // grid cannot give every CU ~6 blocks and each split keeps >= 2 channel chunks.  The runtime autotuner below
 // (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
-static int g_default_da = 2;   // un-tuned default: direct-A + LDS-DMA patch (see pnsfm_set_conv_variant)
+static int g_default_dma = 0;   // un-tuned default variant (see pnsfm_set_conv_variant)
 
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
   ConvGeom g;
   int NT = 2;
-  { static bool once = false; if (!once) { once = true; const char* e = getenv("PNSFM_CONV_VARIANT"); if (e) g_default_da = atoi(e); } }
-  const int DA = g_default_da;
+  int DA = g_default_dma;
   if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA) ||
       (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
   conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA);
@@ -93,7 +93,7 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
     if (split > g.nchunks / 2) split = g.nchunks / 2;
     if (split < 1) split = 1;
   }
-  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, DA);
+  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, DA) && DA) conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, 0);
   return g;
 }
 
@@ -123,29 +123,29 @@ struct ConvArgs {
   float* y;           // [B][Cout][H][W]
   int B, Cin, Cout, H, W, KS;
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
-  int pstride;   // DMA variant: floats between the two patch buffers
-  int dbg;       // ablation switches for tools/conv_micro.py (env PNSFM_CONV_DBG): 1 skip patch staging after the first chunk,
-                 // 2 skip weight reloads after the first tap, 4 skip the epilogue stores.  0 in production.
+  int pstride;        // DMA variant: floats between the two patch buffers
   float invPW, invPS;
 };
 
-// DA = "direct A": each wave fetches its MFMA A fragments (weights) straight from global/L2 into registers, one tap
-// ahead, instead of sharing a per-tap LDS slab.  The four waves of a block then run the whole k*k tap loop of a channel
-// chunk WITHOUT barriers (2 barriers per chunk instead of k*k+1) and the LDS holds only the input patch; the price is
-// that the same 4 KB slab is read by four waves (coalesced 128-B rows, L1/L2-resident: ~8 B/clk/CU).
-// DMA (with DA): the input halo patch is double-buffered in LDS and the NEXT chunk's patch is fetched with
-// global_load_lds (LDS-DMA: no VGPR staging, no ds_write pass), issued in slices between the taps of the CURRENT chunk
-// so that address generation interleaves with the MFMAs; one barrier per chunk.  Out-of-image / padded elements read
-// a zero page.
+// out-of-image / padded elements are read from here: selecting the POINTER (address | zero page) keeps every staging
+// load unconditional; hipcc turns `ok ? x[off] : 0` into a branch around the load plus s_waitcnt vmcnt(0) per element
 __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 
-template <int MT, int NT, bool DA, bool DMA>
+// DMA = 0: the halo patch of a channel chunk is staged through registers (8 loads in flight per thread) between two
+//          barriers;
+// DMA = 1: the patch is DOUBLE-BUFFERED in LDS and the next chunk's patch is fetched with global_load_lds (LDS-DMA: no
+//          VGPR round trip, no ds_write pass), issued in slices between the taps of the current chunk so that address
+//          generation interleaves with the MFMAs and the fetch latency hides behind them -- this is what lets a grid
+//          that is resident in a single round (the low-resolution layers) overlap staging with math.
+// The autotuner times both per layer shape.
+template <int MT, int NT, bool DMA>
 __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   PNSFM_DYN_SMEM(float, smem);
   constexpr int BM = 32 * MT;
   const int PS = a.PH * a.PW;
-  float* patch = smem;               // [CI][PS]  (DMA: two buffers of a.pstride floats)
-  float* wbuf = smem + ((a.CI * PS + 3) & ~3);    // [2][CI][BM], 16-byte aligned for the float4 slab stores
+  const int ptotal = a.CI * PS;
+  // LDS: [patch buffer(s)] [2 weight slabs of CI x BM]
+  float* wbuf = smem + (DMA ? 2 * a.pstride : ((ptotal + 3) & ~3));
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
@@ -201,157 +201,67 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const float* xb = a.x + (size_t)b * a.Cin * HW;
-  // weight slab loader geometry: slab = [cnt][BM] floats, one float4 per thread
-  const int wrow = tid / (BM / 4), wc4 = tid - wrow * (BM / 4);
-
-  // element `idx` of a chunk's patch -> (global source address or the zero page)
-  auto patch_src = [&](int ci0, int idx, int total) -> const float* {
+  // element `idx` of the patch of the chunk starting at channel ci0 -> its global address, or the zero page
+  auto patch_src = [&](int ci0, int idx) -> const float* {
     const int cil = (int)(((float)idx + 0.5f) * a.invPS);
     const int e = idx - cil * PS;
     const int r = (int)(((float)e + 0.5f) * a.invPW);
     const int cc = e - r * a.PW;
     const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
-    const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const bool ok = idx < ptotal && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
     return ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
   };
-  const int ptotal = a.CI * PS;
+  // weight slab loader geometry: slab = [CI][BM] floats, one float4 per thread (rows past the packed K extent are zero)
+  const int wrow = tid / (BM / 4), wc4 = tid - wrow * (BM / 4);
+  const bool wact = wrow < a.CI;
+  const size_t tap_stride = (size_t)a.KP * a.MP;
+  const int ksteps = a.CI >> 1;
   const int nld = (ptotal + 255) >> 8;           // DMA groups of 256 elements (64 per wave)
+  const int per_tap = (nld + KK - 1) / KK;
   int dma_cur = 0;
-  if constexpr (DMA) {
+
+  if constexpr (DMA) {   // first chunk's patch
     for (int ld = 0; ld < nld; ++ld) {
       const int idx = ld * 256 + tid;
-      const float* src = patch_src(c_begin * a.CI, idx, ptotal);
+      const float* src = patch_src(c_begin * a.CI, idx);
       if (idx < ptotal) pnsfm_glds4(src, smem + ld * 256 + wave * 64);
     }
   }
 
   for (int c = c_begin; c < c_end; ++c) {
     const int ci0 = c * a.CI;
-    __syncthreads();  // all waves are done with the previous chunk's buffers (DMA: and this chunk's patch has landed)
-    if constexpr (DMA) patch = smem + dma_cur * a.pstride;
+    float* patch = smem + (DMA ? dma_cur * a.pstride : 0);
     if constexpr (!DMA) {
-    if (!((a.dbg & 1) && c > c_begin))
-    // ---- stage the halo patch of `cnt` input channels (zero padding by predication).
-    // Branch-free and batched: 8 independent global loads are in flight per thread before the first LDS store
-    // (a guarded `if (ok) v = x[..]` makes hipcc branch around every load and wait vmcnt(0) per element).
-    {
-      const int total = a.CI * PS;   // channels past Cin (last chunk) are staged as zeros
-      for (int base = tid; base < total; base += 256 * 8) {
+      __syncthreads();  // every wave is done reading the previous chunk's patch
+      for (int base = tid; base < ptotal; base += 256 * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * 256;
-          const int cil = (int)(((float)idx + 0.5f) * a.invPS);
-          const int e = idx - cil * PS;
-          const int r = (int)(((float)e + 0.5f) * a.invPW);
-          const int cc = e - r * a.PW;
-          const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
-          const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-          // pointer select, not value select: hipcc turns `ok ? x[off] : 0` into a branch around the load plus a
-          // vmcnt(0) per element; an unconditional load from (address | zero page) keeps all 8 loads in flight
-          const float* src = ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
-          v[u] = *src;
-        }
+        for (int u = 0; u < 8; ++u) v[u] = *patch_src(ci0, base + u * 256);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * 256;
-          if (idx < total) patch[idx] = v[u];
-        }
+        for (int u = 0; u < 8; ++u)
+          if (base + u * 256 < ptotal) patch[base + u * 256] = v[u];
       }
     }
-    }
-    const int ksteps = a.CI >> 1;
-    if constexpr (DA) {
-      if constexpr (!DMA) __syncthreads();   // patch staged
-      // DMA: slices of the NEXT chunk's patch are issued after each tap into the other buffer
-      const bool dma_next = DMA && (c + 1 < c_end) && !(a.dbg & 1);
-      float* dma_dst = smem + (dma_cur ^ 1) * a.pstride;
-      const int per_tap = (nld + KK - 1) / KK;
-      int ld_next = 0;
-      auto dma_slice = [&]() {
-        if constexpr (DMA) {
-          if (dma_next) {
-            for (int i = 0; i < per_tap; ++i) {
-              if (ld_next < nld) {
-                const int idx = ld_next * 256 + tid;
-                const float* src = patch_src(ci0 + a.CI, idx, ptotal);
-                if (idx < ptotal) pnsfm_glds4(src, dma_dst + ld_next * 256 + wave * 64);
-                ++ld_next;
-              }
-            }
-          }
-        }
-      };
-      const float* abase = a.wp + co0 + l32;
-      const size_t tap_stride = (size_t)a.KP * a.MP;
-      float A0[8][MT], A1[8][MT];
-      auto loadA = [&](int tap, float (&dst)[8][MT]) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const int row = ci0 + 2 * kk + half;
-          const bool ok = kk < ksteps && row < a.KP;
-          const float* src = ok ? abase + ((size_t)tap * tap_stride + (size_t)row * a.MP) : pnsfm_zero_page;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) dst[kk][mt] = src[ok ? mt * 32 : 0];
-        }
-      };
-      auto compute = [&](int tap, const float (&A)[8][MT]) {
-        const int ky = tap / a.KS, kx = tap - ky * a.KS;
-        const float* pb = patch + half * PS + ky * a.PW + kx;
-#pragma unroll
-        for (int kb = 0; kb < 8; kb += 4) {
-          if (kb < ksteps) {
-            float bv[4][NT];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) bv[j][nt] = pb[(kb + j) * 2 * PS + boff[nt]];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(A[kb + j][mt], bv[j][nt], acc[mt][nt]);
-          }
-        }
-      };
-      loadA(0, A0);
-      if (a.dbg & 2) loadA(0, A1);
-      int tap = 0;
-      for (; tap + 1 < KK; tap += 2) {
-        if (!(a.dbg & 2)) loadA(tap + 1, A1);
-        compute(tap, A0);
-        dma_slice();
-        if (tap + 2 < KK && !(a.dbg & 2)) loadA(tap + 2, A0);
-        compute(tap + 1, A1);
-        dma_slice();
-      }
-      if (tap < KK) { compute(tap, A0); dma_slice(); }
-      if constexpr (DMA) dma_cur ^= 1;
-    } else {
-    // ---- tap 0 weight slab (rows past the packed K extent are zero)
-    const bool wact = wrow < a.CI;
+    // ---- tap 0 weight slab
     const bool wok = wact && (ci0 + wrow) < a.KP;
-    const float* wsrc = a.wp + ((size_t)(ci0 + (wok ? wrow : 0))) * a.MP + co0 + wc4 * 4;
-    const size_t tap_stride = (size_t)a.KP * a.MP;
+    const float* wsrc = wok ? a.wp + ((size_t)(ci0 + wrow) * a.MP + co0 + wc4 * 4) : pnsfm_zero_page;
+    const size_t wstep = wok ? tap_stride : 0;
     float4 wreg = *reinterpret_cast<const float4*>(wsrc);
-    if (!wok) wreg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wact) *reinterpret_cast<float4*>(wbuf + wrow * BM + wc4 * 4) = wreg;
-    __syncthreads();
+    __syncthreads();   // patch (DMA: drained by the barrier's vmcnt(0)) and slab 0 visible; previous chunk fully consumed
 
+    const bool dma_next = DMA && (c + 1 < c_end);
+    float* dma_dst = smem + (dma_cur ^ 1) * a.pstride;
+    int ld_next = 0;
     int ky = 0, kx = 0;
     for (int tap = 0; tap < KK; ++tap) {
-      const int cur = (a.dbg & 2) ? 0 : (tap & 1);
-      if (tap + 1 < KK && !(a.dbg & 2)) {
-        wreg = *reinterpret_cast<const float4*>(wsrc + (size_t)(tap + 1) * tap_stride);
-        if (!wok) wreg = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const int cur = tap & 1;
+      if (tap + 1 < KK) wreg = *reinterpret_cast<const float4*>(wsrc + (size_t)(tap + 1) * wstep);
       const float* wb = wbuf + cur * a.CI * BM + half * BM + l32;
       const float* pb = patch + half * PS + ky * a.PW + kx;
       if (++kx == a.KS) { kx = 0; ++ky; }
       // batches of 4 k-steps (8 channels).  Software-pipelined: the LDS reads of batch 1 are issued BEFORE the MFMAs of
-      // batch 0, so their latency hides under 4*MT*NT MFMAs instead of stalling the wave (measured on the loop alone:
-      // 121 -> 135 TFLOP/s, tools/micro/conv_loop.hip)
+      // batch 0, so their latency hides under 4*MT*NT MFMAs instead of stalling the wave
       float av[2][4][MT], bv[2][4][NT];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -383,16 +293,24 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[1][j][mt], bv[1][j][nt], acc[mt][nt]);
       }
-      if (tap + 1 < KK && wact && !(a.dbg & 2)) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
-      if (!(a.dbg & 8)) __syncthreads();
+      if constexpr (DMA) {   // a slice of the NEXT chunk's patch rides behind this tap's MFMAs
+        if (dma_next) {
+          for (int i = 0; i < per_tap && ld_next < nld; ++i, ++ld_next) {
+            const int idx = ld_next * 256 + tid;
+            const float* src = patch_src(ci0 + a.CI, idx);
+            if (idx < ptotal) pnsfm_glds4(src, dma_dst + ld_next * 256 + wave * 64);
+          }
+        }
+      }
+      if (tap + 1 < KK && wact) *reinterpret_cast<float4*>(wbuf + (cur ^ 1) * a.CI * BM + wrow * BM + wc4 * 4) = wreg;
+      __syncthreads();
     }
-    }
+    if constexpr (DMA) dma_cur ^= 1;
   }
 
   // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l32
   float* yb = a.y + (size_t)b * a.Cout * HW;
   const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
-  if ((a.dbg & 4) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -424,22 +342,20 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.invPW = 1.0f / (float)g.PW;
   a.invPS = 1.0f / (float)(g.PH * g.PW);
   a.pstride = round_up(g.CI * g.PH * g.PW, 64);
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PNSFM_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
-#define PNSFM_CONV_DISPATCH(DAv, DMAv)                                                                                   \
-  do {                                                                                                                   \
-    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);      \
-    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
-    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
-    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, DAv, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);                  \
+#define PNSFM_CONV_DISPATCH(DMAv)                                                                                 \
+  do {                                                                                                             \
+    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);      \
+    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 1, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
+    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
+    else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);                 \
   } while (0)
-  if (g.DA == 2) PNSFM_CONV_DISPATCH(true, true);
-  else if (g.DA == 1) PNSFM_CONV_DISPATCH(true, false);
-  else PNSFM_CONV_DISPATCH(false, false);
+  if (g.DMA) PNSFM_CONV_DISPATCH(true);
+  else PNSFM_CONV_DISPATCH(false);
 #undef PNSFM_CONV_DISPATCH
   return check_launch(what);
 }
@@ -475,9 +391,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     if (it == g_tuned.end()) {
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
-      std::array<int, 2> best = {g.NT | (g.DA << 4), g.splitK};
-      for (int cfg = 0; cfg < 6; ++cfg) {
-        const int NT = 2 - (cfg & 1), DA = 2 - (cfg >> 1);
+      std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
+      for (int cfg = 0; cfg < 4; ++cfg) {
+        const int NT = 2 - (cfg & 1), DA = cfg >> 1;
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -926,8 +842,8 @@ int pnsfm_set_autotune(int on) {
   return 0;
 }
 
-int pnsfm_set_conv_variant(int direct_a) {
-  g_default_da = direct_a < 0 ? 0 : (direct_a > 2 ? 2 : direct_a);
+int pnsfm_set_conv_variant(int lds_dma) {
+  g_default_dma = lds_dma ? 1 : 0;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned.clear();
   return 0;

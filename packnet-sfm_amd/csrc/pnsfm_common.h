@@ -59,7 +59,7 @@ struct ConvGeom {
   int PH, PW;         // staged input patch (rows, cols) incl. halo
   int KP, MP;         // padded K-channels / M-channels of the packed weight
   int nchunks, splitK;
-  int DA;             // 1: weights fetched per wave straight into registers (no LDS slab, no per-tap barrier)
+  int DMA;            // 1: input patch double-buffered in LDS and fetched by LDS-DMA (global_load_lds)
   size_t smem_bytes;
 };
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks);

@@ -61,12 +61,12 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
-@pytest.mark.parametrize('direct_a', [2, 1, 0])
+@pytest.mark.parametrize('direct_a', [1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
                                    (1, 96, 64, 6, 20, 3)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
     """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; both
-    weight-operand variants of the forward/backward-data kernel (register-fetched vs LDS slab)."""
+    patch-staging variants of the forward/backward-data kernel (registers vs LDS-DMA)."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     _lib.get().pnsfm_set_conv_variant(direct_a)

@@ -46,6 +46,14 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
                                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 
+/* Strided variants (stride 1 or 2, zero pad k/2): PoseNet's stride-2 conv_gn blocks, networks/pose/PoseNet.py:28-34.
+ * x:[B,Cin,Hin,Win] -> y / dy:[B,Cout,Ho,Wo] with Ho = (Hin + 2*(k/2) - k)/stride + 1.  Backward-data of a stride-2 conv is
+ * pnsfm_conv2d_backward_data applied to dy zero-upsampled onto the input grid (dy[y][x] at (2y, 2x)). */
+int pnsfm_conv2d_forward_strided(const float* x, const float* wp_fwd, const float* bias /*nullable*/, float* y,
+                                 int B, int Cin, int Cout, int Hin, int Win, int ks, int stride, void* stream);
+int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
+                                         int B, int Cin, int Cout, int Hin, int Win, int ks, int stride, void* stream);
+
 /* Runtime autotuning of the conv kernels' tiling / split factors (default on; env PNSFM_AUTOTUNE=0 turns it off).
  * The first call for a new shape times the candidate configurations on the caller's stream (it synchronises), like
  * `torch.backends.cudnn.benchmark = True` in the reference (trainers/horovod_trainer.py:19). */

@@ -33,7 +33,8 @@ int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 static const size_t kMaxSmem = 64 * 1024;
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
-static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0) {
+static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0,
+                            int S = 1) {
   g.DMA = DMA;
   const int HW = H * W;
   g.MT = conv_pick_MT(Cout);
@@ -46,16 +47,16 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   if (g.mode == 0) {
     g.tiles_x = W / 32;
     g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
-    g.PH = 4 * NT + ks - 1;
-    g.PW = 32 + ks - 1;
+    g.PH = (4 * NT - 1) * S + ks;
+    g.PW = 31 * S + ks;
   } else {
     const int tile_px = 128 * NT;
     g.tiles_x = 0;
     g.tiles_per_img = ceil_div(HW, tile_px);
     int rows = (tile_px + W - 2) / W + 1;
     if (rows > H) rows = H;
-    g.PH = rows + ks - 1;
-    g.PW = W + ks - 1;
+    g.PH = (rows - 1) * S + ks;
+    g.PW = (W - 1) * S + ks;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
   auto smem_for = [&](int CI) -> size_t {
@@ -79,13 +80,13 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
 // (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
 static int g_default_dma = 0;   // un-tuned default variant (see pnsfm_set_conv_variant)
 
-ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
+ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S) {
   ConvGeom g;
   int NT = 2;
   int DA = g_default_dma;
-  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA) ||
+  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA, S) ||
       (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
-  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA);
+  conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA, S);
   const long blocks = (long)B * g.tiles_per_img * (g.MP / (32 * g.MT));
   int split = 1;
   if (blocks < 4 * 256 && g.nchunks >= 4) {
@@ -93,7 +94,7 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks) {
     if (split > g.nchunks / 2) split = g.nchunks / 2;
     if (split < 1) split = 1;
   }
-  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, DA) && DA) conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, 0);
+  if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, DA, S) && DA) conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split, g, 0, S);
   return g;
 }
 
@@ -121,7 +122,8 @@ struct ConvArgs {
   const float* wp;    // [KK][KP][MP]
   const float* bias;  // [Cout] or null
   float* y;           // [B][Cout][H][W]
-  int B, Cin, Cout, H, W, KS;
+  int B, Cin, Cout, H, W, KS;   // H, W: OUTPUT size
+  int S, Hi, Wi;                // stride (1 | 2) and INPUT size (Hi = H, Wi = W when S == 1)
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
   int pstride;        // DMA variant: floats between the two patch buffers
   float invPW, invPS;
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
   const int P = a.KS >> 1, KK = a.KS * a.KS;
   const int H = a.H, W = a.W, HW = H * W;
+  const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = Hi * Wi;
 
   const int b = blockIdx.x / a.tiles_per_img;
   const int t = blockIdx.x - b * a.tiles_per_img;
@@ -166,20 +169,20 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
   if (a.mode == 0) {
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int y0 = ty * 4 * NT, x0 = tx * 32;
-    py0 = y0 - P;
-    px0 = x0 - P;
+    py0 = y0 * S - P;
+    px0 = x0 * S - P;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int row = wave * NT + nt;
       oy[nt] = y0 + row;
       ox[nt] = x0 + l32;
       pvalid[nt] = oy[nt] < H;
-      boff[nt] = row * a.PW + l32;
+      boff[nt] = (row * a.PW + l32) * S;
     }
   } else {
     const int n0 = t * 128 * NT;
     const int r0 = n0 / W;
-    py0 = r0 - P;
+    py0 = r0 * S - P;
     px0 = -P;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
       const int yy = pvalid[nt] ? n / W : r0;
       oy[nt] = yy;
       ox[nt] = pvalid[nt] ? n - yy * W : 0;
-      boff[nt] = (yy - r0) * a.PW + ox[nt];
+      boff[nt] = ((yy - r0) * a.PW + ox[nt]) * S;
     }
   }
 
@@ -200,16 +203,16 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* xb = a.x + (size_t)b * a.Cin * HW;
+  const float* xb = a.x + (size_t)b * a.Cin * HWi;
   // element `idx` of the patch of the chunk starting at channel ci0 -> its global address, or the zero page
   auto patch_src = [&](int ci0, int idx) -> const float* {
     const int cil = (int)(((float)idx + 0.5f) * a.invPS);
     const int e = idx - cil * PS;
     const int r = (int)(((float)e + 0.5f) * a.invPW);
     const int cc = e - r * a.PW;
-    const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
-    const bool ok = idx < ptotal && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    return ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
+    const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;   // input coordinates
+    const bool ok = idx < ptotal && ci < a.Cin && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+    return ok ? xb + ((size_t)ci * HWi + yy * Wi + xx) : pnsfm_zero_page;
   };
   // weight slab loader geometry: slab = [CI][BM] floats, one float4 per thread (rows past the packed K extent are zero)
   const int wrow = tid / (BM / 4), wc4 = tid - wrow * (BM / 4);
@@ -332,10 +335,11 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 }
 
 static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
-                        int Cout, int H, int W, int ks, hipStream_t stream, const char* what) {
+                        int Cout, int H, int W, int ks, hipStream_t stream, const char* what, int S, int Hi, int Wi) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.y = y;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
+  a.S = S; a.Hi = Hi; a.Wi = Wi;
   a.CI = g.CI; a.mode = g.mode; a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img;
   a.PH = g.PH; a.PW = g.PW; a.KP = g.KP; a.MP = g.MP; a.nchunks = g.nchunks;
   a.chunks_per_split = ceil_div(g.nchunks, g.splitK); a.splitK = g.splitK;
@@ -378,14 +382,17 @@ static float time_on_stream(hipStream_t stream, int reps, F fn) {
 #endif
 
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
-                       int H, int W, int ks, hipStream_t stream, const char* what, int kind_tag) {
+                       int H, int W, int ks, hipStream_t stream, const char* what, int kind_tag, int S = 1, int Hi = 0,
+                       int Wi = 0) {
+  if (S == 1) { Hi = H; Wi = W; }
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
-  ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks);
+  if (S != 1 && S != 2) { set_error("%s: unsupported stride %d", what, S); return -1; }
+  ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks, S);
   if (g.smem_bytes > kMaxSmem) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
 #ifndef PNSFM_EMU
   if (autotune_enabled()) {
-    const std::array<int, 7> key = {kind_tag, B, Cin, Cout, H, W, ks};
+    const std::array<int, 7> key = {kind_tag + 10 * S, B, Cin, Cout, H, W, ks};
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it == g_tuned.end()) {
@@ -397,24 +404,24 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
-          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA)) break;
+          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA, S)) break;
           if (c.splitK == last_split) continue;
           last_split = c.splitK;
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
-          const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what); });
+          const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi); });
           if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4), c.splitK}; }
         }
       }
       it = g_tuned.emplace(key, best).first;
     }
-    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, it->second[0] >> 4);
+    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, it->second[0] >> 4, S);
   }
 #endif
-  const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;
+  const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
   prof_begin(0, flops, stream, meta);
-  const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what);
+  const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi);
   prof_end(0, stream);
   return rc;
 }
@@ -480,7 +487,8 @@ struct WgradArgs {
   float* dbias;     // [Cout] or null: bias gradient (row sums of dY), accumulated by the n-tile-0 blocks
   int B, Cin, Cout, H, W, KS;
   int PT, mode, tiles_x, tiles_per_img, PH, PW, NCI, total_tiles, tiles_per_split, splitP;
-  int cstride;  // true H*W (channel stride); H, W above are the TILING dims (k=1 flattens the image to 32-wide rows)
+  int cstride;  // true H*W of dY (channel stride); H, W above are the TILING dims (k=1 flattens the image to 32-wide rows)
+  int S, Hi, Wi; // stride and INPUT (x) size; dY / the pixel tiles live on the OUTPUT grid
   int vec4, PTlog;
   float invPW, invPS;
 };
@@ -499,6 +507,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
   const int P = a.KS >> 1, KK = a.KS * a.KS;
   const int H = a.H, W = a.W, HW = a.cstride;
+  const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = a.S == 1 ? a.cstride : a.Hi * a.Wi;
   const int N = a.Cin * KK;
 
   const int n0 = blockIdx.x * 128;
@@ -533,12 +542,12 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
       y0 = ty * (PT >> 5);
       x0 = tx * 32;
-      py0 = y0 - P;
-      px0 = x0 - P;
+      py0 = y0 * S - P;
+      px0 = x0 * S - P;
     } else {
       pn0 = t * PT;
       r0 = pn0 / W;
-      py0 = r0 - P;
+      py0 = r0 * S - P;
       px0 = -P;
     }
     __syncthreads();  // previous tile fully consumed
@@ -598,10 +607,10 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
       int off;
       if (a.mode == 0) off = (p >> 5) * a.PW + (p & 31);
       else { const int pn = pn0 + p; const bool ok = pn < HW; const int yy = ok ? pn / W : r0; const int xx = ok ? pn - yy * W : 0; off = (yy - r0) * a.PW + xx; }
-      poff[p] = off;
+      poff[p] = off * S;
     }
     // ---- input halo patch for channels ci_lo .. ci_lo+NCI-1 (branch-free, batched)
-    const float* xb = a.x + (size_t)b * a.Cin * HW;
+    const float* xb = a.x + (size_t)b * a.Cin * HWi;
     {
       const int total = a.NCI * PS;
       for (int base = tid; base < total; base += 256 * 8) {
@@ -614,8 +623,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
           const int r = (int)(((float)e + 0.5f) * a.invPW);
           const int cc = e - r * a.PW;
           const int yy = py0 + r, xx = px0 + cc, ci = ci_lo + cil;
-          const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W && yy * W + xx < HW;
-          const float* src = ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page;
+          const bool ok = idx < total && ci < a.Cin && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi && yy * Wi + xx < HWi;
+          const float* src = ok ? xb + ((size_t)ci * HWi + yy * Wi + xx) : pnsfm_zero_page;
           v[u] = *src;
         }
 #pragma unroll
@@ -724,19 +733,24 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx, 
   return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data", 1);
 }
 
-int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
-                                 int H, int W, int ks, void* stream) {
+// H, W: size of dY (the conv OUTPUT); x is [B, Cin, Hi, Wi] with Hi = H, Wi = W when S == 1
+static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                      int ks, int S, int Hi, int Wi, void* stream) {
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("backward_weight: unsupported kernel size %d", ks); return -1; }
+  if (S != 1 && S != 2) { set_error("backward_weight: unsupported stride %d", S); return -1; }
   hipStream_t s = (hipStream_t)stream;
   const int KK = ks * ks, N = Cin * KK, HW = H * W;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.cstride = HW;
-  if (ks == 1) {  // no halo: any pixel order works, so tile the flattened image as 32-wide rows
+  a.S = S;
+  if (ks == 1 && S == 1) {  // no halo: any pixel order works, so tile the flattened image as 32-wide rows
     a.W = W = 32;
     a.H = H = ceil_div(HW, 32);
+    Hi = H; Wi = W;
   }
+  a.Hi = Hi; a.Wi = Wi;
   const int MT = conv_pick_MT(Cout), BM = 32 * MT;
   a.mode = (W % 32 == 0) ? 0 : 1;
   a.NCI = 127 / KK + 2;
@@ -747,15 +761,15 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
     if (a.mode == 0) {
       a.tiles_x = W / 32;
       a.tiles_per_img = a.tiles_x * ceil_div(H, PT / 32);
-      a.PH = PT / 32 + ks - 1;
-      a.PW = 32 + ks - 1;
+      a.PH = (PT / 32 - 1) * S + ks;
+      a.PW = 31 * S + ks;
     } else {
       a.tiles_x = 0;
       a.tiles_per_img = ceil_div(HW, PT);
       int rows = (PT + W - 2) / W + 1;
       if (rows > H) rows = H;
-      a.PH = rows + ks - 1;
-      a.PW = W + ks - 1;
+      a.PH = (rows - 1) * S + ks;
+      a.PW = (W - 1) * S + ks;
     }
     smem = ((size_t)BM * (PT + 1) + (size_t)a.NCI * a.PH * a.PW + PT) * sizeof(float);
     if (smem <= kMaxSmem) break;
@@ -807,7 +821,7 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   };
 #ifndef PNSFM_EMU
   if (autotune_enabled()) {
-    const std::array<int, 7> key = {2, B, Cin, Cout, a.cstride, W, ks};
+    const std::array<int, 7> key = {2 + 10 * S, B, Cin, Cout, a.cstride, W, ks};
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it == g_tuned.end()) {
@@ -835,6 +849,26 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
   const int rc = enqueue(a.splitP);
   prof_end(1, s);
   return rc;
+}
+
+int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
+                                 int H, int W, int ks, void* stream) {
+  return wgrad_impl(x, dy, dw, dbias, B, Cin, Cout, H, W, ks, 1, H, W, stream);
+}
+
+int pnsfm_conv2d_forward_strided(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin,
+                                 int Cout, int Hin, int Win, int ks, int stride, void* stream) {
+  const int P = ks / 2;
+  const int Ho = (Hin + 2 * P - ks) / stride + 1, Wo = (Win + 2 * P - ks) / stride + 1;
+  return launch_conv(x, wp_fwd, bias, y, B, Cin, Cout, Ho, Wo, ks, (hipStream_t)stream, "conv2d_forward_strided", 0, stride,
+                     Hin, Win);
+}
+
+int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin,
+                                         int Cout, int Hin, int Win, int ks, int stride, void* stream) {
+  const int P = ks / 2;
+  const int Ho = (Hin + 2 * P - ks) / stride + 1, Wo = (Win + 2 * P - ks) / stride + 1;
+  return wgrad_impl(x, dy, dw, dbias, B, Cin, Cout, Ho, Wo, ks, stride, Hin, Win, stream);
 }
 
 int pnsfm_set_autotune(int on) {

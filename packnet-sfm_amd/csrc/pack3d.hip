@@ -98,59 +98,47 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
 }
 
 // dp[b][d][y][x] = sum_{f,dz,dy,dx} w3[f][dz][dy][dx] * dout[b][f*D + d-dz+1][y-dy+1][x-dx+1]
-// grid: (ceil(D*H*ceil(W/4)/256), 1, B): one thread per run of 4 consecutive x -- the 6 values dout[..][x0-1 .. x0+4] of
-// each (f, dz, dy) row feed 3 taps x 4 outputs, halving the loads per voxel (108 instead of 216); all loads of one
-// (dz, dy) slab (8 features x 6) are issued branch-free before use.
+// same thread mapping as the forward stencil; the 8x9 loads of one dz slab are issued together (unconditional loads,
+// pointer-selected against the zero page) before they are consumed.  (A variant that register-blocks 4 consecutive x per
+// thread to halve the loads measured slower -- 1.66 vs 1.14 ms per step -- and was dropped.)
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
                                                             float* __restrict__ dp, int D, int H, int W) {
   __shared__ float ws[8 * 27];
   for (int i = threadIdx.x; i < 8 * 27; i += 256) ws[i] = w3[i];
   __syncthreads();
-  const int HW = H * W, DHW = D * HW, W4 = (W + 3) >> 2;
-  const int grp = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W, DHW = D * HW;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.z;
-  const bool active = grp < D * H * W4;
-  const int d = active ? grp / (H * W4) : 0;
-  const int rem = active ? grp - d * (H * W4) : 0;
-  const int y = rem / W4, x0 = (rem - y * W4) << 2;
+  const bool active = vox < DHW;
+  const int d = active ? vox / HW : 0;
+  const int pix = active ? vox - d * HW : 0;
+  const int y = pix / W, x = pix - y * W;
   const float* gb = dout + (size_t)b * 8 * DHW;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  // the 9 (dz, dy) slabs stay a real loop: fully unrolled, hipcc hoists all 432 loads and spills
+  float acc = 0.f;
 #pragma unroll 1
   for (int dz = 0; dz < 3; ++dz) {
     const int dd = d - dz + 1;
     const bool dok = active && dd >= 0 && dd < D;
-#pragma unroll 1
+    float g[8][9];
+#pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int yy = y - dy + 1;
-      const bool rok = dok && yy >= 0 && yy < H;
-      const int rowoff = rok ? (dd * HW + yy * W) : 0;
-      float v[8][6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int xx = x0 - 1 + i;
-        const bool ok = rok && xx >= 0 && xx < W;
-        const float* src = ok ? gb + (rowoff + xx) : pnsfm_zero_page3;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x - dx + 1;
+        const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* src = ok ? gb + (dd * HW + yy * W + xx) : pnsfm_zero_page3;
         const size_t fstride = ok ? (size_t)DHW : 0;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) v[f][i] = src[f * fstride];
+        for (int f = 0; f < 8; ++f) g[f][dy * 3 + dx] = src[f * fstride];
       }
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float wv = ws[f * 27 + dz * 9 + dy * 3 + dx];
-#pragma unroll
-          for (int o = 0; o < 4; ++o) acc[o] = fmaf(wv, v[f][o - dx + 2], acc[o]);
-        }
     }
-  }
-  if (active) {
-    float* out = dp + (size_t)b * DHW + (size_t)d * HW + y * W + x0;
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
-      if (x0 + o < W) out[o] = acc[o];
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc = fmaf(ws[f * 27 + dz * 9 + t], g[f][t], acc);
   }
+  if (active) dp[(size_t)b * DHW + vox] = acc;
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
@@ -251,7 +239,7 @@ int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, 
 }
 
 int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * ((W + 3) / 4), 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
+  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
   return check_launch("conv3d_backward_data");
 }
 

@@ -62,7 +62,7 @@ struct ConvGeom {
   int DMA;            // 1: input patch double-buffered in LDS and fetched by LDS-DMA (global_load_lds)
   size_t smem_bytes;
 };
-ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks);
+ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S = 1);   // H, W: output size; S: stride
 // padded dims of a packed weight [ks*ks][KP][MP] for a conv with K-channels `Kc`, M-channels `Mc`
 int conv_pack_KP(int Kc);
 int conv_pack_MP(int Mc);

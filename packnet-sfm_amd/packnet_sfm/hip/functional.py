@@ -90,6 +90,42 @@ def conv2d(x, weight, bias, cache):
     return Conv2dFn.apply(x, weight, bias, cache)
 
 
+class Conv2dStride2Fn(Function):
+    """Stride-2 conv with zero padding k//2 (PoseNet).  Forward and weight-gradient run the strided MFMA kernels; the
+    data-gradient is the stride-1 backward-data kernel on dy zero-upsampled onto the input grid."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache):
+        x = x.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        wp_fwd, wp_bwd = cache.get(weight, need_dx)
+        Cout, Cin, ks, _ = weight.shape
+        y = ops.conv2d_forward_strided(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks, 2)
+        ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
+        ctx.meta = (Cin, Cout, ks, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wp_bwd = ctx.saved_tensors
+        Cin, Cout, ks, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            B, _, H, W = x.shape
+            up = dy.new_zeros((B, Cout, H, W))
+            up[:, :, ::2, ::2] = dy                      # dy[y][x] sits at (2y, 2x) of the input grid
+            dx = ops.conv2d_backward_data(up, wp_bwd, Cin, ks)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.conv2d_backward_weight_strided(x, dy, ks, 2, want_bias=has_bias)
+        return dx, dw, db, None
+
+
+def conv2d_stride2(x, weight, bias, cache):
+    return Conv2dStride2Fn.apply(x, weight, bias, cache)
+
+
 class GroupNormActFn(Function):
     """y = act(GroupNorm_G(x [+ res]))."""
 

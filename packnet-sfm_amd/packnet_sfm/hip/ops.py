@@ -91,6 +91,30 @@ def conv2d_backward_weight(x, dy, ks, want_bias=True):
     return dw, db
 
 
+def conv2d_forward_strided(x, wp_fwd, bias, Cout, ks, stride):
+    _chk(x, wp_fwd, bias); _f32(x, wp_fwd, bias)
+    B, Cin, H, W = x.shape
+    P = ks // 2
+    Ho, Wo = (H + 2 * P - ks) // stride + 1, (W + 2 * P - ks) // stride + 1
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    rc = _lib.get().pnsfm_conv2d_forward_strided(_ptr(x), _ptr(wp_fwd), _ptr(bias), _ptr(y), B, Cin, Cout, H, W, ks, stride,
+                                                 _stream(x))
+    _lib.check(rc, "conv2d_forward_strided")
+    return y
+
+
+def conv2d_backward_weight_strided(x, dy, ks, stride, want_bias=True):
+    _chk(x, dy); _f32(x, dy)
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    rc = _lib.get().pnsfm_conv2d_backward_weight_strided(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, ks, stride,
+                                                         _stream(x))
+    _lib.check(rc, "conv2d_backward_weight_strided")
+    return dw, db
+
+
 # ------------------------------------------------------------------------------------------- groupnorm
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 GN_MAX_SPLIT = 64     # PNSFM_GN_MAX_SPLIT in include/pnsfm.h

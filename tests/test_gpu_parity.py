@@ -59,6 +59,10 @@ def test_packnet01_golden():
     P.case_packnet01(DEV)
 
 
+def test_posenet_golden():
+    P.case_posenet(DEV)
+
+
 def _selfsup(device, fx):
     from oracle import packnet_oracle as O
     from packnet_sfm.models.SelfSupModel import SelfSupModel

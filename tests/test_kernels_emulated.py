@@ -122,3 +122,28 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     for pa, pb in zip(net_a.parameters(), net_b.parameters()):
         P.check(pb, pa, 1e-5, 'flat adam parameter')
     assert set(net_b.state_dict().keys()) == set(net_a.state_dict().keys())
+
+
+@pytest.mark.parametrize('shape', [(1, 9, 16, 8, 64, 7), (2, 6, 32, 12, 40, 5), (1, 16, 8, 3, 10, 3), (1, 4, 8, 6, 20, 3)])
+def test_conv2d_stride2(emulated_kernels, shape):
+    """PoseNet's stride-2 convs (even and odd input sizes): strided forward / weight-gradient kernels and the
+    zero-upsample + stride-1 backward-data path vs torch."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import functional as HF
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=2, padding=(ks - 1) // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xh, wh, bh = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = HF.conv2d_stride2(xh, wh, bh, HF.PackedConvWeight())
+    assert y.shape == yr.shape
+    y.backward(dy)
+    P.check(y, yr, 1e-5, 'fwd')
+    P.check(xh.grad, xr.grad, 1e-5, 'dgrad')
+    P.check(wh.grad, wr.grad, 1e-5, 'wgrad')
+    P.check(bh.grad, br.grad, 1e-5, 'dbias')

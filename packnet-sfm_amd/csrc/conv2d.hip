@@ -34,10 +34,13 @@ static const size_t kMaxSmem = 64 * 1024;
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
 static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0,
-                            int S = 1) {
+                            int S = 1, int forceMT = 0) {
   g.DMA = DMA;
   const int HW = H * W;
   g.MT = conv_pick_MT(Cout);
+  // 32-row M tiles instead of 64 double the block count of a low-resolution layer WITHOUT split-K atomics; the packed
+  // weight layout is the same as long as its padded M extent is a multiple of 64 anyway
+  if (forceMT == 1 && g.MT == 2) g.MT = 1;
   const int BM = 32 * g.MT;
   g.MP = conv_pack_MP(Cout);
   g.KP = conv_pack_KP(Cin);
@@ -399,23 +402,24 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
-      for (int cfg = 0; cfg < 4; ++cfg) {
-        const int NT = 2 - (cfg & 1), DA = cfg >> 1;
+      const int ncfg = (conv_pick_MT(Cout) == 2) ? 8 : 4;
+      for (int cfg = 0; cfg < ncfg; ++cfg) {
+        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) & 1, fMT = (cfg >> 2) & 1;
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
-          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA, S)) break;
+          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA, S, fMT)) break;
           if (c.splitK == last_split) continue;
           last_split = c.splitK;
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
           const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi); });
-          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4), c.splitK}; }
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8), c.splitK}; }
         }
       }
       it = g_tuned.emplace(key, best).first;
     }
-    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, it->second[0] >> 4, S);
+    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 1, S, (it->second[0] >> 8) & 1);
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)

@@ -62,6 +62,9 @@ int pnsfm_set_autotune(int on);
  * LDS-DMA (global_load_lds) issued in slices between the taps.  The autotuner times both; this switch exists for tests.
  * Clears the tuning cache. */
 int pnsfm_set_conv_variant(int lds_dma);
+/* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and
+ * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen
+ * convolutions.  A process started with a complete database launches no candidate kernels. */
 
 /* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the

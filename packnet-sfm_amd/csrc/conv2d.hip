@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
+#include <cstdio>
 
 namespace pnsfm {
 
@@ -108,6 +110,31 @@ static int g_autotune = -1;
 static std::map<std::array<int, 7>, std::array<int, 2>> g_tuned;
 static std::mutex g_tune_mu;
 
+// Tuning database (the analogue of MIOpen's user find-db): PNSFM_TUNE_DB=<file> loads earlier decisions at start-up
+// and appends new ones, so that a later process (a profiling run, a resumed training job) launches no candidates.
+// One text line per decision: kind B Cin Cout H W ks  cfg split.
+static std::string g_tune_db;
+
+static int tune_db_load(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  int k[7], v[2], n = 0;
+  while (fscanf(f, "%d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &v[0], &v[1]) == 9) {
+    g_tuned[{k[0], k[1], k[2], k[3], k[4], k[5], k[6]}] = {v[0], v[1]};
+    ++n;
+  }
+  fclose(f);
+  return n;
+}
+
+static void tune_db_append(const std::array<int, 7>& k, const std::array<int, 2>& v) {
+  if (g_tune_db.empty()) return;
+  FILE* f = fopen(g_tune_db.c_str(), "a");
+  if (!f) return;
+  fprintf(f, "%d %d %d %d %d %d %d %d %d\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], v[0], v[1]);
+  fclose(f);
+}
+
 static bool autotune_enabled() {
 #ifdef PNSFM_EMU
   return false;
@@ -115,6 +142,12 @@ static bool autotune_enabled() {
   if (g_autotune < 0) {
     const char* e = getenv("PNSFM_AUTOTUNE");
     g_autotune = (e && e[0] == '0') ? 0 : 1;
+    const char* db = getenv("PNSFM_TUNE_DB");
+    if (db && db[0] && g_autotune == 1) {
+      g_tune_db = db;
+      std::lock_guard<std::mutex> lk(g_tune_mu);
+      tune_db_load(db);
+    }
   }
   return g_autotune == 1;
 #endif
@@ -418,6 +451,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
         }
       }
       it = g_tuned.emplace(key, best).first;
+      tune_db_append(key, best);
     }
     conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 1, S, (it->second[0] >> 8) & 1);
   }
@@ -843,6 +877,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; }
       }
       it = g_tuned.emplace(key, std::array<int, 2>{best_split, 0}).first;
+      tune_db_append(key, it->second);
     }
     a.splitP = it->second[0];
   }

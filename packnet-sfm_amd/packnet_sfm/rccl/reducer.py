@@ -7,7 +7,9 @@ ROCm (xGMI on an MI355X node), "gloo" is used by the CPU tests.
 
 MI355X-first choices (not a translation of horovod's tensor-fusion queue):
   * parameters are laid into a few LARGE flat fp32 buckets once, in reverse registration order (~ the order backward
-    produces them); each `param.grad` is a *view* into its bucket, so there is no pack/unpack copy per step;
+    produces them).  Autograd hands each parameter its freshly computed gradient tensor (no accumulate pass, no
+    zero-fill); when the last gradient of a bucket exists, ONE multi-tensor copy (`torch._foreach_copy_`) gathers the
+    bucket and every `param.grad` is re-pointed at its bucket view, so the optimizer reads the reduced values in place;
   * xGMI is point-to-point and a ring all-reduce is bound by one link (~153 GB/s), so a step wants few, big
     collectives: the default bucket is 128 MiB (519.5 MB of PackNet01+PoseNet gradients -> 5 collectives; the
     302 MB pack5 weight is its own bucket), and 288 GB of HBM makes the duplicate flat buffers free;
@@ -72,6 +74,10 @@ class GradBucketReducer:
         # run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
         self.force = bool(force_collectives) and dist.is_initialized()
         self.average = average
+        # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG, so the CPU tests scale afterwards
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._fused_avg = bool(average) and backend == 'nccl'
+        self._reduce_op = dist.ReduceOp.AVG if self._fused_avg else dist.ReduceOp.SUM
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError('GradBucketReducer: no trainable parameters')
@@ -91,8 +97,8 @@ class GradBucketReducer:
         self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         self._hooks = []
         for b in self.buckets:
-            for p, v in zip(b.params, b.views):
-                p.grad = v                               # gradients accumulate straight into the bucket
+            for p in b.params:
+                p.grad = None
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
         self._launched = 0
 
@@ -104,44 +110,55 @@ class GradBucketReducer:
 
     def _make_hook(self, bucket):
         def hook(param):
-            # autograd may have replaced .grad (first accumulation into a None grad); keep the bucket view
-            idx = next(i for i, q in enumerate(bucket.params) if q is param)
-            if param.grad is not bucket.views[idx]:
-                if param.grad is not None and param.grad.data_ptr() != bucket.views[idx].data_ptr():
-                    bucket.views[idx].copy_(param.grad)
-                param.grad = bucket.views[idx]
             bucket.pending -= 1
             if bucket.pending == 0:
+                self._gather(bucket)
                 self._launch(bucket)
         return hook
+
+    @staticmethod
+    def _gather(bucket):
+        """Copy the bucket's gradients into its flat buffer with one multi-tensor launch and alias p.grad to the views."""
+        src, dst = [], []
+        for p, v in zip(bucket.params, bucket.views):
+            g = p.grad
+            if g is None:
+                v.zero_()                               # unused parameter this step
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g.detach())
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(bucket.params, bucket.views):
+            p.grad = v
 
     def _launch(self, bucket):
         self._launched += 1
         if self.world == 1 and not self.force:
             return
+        op = self._reduce_op
         if self.side_stream is not None:
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
-                bucket.work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                bucket.work = dist.all_reduce(bucket.flat, op=op, group=self.group, async_op=True)
         else:
-            bucket.work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            bucket.work = dist.all_reduce(bucket.flat, op=op, group=self.group, async_op=True)
 
     def zero_grad(self):
-        """Zero the buckets (gradients stay views; never set to None) and re-arm the hooks."""
+        """Drop the gradients (autograd will hand out fresh tensors; nothing is zero-filled) and re-arm the hooks."""
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = len(b.params)
             b.work = None
-            for p, v in zip(b.params, b.views):
-                if p.grad is not v:
-                    p.grad = v
+            for p in b.params:
+                p.grad = None
         self._launched = 0
 
     def synchronize(self):
         """Block the compute stream until every bucket is reduced; buckets whose hooks never all fired (unused
         parameters) are reduced now.  Applies the averaging."""
         for b in self.buckets:
-            if b.pending != 0 and (self.world > 1 or self.force) and b.work is None:
+            if b.pending != 0 and b.work is None:      # some parameters got no gradient: gather what exists, reduce now
+                self._gather(b)
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
@@ -149,7 +166,7 @@ class GradBucketReducer:
                 b.work = None
         if self.side_stream is not None and (self.world > 1 or self.force):
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
-        if self.average and self.world > 1:
+        if self.average and self.world > 1 and not self._fused_avg:
             scale = 1.0 / self.world
             for b in self.buckets:
                 b.flat.mul_(scale)

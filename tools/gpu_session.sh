@@ -19,13 +19,18 @@ bench)
   echo "== bench"
   timeout 900 python bench.py --steps 8 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1; tail -4 gpurun_out/bench_$TAG.log ;;
 prof)
-  echo "== rocprofv3 kernel trace"
+  echo "== rocprofv3 kernel trace (tuning database primed first, so the trace holds no autotune candidates)"
+  export PNSFM_TUNE_DB=$R/gpurun_out/tune_$TAG.db
+  [ -s $PNSFM_TUNE_DB ] || timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
+  wc -l $PNSFM_TUNE_DB
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o bench -- \
-      python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $R/gpurun_out/rocprof_$TAG.log 2>&1)
+      python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prof > $R/gpurun_out/rocprof_$TAG.log 2>&1)
   tail -2 gpurun_out/rocprof_$TAG.log; find gpurun_out/prof_$TAG -name "*stats*" | head
   f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 $f ;;
 pmc)
   echo "== rocprofv3 PMC passes (counters only, separate runs)"
+  export PNSFM_TUNE_DB=$R/gpurun_out/tune_$TAG.db
+  [ -s $PNSFM_TUNE_DB ] || timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)
     (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_${TAG}_$n -o bench -- \

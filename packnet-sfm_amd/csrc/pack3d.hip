@@ -98,103 +98,171 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
 }
 
 // dp[b][d][y][x] = sum_{f,dz,dy,dx} w3[f][dz][dy][dx] * dout[b][f*D + d-dz+1][y-dy+1][x-dx+1]
-// same thread mapping as the forward stencil; the 8x9 loads of one dz slab are issued together (unconditional loads,
-// pointer-selected against the zero page) before they are consumed.  (A variant that register-blocks 4 consecutive x per
-// thread to halve the loads measured slower -- 1.66 vs 1.14 ms per step -- and was dropped.)
+// The per-voxel form of this stencil issues 216 loads per output and is bound by the L1/TA path (measured: 166 us for
+// unpack1, 5x its HBM time).  Here one thread owns a column of `len` consecutive d at a fixed (y, x) and slides along d:
+// each dout plane (8 features x 9 in-plane neighbours = 72 raw buffer loads; zero padding by the hardware range check)
+// is loaded once and feeds the three outputs d = dd-1, dd, dd+1 (three rolling accumulators) -> 72*(len+2)/len loads
+// per output, ~80 for the run lengths the launcher picks.
+// Lanes still run along x (coalesced); the flattened (chunk, pixel) index keeps tiny planes (6x20 maps, 5x5 / 7x7 weight
+// volumes of the kernel composition) on full waves.  Weights are uniform global reads (scalar loads -> SGPR operands).
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
-                                                            float* __restrict__ dp, int D, int H, int W) {
-  __shared__ float ws[8 * 27];
-  for (int i = threadIdx.x; i < 8 * 27; i += 256) ws[i] = w3[i];
-  __syncthreads();
+                                                            float* __restrict__ dp, int D, int H, int W, int len) {
   const int HW = H * W, DHW = D * HW;
-  const int vox = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.z;
-  const bool active = vox < DHW;
-  const int d = active ? vox / HW : 0;
-  const int pix = active ? vox - d * HW : 0;
+  const int nchunk = (D + len - 1) / len;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool active = idx < nchunk * HW;
+  const int chunk = active ? idx / HW : 0;
+  const int pix = active ? idx - chunk * HW : 0;
   const int y = pix / W, x = pix - y * W;
-  const float* gb = dout + (size_t)b * 8 * DHW;
-  float acc = 0.f;
+  const int d0 = chunk * len;
+  const int dend = (d0 + len < D) ? d0 + len : D;
+  // one descriptor per feature slab [D][H][W] (the range-checked window); all wave-uniform, they live in SGPRs
+  pnsfm_buf gbuf[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) gbuf[f] = pnsfm_make_buf(dout + ((size_t)blockIdx.z * 8 + f) * DHW, (unsigned)DHW * 4u);
+  float* ob = dp + (size_t)blockIdx.z * DHW + pix;
+  const unsigned kOut = 0x7fffffffu;       // out-of-range byte offset -> the load returns 0
+  unsigned off[9];                         // in-plane byte offsets of the 9 neighbours (kOut outside the image)
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = y - dy + 1, xx = x - dx + 1;
+      const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      off[dy * 3 + dx] = ok ? (unsigned)(yy * W + xx) * 4u : kOut;
+    }
+  // a_lo -> output dd-1 (complete after this plane), a_mid -> output dd, a_hi -> output dd+1
+  float a_lo = 0.f, a_mid = 0.f, a_hi = 0.f;
 #pragma unroll 1
-  for (int dz = 0; dz < 3; ++dz) {
-    const int dd = d - dz + 1;
-    const bool dok = active && dd >= 0 && dd < D;
+  for (int dd = d0 - 1; dd <= dend; ++dd) {
+    const bool dok = dd >= 0 && dd < D;
+    const unsigned plane = dok ? (unsigned)dd * (unsigned)HW * 4u : 0u;
     float g[8][9];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y - dy + 1;
+    for (int t = 0; t < 9; ++t) {
+      const unsigned vo = (dok && off[t] != kOut) ? plane + off[t] : kOut;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x - dx + 1;
-        const bool ok = dok && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float* src = ok ? gb + (dd * HW + yy * W + xx) : pnsfm_zero_page3;
-        const size_t fstride = ok ? (size_t)DHW : 0;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) g[f][dy * 3 + dx] = src[f * fstride];
-      }
+      for (int f = 0; f < 8; ++f) g[f][t] = pnsfm_buf_load(gbuf[f], vo, 0u);
     }
 #pragma unroll
     for (int f = 0; f < 8; ++f)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc = fmaf(ws[f * 27 + dz * 9 + t], g[f][t], acc);
+      for (int t = 0; t < 9; ++t) {
+        a_lo = fmaf(w3[f * 27 + t], g[f][t], a_lo);             // dz = 0: d = dd - 1
+        a_mid = fmaf(w3[f * 27 + 9 + t], g[f][t], a_mid);       // dz = 1: d = dd
+        a_hi = fmaf(w3[f * 27 + 18 + t], g[f][t], a_hi);        // dz = 2: d = dd + 1
+      }
+    if (active && dd - 1 >= d0 && dd - 1 < dend) ob[(size_t)(dd - 1) * HW] = a_lo;
+    a_lo = a_mid;
+    a_mid = a_hi;
+    a_hi = 0.f;
   }
-  if (active) dp[(size_t)b * DHW + vox] = acc;
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
-// A reduction of 8 x 28 numbers over every voxel -- done on the matrix cores: per v_mfma_f32_32x32x2_f32,
-//   A[m = feature f (8 of 32 rows used)][k = 2 consecutive voxels]  = dout[f][voxel]
-//   B[k][n = tap (27 of 32 columns) | n = 27: a column of ones]     = p[voxel + offset(tap)]  (zero outside the volume)
-// so D[f][tap] accumulates dw3 and D[f][27] accumulates db3.  Operands come straight from global/L1 (neighbouring voxels
-// share cache lines); each wave walks whole (b, d, y) rows so no index division sits in the x loop.  No LDS staging, no
-// barriers; one LDS reduction over the block's 4 waves at the end, then 224 fp64 atomics per block.
+// A reduction of 8 x 28 numbers over every voxel; 216 FMAs per voxel, so the floor is the fp32 VALU rate (43 us for
+// unpack1), close to the HBM time of reading dout once (35 us).  (An MFMA formulation -- A = dout[f], B = the 27 shifted
+// copies of p -- needs one gathered operand load per lane per 2 voxels and measured 217 us: the taps of one B fragment
+// touch 9 different rows.)  Same column-sliding scheme as the data gradient: a thread owns (b, 4 of the 8 features, a
+// run of `len` consecutive d, one (y, x)); it keeps the three p planes d-1, d, d+1 (27 registers, rotated by a 3x
+// unrolled loop instead of moves), loads 9 new p values + 4 dout values per step, and accumulates 4 x 27 products (+ 4
+// bias sums) in registers.  Lanes run along x, so every load is coalesced.  The 112 per-thread partials are reduced
+// through LDS 16 at a time (conflict-free padded rows, then a 16-lane shuffle), one fp64 atomic per value per block.
+constexpr int kW3Pass = 16, kW3Row = 256 + 16;
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
-                                                            double* __restrict__ ws, int B, int D, int H, int W) {
-  __shared__ float red[4][8 * 28];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
-  const int HW = H * W;
-  const bool fa = l32 < 8;                  // A row = feature
-  const bool tb = l32 < 27, ones = l32 == 27;   // B column = tap / ones column
-  const int dz = l32 / 9, dy = (l32 - dz * 9) / 3, dx = l32 - dz * 9 - dy * 3;
-  f32x16 acc;
+                                                            double* __restrict__ ws, int D, int H, int W, int len) {
+  __shared__ float red[kW3Pass * kW3Row];
+  const int tid = threadIdx.x;
+  const int HW = H * W, DHW = D * HW;
+  const int nchunk = (D + len - 1) / len;
+  const int idx = blockIdx.x * 256 + tid;
+  const bool active = idx < nchunk * HW;
+  const int chunk = active ? idx / HW : 0;
+  const int pix = active ? idx - chunk * HW : 0;
+  const int y = pix / W, x = pix - y * W;
+  const int fg = blockIdx.y, b = blockIdx.z;
+  const int d0 = chunk * len;
+  const int dend = (d0 + len < D) ? d0 + len : D;
+  const float* pb = p + (size_t)b * DHW;
+  const float* gb = dout + ((size_t)b * 8 + fg * 4) * DHW + pix;
+  int off[9];
+  bool okp[9];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const long rows = (long)B * D * H;
-  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-    const int y = (int)(row % H);
-    const long bd = row / H;
-    const int d = (int)(bd % D), b = (int)(bd / D);
-    const float* grow = dout + (((size_t)b * 8 + (fa ? l32 : 0)) * D + d) * HW + (size_t)y * W;
-    const int dd = d + dz - 1, yy = y + dy - 1;
-    const bool rowok = tb && dd >= 0 && dd < D && yy >= 0 && yy < H;
-    const float* prow = p + ((size_t)b * D + (rowok ? dd : 0)) * HW + (size_t)(rowok ? yy : 0) * W;
-    for (int x0 = 0; x0 < W; x0 += 8) {
-      float av[4], bv[4];
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int x = x0 + 2 * u + half;
-        const bool okx = x < W;
-        const float* sa = (fa && okx) ? grow + x : pnsfm_zero_page3;
-        av[u] = *sa;
-        const int xx = x + dx - 1;
-        const bool okb = rowok && okx && xx >= 0 && xx < W;
-        const float* sb = okb ? prow + xx : pnsfm_zero_page3;
-        const float t = *sb;
-        bv[u] = (ones && okx) ? 1.f : t;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = pnsfm_mfma_32x32x2(av[u], bv[u], acc);
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = y + dy - 1, xx = x + dx - 1;
+      okp[dy * 3 + dx] = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      off[dy * 3 + dx] = yy * W + xx;
     }
-  }
-  // D row = (r&3) + 8*(r>>2) + 4*half: rows 0..7 live in r = 0..3 -> feature f = r + 4*half; column = l32 (tap, 27 = bias)
-  if (l32 < 28) {
+  auto load_plane = [&](float (&q)[9], int dd) {
+    const bool dok = dd >= 0 && dd < D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(r + 4 * half) * 28 + l32] = acc[r];
+    for (int t = 0; t < 9; ++t) {
+      const float* src = (dok && okp[t]) ? pb + ((size_t)dd * HW + off[t]) : pnsfm_zero_page3;
+      q[t] = *src;
+    }
+  };
+  float acc[4][27], bs[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    bs[f] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[f][t] = 0.f;
   }
-  __syncthreads();
-  if (tid < 8 * 28) {
-    const double s = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
-    atomicAdd(&ws[tid], s);
+  auto step = [&](int d, const float (&q0)[9], const float (&q1)[9], const float (&q2)[9]) {
+    const bool ok = active && d < dend;
+    const float* src = ok ? gb + (size_t)d * HW : pnsfm_zero_page3;
+    const unsigned fstride = ok ? (unsigned)DHW : 0u;
+    float g[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) g[f] = src[f * fstride];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      bs[f] += g[f];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc[f][t] = fmaf(g[f], q0[t], acc[f][t]);
+        acc[f][9 + t] = fmaf(g[f], q1[t], acc[f][9 + t]);
+        acc[f][18 + t] = fmaf(g[f], q2[t], acc[f][18 + t]);
+      }
+    }
+  };
+  float pa[9], pc[9], pd[9];
+  load_plane(pa, d0 - 1);
+  load_plane(pc, d0);
+  for (int d = d0; d < dend; d += 3) {
+    load_plane(pd, d + 1);
+    step(d, pa, pc, pd);
+    load_plane(pa, d + 2);
+    step(d + 1, pc, pd, pa);
+    load_plane(pc, d + 3);
+    step(d + 2, pd, pa, pc);
+  }
+  // ---- block reduction of the 4 x 28 partials, kW3Pass values per pass
+  const int rv = tid >> 4, rj = tid & 15;
+#pragma unroll
+  for (int pass = 0; pass < 7; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kW3Pass; ++u) {
+      const int v = pass * kW3Pass + u;      // 0..111: v = f*28 + t  (t = 27: bias)
+      const int f = v / 28, t = v - f * 28;
+      red[u * kW3Row + tid] = (t < 27) ? acc[f][t < 27 ? t : 0] : bs[f];
+    }
+    __syncthreads();
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += red[rv * kW3Row + rj + 16 * i];
+    sacc += __shfl_xor(sacc, 8);
+    sacc += __shfl_xor(sacc, 4);
+    sacc += __shfl_xor(sacc, 2);
+    sacc += __shfl_xor(sacc, 1);
+    if (rj == 0) {
+      const int v = pass * kW3Pass + rv;
+      const int f = v / 28, t = v - f * 28;
+      atomicAdd(&ws[(fg * 4 + f) * 28 + t], (double)sacc);
+    }
   }
 }
 
@@ -239,7 +307,12 @@ int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, 
 }
 
 int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W);
+  if ((size_t)D * H * W * 4 >= 0x7fffffffull) { set_error("conv3d_backward_data: feature slab exceeds the 2 GiB buffer window"); return -1; }
+  // run length along d: 8 (25 % halo planes) when that still gives every CU a few blocks, shorter for small volumes
+  int len = D < 8 ? D : 8;
+  while (len > 2 && (long)B * ceil_div(D, len) * H * W < 2L * 256 * 256) len = ceil_div(len, 2);
+  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), 1, B), dim3(256), 0,
+               (hipStream_t)stream, dout, w3, dp, D, H, W, len);
   return check_launch("conv3d_backward_data");
 }
 
@@ -248,11 +321,13 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
   if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
-  long nrows = (long)B * D * H;
-  int nblk = (int)((nrows + 3) / 4);
-  if (nblk > 2048) nblk = 2048;
-  if (nblk < 1) nblk = 1;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(nblk), dim3(256), 0, s, p, dout, ws, B, D, H, W);
+  // run length along d per thread: as long as possible (amortises the block reduction) while the grid still gives every
+  // CU a few blocks
+  int len = D;
+  while (len > 12 && (long)B * 2 * ceil_div(D, len) * H * W < 4L * 256 * 256) len = ceil_div(len, 2);
+  len = ceil_div(len, 3) * 3;
+  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), 2, B), dim3(256), 0, s, p, dout, ws, D, H,
+               W, len);
   e = check_launch("conv3d_backward_weight");
   if (e) return e;
   PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3);

@@ -15,6 +15,13 @@ typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
 // LDS-DMA: lane l of the wave copies 4 bytes from its own global address to lds_wave_base[l] (emulated synchronously)
 static inline void pnsfm_glds4(const float* src, float* lds_wave_base) { lds_wave_base[hipemu::my_lane()] = *src; }
+// buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
+struct pnsfm_buf { const char* base; unsigned bytes; };
+static inline pnsfm_buf pnsfm_make_buf(const void* base, unsigned bytes) { return pnsfm_buf{(const char*)base, bytes}; }
+static inline float pnsfm_buf_load(const pnsfm_buf& b, unsigned voff_bytes, unsigned soff_bytes) {
+  if (voff_bytes + 4u > b.bytes || voff_bytes > 0x7fffffffu) return 0.f;
+  return *reinterpret_cast<const float*>(b.base + (size_t)soff_bytes + voff_bytes);
+}
 #else
 #include <hip/hip_runtime.h>
 #define PNSFM_DYN_SMEM(T, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
@@ -32,6 +39,28 @@ __device__ __forceinline__ f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c)
 __device__ __forceinline__ void pnsfm_glds4(const float* src, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// Raw buffer loads (buffer_load_dword v, v_off, s[rsrc], s_off offen): the address is base + s_off + v_off with a
+// wave-uniform base and s_off, so a stencil's 72 neighbour loads need 9 offset VGPRs instead of 72 64-bit pointers, and
+// the hardware range check (v_off + 4 > num_records -> returns 0, no memory access) implements zero padding: invalid
+// lanes just carry an out-of-range v_off.  Callers pass s_off = 0 (one descriptor per uniform sub-tensor): how the scalar
+// offset enters the range check differs between ISA documents, so it is not relied upon.
+typedef int pnsfm_i32x4 __attribute__((ext_vector_type(4)));
+struct pnsfm_buf { pnsfm_i32x4 rsrc; };
+__device__ float pnsfm_llvm_raw_buffer_load_f32(pnsfm_i32x4 rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ __forceinline__ pnsfm_buf pnsfm_make_buf(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  pnsfm_buf b;
+  // the base is wave-uniform: keep the descriptor in SGPRs
+  b.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffu));
+  b.rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));   // stride 0
+  b.rsrc[2] = __builtin_amdgcn_readfirstlane((int)bytes);                              // num_records (bytes)
+  b.rsrc[3] = 0x00020000;                                                              // gfx9 raw dword buffer
+  return b;
+}
+__device__ __forceinline__ float pnsfm_buf_load(const pnsfm_buf& b, unsigned voff_bytes, unsigned soff_bytes) {
+  return pnsfm_llvm_raw_buffer_load_f32(b.rsrc, (int)voff_bytes, (int)soff_bytes, 0);
 }
 #endif
 

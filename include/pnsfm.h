@@ -42,7 +42,9 @@ int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias 
                          int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
                                int B, int Cin, int Cout, int H, int W, int ks, void* stream);
-/* dw in the reference layout [Cout][Cin][k][k]; dbias [Cout] (nullable). Both are overwritten. */
+/* dw in the reference layout [Cout][Cin][k][k]; dbias [Cout] (nullable). Both are overwritten.  When the autotuner
+ * splits the pixel reduction the outputs are zero-filled first; placing dbias directly behind dw (dbias == dw +
+ * Cout*Cin*k*k) lets one fill cover both. */
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
                                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 
@@ -106,6 +108,16 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
 int pnsfm_invdepth_act_forward(const float* x, float* y, size_t n, float min_depth, void* stream);
 int pnsfm_invdepth_act_backward(const float* dy, const float* y, float* dx, size_t n, float min_depth,
                                 void* stream);
+
+/* ---- InvDepth head, fused: y = sigmoid(conv3x3(zero_pad1(x)) + b) / min_depth, ONE output channel -----------------
+ * replaces InvDepth.forward (layers01.py:98-122: ConstantPad2d(1) -> Conv2d(C, 1, 3) -> Sigmoid -> / min_depth) with a
+ * streaming channel reduction (no matrix cores for a 1-row GEMM).  x:[B,C,H,W], w:[1][C][3][3], bias:[1], y:[B,1,H,W].
+ * backward: dz = dy * y * (1 - y*min_depth) from pnsfm_invdepth_act_backward; one kernel then produces dx:[B,C,H,W],
+ * dw:[C*9] and db:[1] (both overwritten; placing db right behind dw saves a fill). */
+int pnsfm_invdepth_conv_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
+                                float min_depth, void* stream);
+int pnsfm_invdepth_conv_backward(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int B,
+                                 int C, int H, int W, void* stream);
 
 /* ---- view synthesis: inv2depth -> Camera.reconstruct -> Camera.project -> grid_sample ------
  * replaces MultiViewPhotometricLoss.warp_ref_image for ONE scale and J context images:

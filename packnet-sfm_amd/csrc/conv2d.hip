@@ -724,7 +724,9 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
     bsum += __shfl_down(bsum, 2);
     bsum += __shfl_down(bsum, 1);
     const int m = tid >> 2;
-    if ((tid & 3) == 0 && m < BM && co0 + m < a.Cout) atomicAdd(&a.dbias[co0 + m], bsum);
+    if ((tid & 3) == 0 && m < BM && co0 + m < a.Cout) {
+      if (a.splitP == 1) a.dbias[co0 + m] = bsum; else atomicAdd(&a.dbias[co0 + m], bsum);
+    }
   }
 }
 
@@ -844,12 +846,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     WgradArgs c = a;
     c.tiles_per_split = ceil_div(a.total_tiles, split);
     c.splitP = ceil_div(a.total_tiles, c.tiles_per_split);
+    // un-split: every dw element and every dbias[co] has exactly one writer -> plain stores, nothing to zero.
+    // split over pixel tiles: fp32 atomics into zeroed buffers; one fill covers both when the caller laid dbias right
+    // behind dw (the Python wrapper does), two otherwise.
     if (c.splitP > 1) {
-      int e = (int)hipMemsetAsync(dw, 0, (size_t)Cout * N * sizeof(float), s);
-      if (e) { set_error("backward_weight: memset failed"); return e; }
-    }
-    if (dbias) {
-      int e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+      const bool joined = dbias == dw + (size_t)Cout * N;
+      int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
+      if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
       if (e) { set_error("backward_weight: memset failed"); return e; }
     }
     dim3 grid(n_tiles, m_tiles, c.splitP);

@@ -1,0 +1,187 @@
+// invdepth.hip -- the InvDepth head as one fused kernel each way.
+//
+//   y = sigmoid(conv3x3(zero_pad1(x)) + b) / min_depth,  x:[B,C,H,W] -> y:[B,1,H,W]
+//   /root/reference/packnet_sfm/networks/layers/packnet/layers01.py:98-122 (InvDepth: pad, conv1, Sigmoid, / min_depth)
+//
+// A convolution with ONE output channel has nothing for the matrix cores (a 32-row MFMA tile would be 3 % used: the
+// generic implicit-GEMM kernel ran these four layers at 1-3 TFLOP/s); it is a streaming reduction over the input
+// channels, bound by reading x once.  Algorithmic bytes: forward C*H*W*4 read + H*W*4 write per image; backward
+// C*H*W*4 read (x) + C*H*W*4 write (dx) + small.
+//
+// forward : a block owns 64 consecutive pixels x 4 channel quarters (lanes along x -> coalesced rows); every thread
+//           accumulates 9 taps x C/4 channels with wave-uniform weights (scalar loads), the four quarters meet in LDS.
+// backward: dz = dy * y * (1 - y*min_depth) comes from the caller (pnsfm_invdepth_act_backward).  With
+//           D_t(q) = dz[qy-ky+1][qx-kx+1] (zero outside the image) both gradients use the SAME nine numbers at input
+//           pixel q:   dx[c][q] = sum_t w[c][t] * D_t(q),     dw[c][t] = sum_q x[c][q] * D_t(q),   db = sum_q dz[q]
+//           so one kernel reads x once, writes dx once and keeps 8 channels x 9 taps of dw in registers per thread
+//           (block reduction through LDS, one fp32 atomic per value per block).
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+namespace pnsfm {
+
+__global__ void __launch_bounds__(256) invdepth_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int C, int H, int W, float inv_min_depth) {
+  __shared__ float part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, quarter = tid >> 6;
+  const int HW = H * W;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool active = pix < HW;
+  const int py = active ? pix / W : 0, px = active ? pix - py * W : 0;
+  const unsigned kOut = 0x7fffffffu;
+  unsigned off[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int yy = py + ky - 1, xx = px + kx - 1;
+      const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      off[ky * 3 + kx] = ok ? (unsigned)(yy * W + xx) * 4u : kOut;
+    }
+  const int cq = (C + 3) / 4;
+  const int c0 = quarter * cq;
+  const int c1 = (c0 + cq < C) ? c0 + cq : C;
+  float acc = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    const int cu = PNSFM_UNIFORM(c);      // the channel is wave-uniform (one quarter per wave): scalar weight loads
+    const pnsfm_buf pb = pnsfm_make_buf(x + ((size_t)blockIdx.z * C + cu) * HW, (unsigned)HW * 4u);
+    const float* wc = w + cu * 9;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = pnsfm_buf_load(pb, off[t], 0u);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = fmaf(wc[t], v[t], acc);
+  }
+  part[quarter][lane] = acc;
+  __syncthreads();
+  if (quarter == 0 && active) {
+    const float z = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] + bias[0];
+    y[(size_t)blockIdx.z * HW + pix] = inv_min_depth / (1.f + expf(-z));
+  }
+}
+
+constexpr int kIdCh = 8;                    // channels per thread in the backward kernel
+constexpr int kIdVals = kIdCh * 9 + 1;      // + the bias sum
+constexpr int kIdRow = 256 + 16;            // padded LDS row (conflict-free 16-lane strided reads)
+constexpr int kIdPass = 16;
+
+__global__ void __launch_bounds__(256) invdepth_conv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ dz, float* __restrict__ dx,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int C, int H, int W, int ppt) {
+  __shared__ float red[kIdPass * kIdRow];
+  const int tid = threadIdx.x;
+  const int HW = H * W;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * kIdCh;
+  const pnsfm_buf zb = pnsfm_make_buf(dz + (size_t)b * HW, (unsigned)HW * 4u);
+  const unsigned kOut = 0x7fffffffu;
+  float acc[kIdCh][9], bsum = 0.f;
+#pragma unroll
+  for (int c = 0; c < kIdCh; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  const bool want_db = blockIdx.y == 0;
+  for (int it = 0; it < ppt; ++it) {
+    const int q = (blockIdx.x * ppt + it) * 256 + tid;
+    const bool active = q < HW;
+    const int qy = active ? q / W : 0, qx = active ? q - qy * W : 0;
+    float D[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = qy - ky + 1, xx = qx - kx + 1;
+        const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        D[ky * 3 + kx] = pnsfm_buf_load(zb, ok ? (unsigned)(yy * W + xx) * 4u : kOut, 0u);
+      }
+    if (want_db) bsum += D[4];               // tap (1,1) is dz[q] itself
+    const unsigned qoff = active ? (unsigned)q * 4u : kOut;
+#pragma unroll
+    for (int c = 0; c < kIdCh; ++c) {
+      const int ch = c0 + c;                 // wave-uniform
+      if (ch < C) {
+        const pnsfm_buf xb = pnsfm_make_buf(x + ((size_t)b * C + ch) * HW, (unsigned)HW * 4u);
+        const float xv = pnsfm_buf_load(xb, qoff, 0u);
+        const float* wc = w + ch * 9;
+        float g = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          g = fmaf(wc[t], D[t], g);
+          acc[c][t] = fmaf(xv, D[t], acc[c][t]);
+        }
+        if (active) dx[((size_t)b * C + ch) * HW + q] = g;
+      }
+    }
+  }
+  // ---- block reduction of the 73 partials, kIdPass values per pass (same scheme as conv3d_wgrad_kernel)
+  const int rv = tid >> 4, rj = tid & 15;
+  constexpr int npass = (kIdVals + kIdPass - 1) / kIdPass;
+#pragma unroll
+  for (int pass = 0; pass < npass; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kIdPass; ++u) {
+      const int v = pass * kIdPass + u;
+      float val = 0.f;
+      if (v < kIdCh * 9) val = acc[v / 9][v % 9];
+      else if (v == kIdCh * 9) val = bsum;
+      red[u * kIdRow + tid] = val;
+    }
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[rv * kIdRow + rj + 16 * i];
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    if (rj == 0) {
+      const int v = pass * kIdPass + rv;
+      if (v < kIdCh * 9) {
+        const int ch = c0 + v / 9;
+        if (ch < C) atomicAdd(&dw[ch * 9 + v % 9], s);
+      } else if (v == kIdCh * 9 && want_db) {
+        atomicAdd(db, s);
+      }
+    }
+  }
+}
+
+}  // namespace pnsfm
+
+using namespace pnsfm;
+
+extern "C" {
+
+int pnsfm_invdepth_conv_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W,
+                                float min_depth, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("invdepth_conv_forward: bad shape"); return -1; }
+  if (min_depth <= 0.f) { set_error("invdepth_conv_forward: min_depth must be > 0"); return -1; }
+  if ((size_t)H * W * 4 >= 0x7fffffffull) { set_error("invdepth_conv_forward: plane exceeds the 2 GiB buffer window"); return -1; }
+  PNSFM_LAUNCH(invdepth_conv_fwd_kernel, dim3(ceil_div(H * W, 64), 1, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+               C, H, W, 1.0f / min_depth);
+  return check_launch("invdepth_conv_forward");
+}
+
+int pnsfm_invdepth_conv_backward(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int B,
+                                 int C, int H, int W, void* stream) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("invdepth_conv_backward: bad shape"); return -1; }
+  if ((size_t)H * W * 4 >= 0x7fffffffull) { set_error("invdepth_conv_backward: plane exceeds the 2 GiB buffer window"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  // dw [C*9] and db [1]: one fill when db sits right behind dw (the Python wrapper allocates them together)
+  const bool joined = db == dw + (size_t)C * 9;
+  int e = (int)hipMemsetAsync(dw, 0, ((size_t)C * 9 + (joined ? 1 : 0)) * sizeof(float), s);
+  if (!e && !joined) e = (int)hipMemsetAsync(db, 0, sizeof(float), s);
+  if (e) { set_error("invdepth_conv_backward: memset failed"); return e; }
+  // pixels per thread: up to 16 (amortises the 73-value block reduction) while the grid keeps >= ~2 blocks per CU
+  const int HW = H * W, cgroups = ceil_div(C, kIdCh);
+  int ppt = 16;
+  while (ppt > 1 && (long)ceil_div(HW, 256 * ppt) * cgroups * B < 512) ppt >>= 1;
+  PNSFM_LAUNCH(invdepth_conv_bwd_kernel, dim3(ceil_div(HW, 256 * ppt), cgroups, B), dim3(256), 0, s, x, w, dz, dx, dw, db, C,
+               H, W, ppt);
+  return check_launch("invdepth_conv_backward");
+}
+
+}  // extern "C"

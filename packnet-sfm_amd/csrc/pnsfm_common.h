@@ -15,6 +15,7 @@ typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
 // LDS-DMA: lane l of the wave copies 4 bytes from its own global address to lds_wave_base[l] (emulated synchronously)
 static inline void pnsfm_glds4(const float* src, float* lds_wave_base) { lds_wave_base[hipemu::my_lane()] = *src; }
+#define PNSFM_UNIFORM(i) (i)
 // buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
 struct pnsfm_buf { const char* base; unsigned bytes; };
 static inline pnsfm_buf pnsfm_make_buf(const void* base, unsigned bytes) { return pnsfm_buf{(const char*)base, bytes}; }
@@ -40,6 +41,8 @@ __device__ __forceinline__ void pnsfm_glds4(const float* src, float* lds_wave_ba
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
+// tell the compiler a value is wave-uniform (moves it to an SGPR)
+#define PNSFM_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
 // Raw buffer loads (buffer_load_dword v, v_off, s[rsrc], s_off offen): the address is base + s_off + v_off with a
 // wave-uniform base and s_off, so a stencil's 72 neighbour loads need 9 offset VGPRs instead of 72 64-bit pointers, and
 // the hardware range check (v_off + 4 > num_records -> returns 0, no memory access) implements zero padding: invalid

@@ -40,6 +40,8 @@ SIGNATURES = {
     "pnsfm_conv3d_1to8_backward_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_invdepth_act_forward": (_i, [_p, _p, _sz, _f, _p]),
     "pnsfm_invdepth_act_backward": (_i, [_p, _p, _p, _sz, _f, _p]),
+    "pnsfm_invdepth_conv_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "pnsfm_invdepth_conv_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_photometric_forward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),

@@ -262,6 +262,31 @@ def invdepth_act(x, min_depth):
     return InvDepthActFn.apply(x, min_depth)
 
 
+class InvDepthConvFn(Function):
+    """y = sigmoid(conv3x3(zero_pad1(x), w) + b) / min_depth with ONE output channel (the InvDepth head), fused."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, min_depth):
+        x = x.contiguous()
+        w = weight.detach().contiguous()
+        y = ops.invdepth_conv_forward(x, w, bias.detach(), min_depth)
+        ctx.save_for_backward(x, w, y)
+        ctx.min_depth = min_depth
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dz = ops.invdepth_act_backward(dy.contiguous(), y, ctx.min_depth)
+        dx, dw, db = ops.invdepth_conv_backward(x, w, dz)
+        return dx, dw, db, None
+
+
+def invdepth_conv(x, weight, bias, min_depth):
+    return InvDepthConvFn.apply(x, weight, bias, min_depth)
+
+
 class ViewSynthesisFn(Function):
     """warped[j] = grid_sample(ref[j], project(reconstruct(1/inv_depth))) for the J context views of one scale.
     Differentiable w.r.t. inv_depth and the [J,B,4,4] pose matrices (the context image is data)."""

@@ -80,12 +80,18 @@ def conv2d_backward_data(dy, wp_bwd, Cin, ks):
     return dx
 
 
+def _alloc_dw_db(Cout, Cin, ks, want_bias, device):
+    """dw and dbias in one allocation (dbias right behind dw): a split-K weight gradient zero-fills both with one memset."""
+    n = Cout * Cin * ks * ks
+    buf = torch.empty((n + (Cout if want_bias else 0),), dtype=torch.float32, device=device)
+    return buf[:n].view(Cout, Cin, ks, ks), (buf[n:] if want_bias else None)
+
+
 def conv2d_backward_weight(x, dy, ks, want_bias=True):
     _chk(x, dy); _f32(x, dy)
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw, db = _alloc_dw_db(Cout, Cin, ks, want_bias, x.device)
     rc = _lib.get().pnsfm_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, ks, _stream(x))
     _lib.check(rc, "conv2d_backward_weight")
     return dw, db
@@ -107,8 +113,7 @@ def conv2d_backward_weight_strided(x, dy, ks, stride, want_bias=True):
     _chk(x, dy); _f32(x, dy)
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=x.device)
-    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dw, db = _alloc_dw_db(Cout, Cin, ks, want_bias, x.device)
     rc = _lib.get().pnsfm_conv2d_backward_weight_strided(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, ks, stride,
                                                          _stream(x))
     _lib.check(rc, "conv2d_backward_weight_strided")
@@ -212,6 +217,30 @@ def invdepth_act_backward(dy, y, min_depth):
     _lib.check(_lib.get().pnsfm_invdepth_act_backward(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), float(min_depth), _stream(y)),
                "invdepth_act_backward")
     return dx
+
+
+def invdepth_conv_forward(x, w, bias, min_depth):
+    """x [B,C,H,W], w [1,C,3,3], bias [1] -> sigmoid(conv3x3(x) + b) / min_depth, [B,1,H,W]."""
+    _chk(x, w, bias); _f32(x, w, bias)
+    B, C, H, W = x.shape
+    if tuple(w.shape) != (1, C, 3, 3) or bias is None or bias.numel() != 1:
+        raise RuntimeError("invdepth_conv: weight must be [1,%d,3,3] with a bias of one element" % C)
+    y = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.get().pnsfm_invdepth_conv_forward(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, C, H, W, float(min_depth),
+                                                      _stream(x)), "invdepth_conv_forward")
+    return y
+
+
+def invdepth_conv_backward(x, w, dz):
+    """dz [B,1,H,W] = gradient at the conv output -> (dx [B,C,H,W], dw [1,C,3,3], db [1])."""
+    _chk(x, w, dz); _f32(x, w, dz)
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    buf = torch.empty((C * 9 + 1,), dtype=torch.float32, device=x.device)      # db right behind dw: one fill
+    dw, db = buf[:C * 9].view(1, C, 3, 3), buf[C * 9:]
+    _lib.check(_lib.get().pnsfm_invdepth_conv_backward(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), B, C, H, W,
+                                                       _stream(x)), "invdepth_conv_backward")
+    return dx, dw, db
 
 
 # ---------------------------------------------------------------------------------------------- loss

@@ -10,13 +10,13 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "packnet-sfm_amd", "csrc"))
-SOURCES = ["api.hip", "conv2d.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "loss.hip"]
+SOURCES = ["api.hip", "conv2d.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "invdepth.hip", "loss.hip"]
 LIB = os.path.join(HERE, "libpnsfm_emu.so")
 
 
 def build_emu(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "pnsfm_common.h"), os.path.join(HERE, "hipemu.h"),
+    deps = srcs + [os.path.abspath(__file__), os.path.join(CSRC, "pnsfm_common.h"), os.path.join(HERE, "hipemu.h"),
                    os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB

@@ -111,6 +111,29 @@ def test_conv3d_raw(emulated_kernels, shape):
     P.check(bd.grad, br.grad, 1e-5, 'conv3d dbias')
 
 
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (1, 19, 4, 70), (1, 64, 3, 5)])
+def test_invdepth_conv_raw(emulated_kernels, shape):
+    """Fused InvDepth head (one output channel): ragged channel quarters / channel groups, pixel tails, vs torch."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import functional as HF
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = 0.2 * torch.randn(1, C, 3, 3, generator=g)
+    b = torch.randn(1, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    xd, wd, bd = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.sigmoid(F.conv2d(xr, wr, br, padding=1)) / 0.5
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    y = HF.invdepth_conv(xd, wd, bd, 0.5)
+    y.backward(dy)
+    P.check(y, yr, 1e-5, 'invdepth fwd')
+    P.check(xd.grad, xr.grad, 1e-5, 'invdepth dx')
+    P.check(wd.grad, wr.grad, 1e-5, 'invdepth dw')
+    P.check(bd.grad, br.grad, 1e-5, 'invdepth db')
+
+
 def test_adam_matches_torch(emulated_kernels):
     from packnet_sfm.hip import ops
     g = torch.Generator().manual_seed(3)

@@ -90,6 +90,9 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
  * depth_to_space == nn.PixelShuffle(2) layers01.py:275,285:  x:[B,4C,H,W] -> y:[B,C,2H,2W]
  * Each is the other's backward. */
 int pnsfm_space_to_depth(const float* x, float* y, int B, int C, int H, int W, void* stream);
+/* same, for an x that is a channel slice of a wider tensor (image b starts at x + b*x_batch_stride floats): the
+ * gradient that reaches PixelShuffle's backward through torch.cat((unpack, skip), 1) (PackNet01.py:140-172) */
+int pnsfm_space_to_depth_strided(const float* x, float* y, int B, int C, int H, int W, size_t x_batch_stride, void* stream);
 int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, void* stream);
 
 /* ---- Conv3d(1 -> 8, 3x3x3, padding 1) over the (channel, y, x) volume ----------------------
@@ -118,6 +121,12 @@ int pnsfm_invdepth_conv_forward(const float* x, const float* w, const float* bia
                                 float min_depth, void* stream);
 int pnsfm_invdepth_conv_backward(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int B,
                                  int C, int H, int W, void* stream);
+
+/* ---- pose vector -> rigid transform: vec:[N,6] = (tx,ty,tz,rx,ry,rz) -> mat:[N,4,4], R = Rx*Ry*Rz, bottom row 0 0 0 1
+ * replaces Pose.from_vec(vec, 'euler') (geometry/pose.py:40-46) = pose_vec2mat + euler2mat (geometry/pose_utils.py:8-52).
+ * backward: dmat:[N,4,4] -> dvec:[N,6]. */
+int pnsfm_pose_vec2mat_forward(const float* vec, float* mat, int N, void* stream);
+int pnsfm_pose_vec2mat_backward(const float* vec, const float* dmat, float* dvec, int N, void* stream);
 
 /* ---- view synthesis: inv2depth -> Camera.reconstruct -> Camera.project -> grid_sample ------
  * replaces MultiViewPhotometricLoss.warp_ref_image for ONE scale and J context images:

@@ -1,6 +1,10 @@
 // elementwise.hip -- InvDepth activation and the flat Adam update (pure HBM streaming kernels).
 //
 //  invdepth_act : y = sigmoid(x) / min_depth      /root/reference/packnet_sfm/networks/layers/packnet/layers01.py:119-122
+//  pose_vec2mat : [tx,ty,tz,rx,ry,rz] -> 4x4 rigid transform, R = Rx*Ry*Rz (euler)
+//                 /root/reference/packnet_sfm/geometry/pose_utils.py:8-52 (euler2mat, pose_vec2mat) and
+//                 /root/reference/packnet_sfm/geometry/pose.py:40-46 (Pose.from_vec); ~85 tiny ATen launches
+//                 (slices, sin/cos, stacks, bmm, cat + their backward) become one launch each way.
 //  adam_step    : torch.optim.Adam (amsgrad=False) on one flat parameter group, as configured by
 //                 /root/reference/packnet_sfm/models/model_wrapper.py:128-149 and stepped at
 //                 /root/reference/packnet_sfm/trainers/horovod_trainer.py:93 (28 B/parameter of HBM traffic).
@@ -22,6 +26,63 @@ __global__ void __launch_bounds__(256) invdepth_bwd_kernel(const float* __restri
     const float yy = y[i];
     dx[i] = dy[i] * yy * (1.f - yy * min_depth);
   }
+}
+
+// R = Rx(rx) * Ry(ry) * Rz(rz):
+//   row0 = [ cy cz,            -cy sz,             sy    ]
+//   row1 = [ cx sz + sx sy cz,  cx cz - sx sy sz, -sx cy ]
+//   row2 = [ sx sz - cx sy cz,  sx cz + cx sy sz,  cx cy ]
+__device__ __forceinline__ void euler_rows(float rx, float ry, float rz, float* R) {
+  const float sx = sinf(rx), cx = cosf(rx), sy = sinf(ry), cy = cosf(ry), sz = sinf(rz), cz = cosf(rz);
+  R[0] = cy * cz;                 R[1] = -cy * sz;                R[2] = sy;
+  R[3] = cx * sz + sx * sy * cz;  R[4] = cx * cz - sx * sy * sz;  R[5] = -sx * cy;
+  R[6] = sx * sz - cx * sy * cz;  R[7] = sx * cz + cx * sy * sz;  R[8] = cx * cy;
+}
+
+__global__ void __launch_bounds__(64) pose_vec2mat_fwd_kernel(const float* __restrict__ vec, float* __restrict__ mat, int N) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  const float* v = vec + n * 6;
+  float R[9];
+  euler_rows(v[3], v[4], v[5], R);
+  float* m = mat + n * 16;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    m[i * 4 + 0] = R[i * 3 + 0];
+    m[i * 4 + 1] = R[i * 3 + 1];
+    m[i * 4 + 2] = R[i * 3 + 2];
+    m[i * 4 + 3] = v[i];
+  }
+  m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+}
+
+// dR/drx: row1 -> -row2, row2 -> row1 (row0 -> 0);  dR/drz: col0 -> col1, col1 -> -col0 (col2 -> 0);
+// dR/dry = Rx * N with N = dRy/dry * Rz = [[-sy cz, sy sz, cy], [0,0,0], [-cy cz, cy sz, -sy]]: rows N0, -sx N2, cx N2.
+__global__ void __launch_bounds__(64) pose_vec2mat_bwd_kernel(const float* __restrict__ vec, const float* __restrict__ dmat,
+                                                               float* __restrict__ dvec, int N) {
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  const float* v = vec + n * 6;
+  const float* g = dmat + n * 16;
+  float R[9];
+  euler_rows(v[3], v[4], v[5], R);
+  const float sx = sinf(v[3]), cx = cosf(v[3]), sy = sinf(v[4]), cy = cosf(v[4]), sz = sinf(v[5]), cz = cosf(v[5]);
+  float G[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) G[i * 3 + j] = g[i * 4 + j];
+  float drx = 0.f, dry = 0.f, drz = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) drx += -G[3 + j] * R[6 + j] + G[6 + j] * R[3 + j];
+  const float N0[3] = {-sy * cz, sy * sz, cy}, N2[3] = {-cy * cz, cy * sz, -sy};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dry += G[j] * N0[j] + G[3 + j] * (-sx * N2[j]) + G[6 + j] * (cx * N2[j]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) drz += G[i * 3 + 0] * R[i * 3 + 1] - G[i * 3 + 1] * R[i * 3 + 0];
+  float* d = dvec + n * 6;
+  d[0] = g[3]; d[1] = g[7]; d[2] = g[11];
+  d[3] = drx; d[4] = dry; d[5] = drz;
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -63,6 +124,18 @@ int pnsfm_invdepth_act_forward(const float* x, float* y, size_t n, float min_dep
 int pnsfm_invdepth_act_backward(const float* dy, const float* y, float* dx, size_t n, float min_depth, void* stream) {
   PNSFM_LAUNCH(invdepth_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, min_depth);
   return check_launch("invdepth_act_backward");
+}
+
+int pnsfm_pose_vec2mat_forward(const float* vec, float* mat, int N, void* stream) {
+  if (N <= 0) { set_error("pose_vec2mat: bad N"); return -1; }
+  PNSFM_LAUNCH(pose_vec2mat_fwd_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, vec, mat, N);
+  return check_launch("pose_vec2mat_forward");
+}
+
+int pnsfm_pose_vec2mat_backward(const float* vec, const float* dmat, float* dvec, int N, void* stream) {
+  if (N <= 0) { set_error("pose_vec2mat: bad N"); return -1; }
+  PNSFM_LAUNCH(pose_vec2mat_bwd_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, vec, dmat, dvec, N);
+  return check_launch("pose_vec2mat_backward");
 }
 
 int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,

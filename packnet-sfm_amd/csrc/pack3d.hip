@@ -17,7 +17,7 @@ __device__ __attribute__((aligned(16))) float pnsfm_zero_page3[64];
 
 // y[b][4c+2i+j][h][w] = x[b][c][2h+i][2w+j]; one thread per input 2x2 quad column pair
 __global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                   int C, int H, int W, size_t total) {
+                                                   int C, int H, int W, size_t total, size_t x_batch_stride) {
   // thread per OUTPUT element, w fastest (coalesced writes; reads are stride-2 but both parities are
   // consumed by neighbouring output channels of the same block row, i.e. served from L1/L2)
   const int h2 = H >> 1, w2 = W >> 1;
@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ x, f
     const int oc = (int)(r % (4 * C));
     const int b = (int)(r / (4 * C));
     const int c = oc >> 2, i = (oc >> 1) & 1, j = oc & 1;
-    y[idx] = x[(((size_t)b * C + c) * H + 2 * h + i) * W + 2 * w + j];
+    y[idx] = x[(size_t)b * x_batch_stride + ((size_t)c * H + 2 * h + i) * W + 2 * w + j];
   }
 }
 
@@ -287,11 +287,16 @@ using namespace pnsfm;
 
 extern "C" {
 
-int pnsfm_space_to_depth(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+int pnsfm_space_to_depth_strided(const float* x, float* y, int B, int C, int H, int W, size_t x_batch_stride, void* stream) {
   if ((H & 1) || (W & 1)) { set_error("space_to_depth: H, W must be even (got %d x %d)", H, W); return -1; }
+  if (x_batch_stride < (size_t)C * H * W) { set_error("space_to_depth: batch stride smaller than one image"); return -1; }
   const size_t total = (size_t)B * C * H * W;
-  PNSFM_LAUNCH(s2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total);
+  PNSFM_LAUNCH(s2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total, x_batch_stride);
   return check_launch("space_to_depth");
+}
+
+int pnsfm_space_to_depth(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+  return pnsfm_space_to_depth_strided(x, y, B, C, H, W, (size_t)C * H * W, stream);
 }
 
 int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, void* stream) {

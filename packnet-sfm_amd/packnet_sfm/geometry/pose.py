@@ -22,6 +22,9 @@ class Pose:
     @classmethod
     def from_vec(cls, vec, mode):
         """[B,6] pose vector -> Pose (bottom row [0,0,0,1])."""
+        if mode == 'euler' and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[1] == 6:
+            from packnet_sfm.hip import functional as HF      # one launch each way instead of ~85 tiny ATen kernels
+            return cls(HF.pose_vec2mat44(vec))
         top = pose_vec2mat(vec, mode)
         bottom = torch.zeros((len(vec), 1, 4), device=vec.device, dtype=vec.dtype)
         bottom[:, 0, 3] = 1.0

@@ -34,12 +34,15 @@ SIGNATURES = {
     "pnsfm_groupnorm_act_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_space_to_depth": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_space_to_depth_strided": (_i, [_p, _p, _i, _i, _i, _i, _sz, _p]),
     "pnsfm_depth_to_space": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_conv3d_1to8_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_conv3d_1to8_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_conv3d_1to8_backward_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_invdepth_act_forward": (_i, [_p, _p, _sz, _f, _p]),
     "pnsfm_invdepth_act_backward": (_i, [_p, _p, _p, _sz, _f, _p]),
+    "pnsfm_pose_vec2mat_forward": (_i, [_p, _p, _i, _p]),
+    "pnsfm_pose_vec2mat_backward": (_i, [_p, _p, _p, _i, _p]),
     "pnsfm_invdepth_conv_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "pnsfm_invdepth_conv_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -155,7 +155,7 @@ def groupnorm_act(x, gamma, beta, G=16, eps=1e-5, act=ops.ACT_ELU, res=None):
 class SpaceToDepthFn(Function):
     @staticmethod
     def forward(ctx, x):
-        return ops.space_to_depth(x.contiguous())
+        return ops.space_to_depth(x)
 
     @staticmethod
     @once_differentiable
@@ -171,7 +171,7 @@ class DepthToSpaceFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        return ops.space_to_depth(dy.contiguous())
+        return ops.space_to_depth(dy)       # dy is often a channel slice (cat backward): handled without a copy
 
 
 def space_to_depth(x):
@@ -243,6 +243,115 @@ def compose_pack_weight(W2, W3):
     return ComposePackWeightFn.apply(W2, W3)
 
 
+class PackBorderSplitFn(Function):
+    """Collapsed packing block, input side: P -> (P itself for the interior convolution, the top+bottom row strips,
+    the left+right column strips; strips batched along dim 0).  Plain slicing would make autograd zero-fill and add a
+    full-size dP four times (slice_backward); here the strip gradients are added straight into the interior path's dP."""
+
+    @staticmethod
+    def forward(ctx, P, S):
+        h, w = P.shape[2], P.shape[3]
+        ctx.S = S
+        tb = torch.cat((P[:, :, :S], P[:, :, h - S:]), 0)
+        lr = torch.cat((P[:, :, :, :S], P[:, :, :, w - S:]), 0)
+        return P.view_as(P), tb, lr
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dP, d_tb, d_lr):
+        S = ctx.S
+        if dP is None:
+            raise RuntimeError('pack_border_split: the interior path must be used')
+        dP = dP.contiguous()        # the interior conv's freshly written backward-data buffer: accumulate in place
+        B, h, w = dP.shape[0], dP.shape[2], dP.shape[3]
+        if d_tb is not None:
+            dP[:, :, :S] += d_tb[:B]
+            dP[:, :, h - S:] += d_tb[B:]
+        if d_lr is not None:
+            dP[:, :, :, :S] += d_lr[:B]
+            dP[:, :, :, w - S:] += d_lr[B:]
+        return dP, None
+
+
+def pack_border_split(P, S):
+    return PackBorderSplitFn.apply(P, S)
+
+
+class StripSelectFn(Function):
+    """z: [2B, C, S, w] (dim=2) or [2B, C, h, S] (dim=3), the Conv3d of the batched strips.  Keeps the 2r rows/cols whose
+    Conv3d neighbourhood lies inside the strip: the first 2r of the leading half, the last 2r of the trailing half.
+    Backward writes every element of dz exactly once (no zero-fill + copy)."""
+
+    @staticmethod
+    def forward(ctx, z, B, r, dim):
+        ctx.meta = (B, r, dim, tuple(z.shape))
+        if dim == 2:
+            return torch.cat((z[:B, :, :2 * r], z[B:, :, 1:]), 0)
+        return torch.cat((z[:B, :, :, :2 * r], z[B:, :, :, 1:]), 0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, r, dim, shape = ctx.meta
+        dz = g.new_empty(shape)
+        if dim == 2:
+            dz[:B, :, :2 * r] = g[:B]
+            dz[:B, :, 2 * r:] = 0
+            dz[B:, :, 1:] = g[B:]
+            dz[B:, :, :1] = 0
+        else:
+            dz[:B, :, :, :2 * r] = g[:B]
+            dz[:B, :, :, 2 * r:] = 0
+            dz[B:, :, :, 1:] = g[B:]
+            dz[B:, :, :, :1] = 0
+        return dz, None, None, None
+
+
+def strip_select(z, B, r, dim):
+    return StripSelectFn.apply(z, B, r, dim)
+
+
+class PackBorderPasteFn(Function):
+    """Collapsed packing block, output side: overwrite the r-pixel frame of the interior result y (in place: y is the
+    interior conv's own output buffer) with the strip results o_tb [2B,C,2r,w] / o_lr [2B,C,h,2r] (only their outer r
+    rows / columns are valid).  Replaces two torch.cat copies forward and a zero-fill + copy backward."""
+
+    @staticmethod
+    def forward(ctx, y, o_tb, o_lr, r):
+        B, h, w = y.shape[0], y.shape[2], y.shape[3]
+        ctx.r = r
+        y[:, :, r:h - r, :r] = o_lr[:B, :, r:h - r, :r]
+        y[:, :, r:h - r, w - r:] = o_lr[B:, :, r:h - r, r:]
+        y[:, :, :r] = o_tb[:B, :, :r]
+        y[:, :, h - r:] = o_tb[B:, :, r:]
+        ctx.mark_dirty(y)
+        ctx.shapes = (tuple(o_tb.shape), tuple(o_lr.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        r = ctx.r
+        B, h, w = g.shape[0], g.shape[2], g.shape[3]
+        s_tb, s_lr = ctx.shapes
+        d_tb = g.new_zeros(s_tb)
+        d_lr = g.new_zeros(s_lr)
+        d_tb[:B, :, :r] = g[:, :, :r]
+        d_tb[B:, :, r:] = g[:, :, h - r:]
+        d_lr[:B, :, r:h - r, :r] = g[:, :, r:h - r, :r]
+        d_lr[B:, :, r:h - r, r:] = g[:, :, r:h - r, w - r:]
+        dy = g.clone()
+        dy[:, :, :r] = 0
+        dy[:, :, h - r:] = 0
+        dy[:, :, :, :r] = 0
+        dy[:, :, :, w - r:] = 0
+        return dy, d_tb, d_lr, None
+
+
+def pack_border_paste(y, o_tb, o_lr, r):
+    return PackBorderPasteFn.apply(y, o_tb, o_lr, r)
+
+
 class InvDepthActFn(Function):
     @staticmethod
     def forward(ctx, x, min_depth):
@@ -285,6 +394,26 @@ class InvDepthConvFn(Function):
 
 def invdepth_conv(x, weight, bias, min_depth):
     return InvDepthConvFn.apply(x, weight, bias, min_depth)
+
+
+class PoseVec2MatFn(Function):
+    """[N,6] (tx,ty,tz,rx,ry,rz) -> [N,4,4] rigid transforms, R = Rx*Ry*Rz (euler)."""
+
+    @staticmethod
+    def forward(ctx, vec):
+        vec = vec.contiguous()
+        ctx.save_for_backward(vec)
+        return ops.pose_vec2mat_forward(vec)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dmat):
+        (vec,) = ctx.saved_tensors
+        return ops.pose_vec2mat_backward(vec, dmat.contiguous())
+
+
+def pose_vec2mat44(vec):
+    return PoseVec2MatFn.apply(vec)
 
 
 class ViewSynthesisFn(Function):

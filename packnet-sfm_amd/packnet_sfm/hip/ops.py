@@ -154,11 +154,23 @@ def groupnorm_act_backward(dy, x, res, gamma, beta, mean, rstd, G, act):
 
 
 # ------------------------------------------------------------------------------------ packing / conv3d
-def space_to_depth(x):
-    _chk(x); _f32(x)
+def _is_channel_slice(x):
+    """[B,C,H,W] whose images are dense but B-strided (a channel slice of a wider contiguous tensor)."""
     B, C, H, W = x.shape
-    y = torch.empty((B, 4 * C, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.get().pnsfm_space_to_depth(_ptr(x), _ptr(y), B, C, H, W, _stream(x)), "space_to_depth")
+    st = x.stride()
+    return st[3] == 1 and st[2] == W and st[1] == H * W and st[0] >= C * H * W
+
+
+def space_to_depth(x):
+    """x may be contiguous or a channel slice of a wider contiguous NCHW tensor (no copy in either case)."""
+    B, C, H, W = x.shape
+    if x.is_contiguous() or not _is_channel_slice(x):
+        x = x.contiguous()
+    _chk(y := torch.empty((B, 4 * C, H // 2, W // 2), dtype=torch.float32, device=x.device)); _f32(x)
+    if _lib.REQUIRE_CUDA and not x.is_cuda:
+        raise RuntimeError("packnet_sfm HIP op got a %s tensor: the HIP kernels run on MI355X only" % x.device)
+    _lib.check(_lib.get().pnsfm_space_to_depth_strided(_ptr(x), _ptr(y), B, C, H, W, x.stride(0) if B > 1 else C * H * W,
+                                                       _stream(x)), "space_to_depth")
     return y
 
 
@@ -241,6 +253,23 @@ def invdepth_conv_backward(x, w, dz):
     _lib.check(_lib.get().pnsfm_invdepth_conv_backward(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), _ptr(db), B, C, H, W,
                                                        _stream(x)), "invdepth_conv_backward")
     return dx, dw, db
+
+
+def pose_vec2mat_forward(vec):
+    _chk(vec); _f32(vec)
+    N = vec.shape[0]
+    mat = torch.empty((N, 4, 4), dtype=torch.float32, device=vec.device)
+    _lib.check(_lib.get().pnsfm_pose_vec2mat_forward(_ptr(vec), _ptr(mat), N, _stream(vec)), "pose_vec2mat_forward")
+    return mat
+
+
+def pose_vec2mat_backward(vec, dmat):
+    _chk(vec, dmat); _f32(vec, dmat)
+    N = vec.shape[0]
+    dvec = torch.empty((N, 6), dtype=torch.float32, device=vec.device)
+    _lib.check(_lib.get().pnsfm_pose_vec2mat_backward(_ptr(vec), _ptr(dmat), _ptr(dvec), N, _stream(vec)),
+               "pose_vec2mat_backward")
+    return dvec
 
 
 # ---------------------------------------------------------------------------------------------- loss

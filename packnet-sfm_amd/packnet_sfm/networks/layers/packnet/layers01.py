@@ -179,21 +179,14 @@ class PackLayerConv3d(nn.Module):
         # interior: one (k+2)x(k+2) conv with the composed kernel; its bias is b2 + sum over ALL taps of W2 * b3
         W_eff = HF.compose_pack_weight(W2, W3)
         bias_eff = b2 + (W2.reshape(C, 8, -1).sum(2) * b3.view(1, 8)).sum(1)
-        y = HF.conv2d(P, W_eff, bias_eff, self._eff_packed)
         # border frame (r pixels): original formula on strips of 2r+1 packed rows / columns (top+bottom and left+right
-        # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept
-        tb = torch.cat((P[:, :, :S], P[:, :, h - S:]), 0).contiguous()
-        z = HF.conv3d_1to8(tb, W3, b3)
-        z = torch.cat((z[:B, :, :2 * r], z[B:, :, 1:]), 0)
-        o = base(z)
-        top, bot = o[:B, :, :r], o[B:, :, r:]
-        lr = torch.cat((P[:, :, :, :S], P[:, :, :, w - S:]), 0).contiguous()
-        z = HF.conv3d_1to8(lr, W3, b3)
-        z = torch.cat((z[:B, :, :, :2 * r], z[B:, :, :, 1:]), 0)
-        o = base(z)
-        left, right = o[:B, :, r:h - r, :r], o[B:, :, r:h - r, r:]
-        mid = torch.cat((left, y[:, :, r:h - r, r:w - r], right), 3)
-        return torch.cat((top, mid, bot), 2)
+        # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept.  The three
+        # helper Functions do the strip gather / select / paste without full-size zero-fills and adds in backward.
+        P_main, tb, lr = HF.pack_border_split(P, S)
+        y = HF.conv2d(P_main, W_eff, bias_eff, self._eff_packed)
+        o_tb = base(HF.strip_select(HF.conv3d_1to8(tb, W3, b3), B, r, 2))        # [2B, C, 2r, w]
+        o_lr = base(HF.strip_select(HF.conv3d_1to8(lr, W3, b3), B, r, 3))        # [2B, C, h, 2r]
+        return HF.pack_border_paste(y, o_tb, o_lr, r)
 
     def forward(self, x):
         P = HF.space_to_depth(x)

@@ -21,6 +21,19 @@ def test_packing_invdepth(emulated_kernels):
     P.case_invdepth('cpu')
 
 
+def test_space_to_depth_channel_slice(emulated_kernels):
+    """space_to_depth on a channel slice of a wider tensor (what torch.cat's backward hands to PixelShuffle's backward)."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import ops
+    wide = torch.randn(3, 7, 4, 6, generator=torch.Generator().manual_seed(2))
+    sl = wide[:, 2:5]
+    assert not sl.is_contiguous()
+    assert torch.equal(ops.space_to_depth(sl), F.pixel_unshuffle(sl, 2))
+    assert torch.equal(ops.space_to_depth(wide), F.pixel_unshuffle(wide, 2))
+    tr = wide.transpose(2, 3)                       # not a channel slice: falls back to a contiguous copy
+    assert torch.equal(ops.space_to_depth(tr), F.pixel_unshuffle(tr, 2))
+
+
 def test_unpack(emulated_kernels):
     P.case_unpack('cpu')
 
@@ -132,6 +145,22 @@ def test_invdepth_conv_raw(emulated_kernels, shape):
     P.check(xd.grad, xr.grad, 1e-5, 'invdepth dx')
     P.check(wd.grad, wr.grad, 1e-5, 'invdepth dw')
     P.check(bd.grad, br.grad, 1e-5, 'invdepth db')
+
+
+def test_pose_vec2mat(emulated_kernels):
+    """Pose.from_vec on the fused kernel vs the oracle's euler2mat composition (forward and gradient)."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.geometry.pose import Pose
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn(5, 6, generator=g)
+    a, b = v.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    T = Pose.from_vec(a, 'euler').mat
+    Tr = O.pose_vec2mat44(b)
+    P.check(T, Tr, 1e-6, 'pose matrix')
+    go = torch.randn(5, 4, 4, generator=g)
+    T.backward(go)
+    Tr.backward(go)
+    P.check(a.grad, b.grad, 1e-5, 'd pose vector')
 
 
 def test_adam_matches_torch(emulated_kernels):

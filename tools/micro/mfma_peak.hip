@@ -1,6 +1,7 @@
 // Calibration microbenchmark: what does v_mfma_f32_32x32x2_f32 sustain on this chip (a) alone, (b) fed by LDS reads
 // in the pattern of conv2d_mfma_kernel (per k-step: MT A-reads + NT B-reads, MT*NT MFMAs), at various occupancies?
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,7 +66,31 @@ void run(const char* name, int blocks_per_cu, size_t smem) {
   hipFree(out);
 }
 
-int main() {
+// sustained mode: back-to-back launches of the register-only MFMA loop for `seconds`, TFLOP/s per 0.25 s window
+// (does the clock hold under a sustained fp32-MFMA load, or does power management pull it down?)
+static void sustained(double seconds) {
+  float* out;
+  const int grid = 256 * 2, iters = 4096;
+  hipMalloc(&out, (size_t)grid * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const double flops = (double)grid * 4 * iters * 4.0 * 2 * 2 * (2.0 * 32 * 32 * 2);
+  double t = 0;
+  while (t < seconds) {
+    hipEventRecord(e0, 0);
+    int n = 0;
+    for (; n < 40; ++n) hipLaunchKernelGGL((k_mfma<2, 2, 0>), dim3(grid), dim3(256), 40000, 0, out, iters, 10000);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    t += ms * 1e-3;
+    printf("t=%5.2fs  %7.1f TFLOP/s\n", t, n * flops / ms * 1e-9);
+  }
+  hipFree(out);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) { sustained(atof(argv[1])); return 0; }
   for (int b : {1, 2, 3, 4}) run<2, 2, 0>("regs only  MT2 NT2", b, 40000);
   for (int b : {1, 2, 3, 4}) run<2, 2, 1>("LDS-fed    MT2 NT2", b, 40000);
   for (int b : {1, 2, 4, 6}) run<2, 1, 1>("LDS-fed    MT2 NT1", b, 24000);

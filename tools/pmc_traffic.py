@@ -10,6 +10,7 @@ import re
 import sys
 
 fetch_csv, write_csv, out = sys.argv[1:4]
+layer_csv = sys.argv[4] if len(sys.argv) > 4 else None   # bench.py --layer-table: adds the algorithmic bytes
 
 
 def load(path, counter):
@@ -34,6 +35,23 @@ for k in f:
     wb = w.get(k, 0.0) * 1024 / max(wn.get(k, 1), 1)
     res[k] = {'launches_in_pass': fn[k], 'fetch_bytes_per_launch': fb, 'write_bytes_per_launch': wb,
               'hbm_bytes_per_launch': fb + wb}
+if layer_csv:
+    # algorithmic bytes of a conv launch = its input + output + weight tensors once (fp32)
+    acc = {'0': [0.0, 0], '1': [0.0, 0]}
+    for r in csv.DictReader(open(layer_csv)):
+        B, Cin, Cout, H, W, ks = (int(r[k]) for k in ('B', 'Cin', 'Cout', 'H', 'W', 'ks'))
+        px = H if r['kind'] == '1' else H * W          # the wgrad rows carry H*W in the H column
+        by = 4.0 * (B * Cin * px + B * Cout * px + Cout * Cin * ks * ks)
+        acc[r['kind']][0] += by
+        acc[r['kind']][1] += 1
+    for kind, name in (('0', 'pnsfm::conv2d_mfma_kernel'), ('1', 'pnsfm::conv2d_wgrad_kernel')):
+        if name in res and acc[kind][1]:
+            res[name]['algorithmic_bytes_per_launch'] = acc[kind][0] / acc[kind][1]
+res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` with a '
+                'primed tuning database (PNSFM_TUNE_DB: every launch is a training-step launch, no autotune candidates); '
+                'bytes = counter*1024 averaged over the launches of each kernel; FETCH_SIZE is quoted raw (4-byte/lane loads are '
+                'not a calibrated access width on gfx950). algorithmic = (input + output + weight) bytes of the layer, averaged '
+                'over the launches of bench.py --layer-table.')
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
-for k, v in sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_in_pass'])[:12]:
+for k, v in sorted(((k, v) for k, v in res.items() if isinstance(v, dict)), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_in_pass'])[:12]:
     print('%-40s launches %5d  fetch %8.2f MB  write %8.2f MB per launch' % (k, v['launches_in_pass'], v['fetch_bytes_per_launch'] / 1e6, v['write_bytes_per_launch'] / 1e6))

@@ -47,10 +47,12 @@ def synthetic_batch(B, H, W, seed, device):
     return {'rgb': rgb, 'rgb_context': ctx, 'rgb_original': rgb, 'rgb_context_original': ctx, 'intrinsics': K.to(device)}
 
 
-def build_model(device):
+def build_model(device, depth_net='PackNet01'):
     from packnet_sfm.models.SelfSupModel import SelfSupModel
-    from packnet_sfm.networks.depth.PackNet01 import PackNet01
     from packnet_sfm.networks.pose.PoseNet import PoseNet
+    import importlib
+    # resolved by name like the reference's load_class (utils/load.py:79-111); the headline metric is PackNet01
+    PackNet01 = getattr(importlib.import_module('packnet_sfm.networks.depth.' + depth_net), depth_net)
     torch.manual_seed(42)          # same seed on every rank: replicas start identical (reference: model_wrapper.py:44)
     random.seed(42)
     model = SelfSupModel(**LOSS_DEFAULTS)
@@ -112,6 +114,8 @@ def main():
     ap.add_argument('--height', type=int, default=192)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--batch', type=int, default=4, help='images per GPU')
+    ap.add_argument('--depth-net', default='PackNet01', choices=['PackNet01', 'PackNetSlim01'],
+                    help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with events')
     ap.add_argument('--optimizer', default='torch', choices=['flat', 'torch'],
@@ -132,7 +136,7 @@ def main():
     torch.cuda.set_device(device)
 
     H, W, B = args.height, args.width, args.batch
-    model = build_model(device)
+    model = build_model(device, args.depth_net)
     batch = synthetic_batch(B, H, W, 1234 + rank, device)
     groups = [{'name': 'Depth', 'params': list(model.depth_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0},
               {'name': 'Pose', 'params': list(model.pose_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0}]
@@ -201,10 +205,10 @@ def main():
                     'whole_step_vs_mfma_peak': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                 }
         result = {
-            'metric': 'images/sec PackNet01 self-sup train %dx%d' % (H, W), 'value': round(value, 3), 'unit': 'images/sec',
+            'metric': 'images/sec %s self-sup train %dx%d' % (args.depth_net, H, W), 'value': round(value, 3), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'PackNet01(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
+            'config': {'workload': args.depth_net + '(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
                                    'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (
                                        H, W, B, 'BASELINE.json configs[1]' if (H, W, B) == (192, 640, 4) else
                                        ('BASELINE.json configs[2] shape' if (H, W, B) == (384, 1280, 2) else 'custom shape')),

@@ -106,6 +106,15 @@ int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* d
 /* dw3:[8*27], db3:[8]; overwritten. ws: double[8*28] scratch. */
 int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws,
                                       int B, int D, int H, int W, void* stream);
+/* The same three with NF = 4 or 8 feature maps (`d=num_3d_feat` of PackLayerConv3d / UnpackLayerConv3d,
+ * layers01.py:213-232,250-268: 8 in PackNet01, 4 in PackNetSlim01.py:39 and PackNetSAN01.py).  out / dout:[B,NF*D,H,W],
+ * w3:[NF][27], b3:[NF]; ws stays double[8*28]. */
+int pnsfm_conv3d_forward(const float* p, const float* w3, const float* b3, float* out,
+                         int B, int D, int H, int W, int NF, void* stream);
+int pnsfm_conv3d_backward_data(const float* dout, const float* w3, float* dp,
+                               int B, int D, int H, int W, int NF, void* stream);
+int pnsfm_conv3d_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws,
+                                 int B, int D, int H, int W, int NF, void* stream);
 
 /* ---- InvDepth activation: y = sigmoid(x) / min_depth  (layers01.py:119-122) --------------- */
 int pnsfm_invdepth_act_forward(const float* x, float* y, size_t n, float min_depth, void* stream);

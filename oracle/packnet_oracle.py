@@ -75,15 +75,16 @@ def compose_pack_weight(W2, W3):
     conv2d(conv3d_1to8(x)) has no non-linearity in between (layers01.py:243-246), so in the image interior it equals
     one (k+2)x(k+2) conv over the D packed channels with
         W_eff[co, ci, U, V] = sum_{f,dz,dy,dx} W3[f,0,dz,dy,dx] * W2[co, f*D + (ci-dz+1), U-dy, V-dx]."""
-    C, D8, k, _ = W2.shape
-    D = D8 // 8
-    W2v = W2.reshape(C, 8, D, k, k)
+    C, DF, k, _ = W2.shape
+    NF = W3.shape[0]                      # 3-D feature maps: 8 (PackNet01) or 4 (PackNetSlim01)
+    D = DF // NF
+    W2v = W2.reshape(C, NF, D, k, k)
     Weff = W2.new_zeros(C, D, k + 2, k + 2)
     for dz in range(3):
         lo, hi = max(0, dz - 1), min(D, D + dz - 1)          # ci range with d = ci-dz+1 in [0, D)
         for dy in range(3):
             for dx in range(3):
-                w = W3[:, 0, dz, dy, dx].view(1, 8, 1, 1, 1)
+                w = W3[:, 0, dz, dy, dx].view(1, NF, 1, 1, 1)
                 contrib = (W2v[:, :, lo - dz + 1:hi - dz + 1] * w).sum(1)          # [C, hi-lo, k, k]
                 Weff[:, lo:hi, dy:dy + k, dx:dx + k] += contrib
     return Weff
@@ -352,11 +353,12 @@ def _xavier(shape, gen):
     return (torch.rand(shape, generator=gen) * 2 - 1) * a
 
 
-def packnet01_param_shapes(version='1A'):
-    """Every parameter of PackNet01 with the reference's key and shape.  PackNet01.py:25-96, layers01.py"""
+def packnet01_param_shapes(version='1A', ni=64, n1=64, d=8):
+    """Every parameter of PackNet01 with the reference's key and shape.  PackNet01.py:25-96, layers01.py
+    (ni = n1 = 32, d = 4 gives PackNetSlim01: PackNetSlim01.py:33-39)."""
     assert version[1:] == 'A', 'only the concatenation variant is tabulated here'
-    ni, no = 64, 1
-    n1, n2, n3, n4, n5 = 64, 64, 128, 256, 512
+    no = 1
+    n2, n3, n4, n5 = 64, 128, 256, 512
     shapes = {}
 
     def conv2D(p, cin, cout, k):
@@ -379,12 +381,12 @@ def packnet01_param_shapes(version='1A'):
             resconv('%s.%d' % (p, i), cout, cout)
 
     def conv3d(p):
-        shapes[p + '.conv3d.weight'] = (8, 1, 3, 3, 3)
-        shapes[p + '.conv3d.bias'] = (8,)
+        shapes[p + '.conv3d.weight'] = (d, 1, 3, 3, 3)
+        shapes[p + '.conv3d.bias'] = (d,)
 
     conv2D('pre_calc', 3, ni, 5)
     for name, c, k in (('pack1', n1, 5), ('pack2', n2, 3), ('pack3', n3, 3), ('pack4', n4, 3), ('pack5', n5, 3)):
-        conv2D(name + '.conv', c * 4 * 8, c, k)
+        conv2D(name + '.conv', c * 4 * d, c, k)
         conv3d(name)
     conv2D('conv1', ni, n1, 7)
     resblock('conv2', n1, n2, 2)
@@ -393,7 +395,7 @@ def packnet01_param_shapes(version='1A'):
     resblock('conv5', n4, n5, 3)
     for name, cin, cout in (('unpack5', n5, n5), ('unpack4', n5, n4), ('unpack3', n4, n3), ('unpack2', n3, n2),
                             ('unpack1', n2, n1)):
-        conv2D(name + '.conv', cin, cout * 4 // 8, 3)
+        conv2D(name + '.conv', cin, cout * 4 // d, 3)
         conv3d(name)
     conv2D('iconv5', n5 + n4, n5, 3)
     conv2D('iconv4', n4 + n3, n4, 3)

@@ -24,6 +24,7 @@ from oracle import packnet_oracle as O  # noqa: E402
 
 from packnet_sfm.networks.layers.packnet import layers01 as R  # noqa: E402  (reference)
 from packnet_sfm.networks.depth.PackNet01 import PackNet01 as RefPackNet01  # noqa: E402
+from packnet_sfm.networks.depth.PackNetSlim01 import PackNetSlim01 as RefPackNetSlim01  # noqa: E402
 from packnet_sfm.networks.pose.PoseNet import PoseNet as RefPoseNet  # noqa: E402
 from packnet_sfm.losses.multiview_photometric_loss import MultiViewPhotometricLoss as RefLoss  # noqa: E402
 from packnet_sfm.geometry.pose import Pose as RefPose  # noqa: E402
@@ -289,15 +290,86 @@ def case_step(gen):
     return fx
 
 
+def case_slim(gen):
+    """The d = 4 (`num_3d_feat`) variants of the packing / unpacking blocks and PackNetSlim01('1A') at 32x64."""
+    fx = {}
+    for name, c, k, H, W in (('pack_d4_k3', 16, 3, 12, 40), ('pack_d4_k5', 16, 5, 8, 64)):
+        m = R.PackLayerConv3d(c, k, d=4)
+        randomize(m, gen)
+        with torch.no_grad():
+            m.conv3d.weight.copy_(0.3 * torch.randn(m.conv3d.weight.shape, generator=gen))
+        x = torch.randn(2, c, H, W, generator=gen, requires_grad=True)
+        y = m(x)
+        sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+        close(O.pack_layer_conv3d(x, {'l.' + kk: v for kk, v in sd.items()}, 'l', k), y, 2e-5, name)
+        dy = torch.randn(y.shape, generator=gen)
+        g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+        fx[name] = dict(k=k, d=4, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                        dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    m = R.UnpackLayerConv3d(32, 32, 3, d=4)
+    randomize(m, gen)
+    with torch.no_grad():
+        m.conv3d.weight.copy_(0.3 * torch.randn(m.conv3d.weight.shape, generator=gen))
+    x = torch.randn(2, 32, 6, 20, generator=gen, requires_grad=True)
+    y = m(x)
+    sd = {kk: v.detach() for kk, v in m.state_dict().items()}
+    close(O.unpack_layer_conv3d(x, {'l.' + kk: v for kk, v in sd.items()}, 'l', 3), y, 2e-5, 'unpack_d4')
+    dy = torch.randn(y.shape, generator=gen)
+    g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
+    fx['unpack_d4'] = dict(k=3, d=4, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
+                           dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    # whole network
+    shapes = O.packnet01_param_shapes('1A', ni=32, n1=32, d=4)
+    sd = O.init_params(shapes, seed=2468, randomize_affine=True)
+    net = RefPackNetSlim01(dropout=0.0, version='1A')
+    ref_sd = net.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), 'state-dict key mismatch'
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd)
+    net.train()
+    rgb = torch.rand(1, 3, 32, 64, generator=gen)
+    disps = net(rgb)['inv_depths']
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    disps_o = O.packnet01_forward(sdo, rgb, '1A', True)
+    for a, b in zip(disps_o, disps):
+        close(a, b.detach(), 5e-5, 'packnetslim01.disp')
+    dys = [torch.randn(d.shape, generator=gen) for d in disps]
+    names = [n for n, _ in net.named_parameters()]
+    g = grads_of(sum((d * dy).sum() for d, dy in zip(disps, dys)), list(net.parameters()))
+    go = grads_of(sum((d * dy).sum() for d, dy in zip(disps_o, dys)), [sdo[n] for n in names])
+    for n, a, b in zip(names, go, g):
+        close(a, b, 5e-4, 'packnetslim01.grad.' + n)
+    net64 = RefPackNetSlim01(dropout=0.0, version='1A').double()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    net64.train()
+    disps64 = net64(rgb.double())['inv_depths']
+    g64 = grads_of(sum((d * dy.double()).sum() for d, dy in zip(disps64, dys)), list(net64.parameters()))
+    fx['packnetslim01'] = dict(seed=2468, rgb=rgb, disps=[d.detach() for d in disps], dys=dys,
+                               disps_f64=[d.detach() for d in disps64],
+                               grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},
+                               grad_norms={n: float(t.norm()) for n, t in zip(names, g)})
+    return fx
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     gen = torch.Generator().manual_seed(20260923)
+    only = sys.argv[1:]
+    if only == ['slim']:      # added later: own generator, leaves the four original fixture files untouched
+        fx = case_slim(torch.Generator().manual_seed(20260924))
+        path = os.path.join(GOLD, 'slim.pt')
+        torch.save(fx, path)
+        print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+        return
     for name, fn in (('layers', case_layers), ('loss', case_loss), ('network', case_network), ('step', case_step)):
         print('pinning', name, '...', flush=True)
         fx = fn(gen)
         path = os.path.join(GOLD, name + '.pt')
         torch.save(fx, path)
         print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+    fx = case_slim(torch.Generator().manual_seed(20260924))
+    torch.save(fx, os.path.join(GOLD, 'slim.pt'))
     print('oracle pinned against /root/reference: OK')
 
 

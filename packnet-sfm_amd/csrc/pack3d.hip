@@ -53,11 +53,12 @@ __global__ void __launch_bounds__(256) d2s_kernel(const float* __restrict__ x, f
 // grid: (ceil(D*HW/256), 1, B): one thread per voxel (d, y, x) -- flattened so that small planes (the 7x7 / 5x5 weight
 // volumes of the kernel composition, or 6x20 feature maps) still fill every lane -- produces all 8 features;
 // 27 branch-free neighbour loads (L1/L2 serve the overlap between neighbouring threads), 216 FMAs, 8 stores.
+template <int NF>   // number of 3-D feature maps: 8 (PackNet01) or 4 (PackNetSlim01 / PackNetSAN01, `d=num_3d_feat`)
 __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict__ p, const float* __restrict__ w3,
                                                           const float* __restrict__ b3, float* __restrict__ out,
                                                           int D, int H, int W) {
-  __shared__ float ws[8 * 27 + 8];
-  for (int i = threadIdx.x; i < 8 * 27 + 8; i += 256) ws[i] = i < 216 ? w3[i] : b3[i - 216];
+  __shared__ float ws[NF * 27 + NF];
+  for (int i = threadIdx.x; i < NF * 27 + NF; i += 256) ws[i] = i < NF * 27 ? w3[i] : b3[i - NF * 27];
   __syncthreads();
   const int HW = H * W, DHW = D * HW;
   const int vox = blockIdx.x * 256 + threadIdx.x;
@@ -83,17 +84,17 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
       }
     }
   }
-  float acc[8];
+  float acc[NF];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) acc[f] = ws[216 + f];
+  for (int f = 0; f < NF; ++f) acc[f] = ws[NF * 27 + f];
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) acc[f] = fmaf(ws[f * 27 + tap], v[tap], acc[f]);
+    for (int f = 0; f < NF; ++f) acc[f] = fmaf(ws[f * 27 + tap], v[tap], acc[f]);
   if (active) {
-    float* ob = out + (size_t)b * 8 * DHW + vox;
+    float* ob = out + (size_t)b * NF * DHW + vox;
 #pragma unroll
-    for (int f = 0; f < 8; ++f) ob[(size_t)f * DHW] = acc[f];
+    for (int f = 0; f < NF; ++f) ob[(size_t)f * DHW] = acc[f];
   }
 }
 
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
 // per output, ~80 for the run lengths the launcher picks.
 // Lanes still run along x (coalesced); the flattened (chunk, pixel) index keeps tiny planes (6x20 maps, 5x5 / 7x7 weight
 // volumes of the kernel composition) on full waves.  Weights are uniform global reads (scalar loads -> SGPR operands).
+template <int NF>
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
                                                             float* __restrict__ dp, int D, int H, int W, int len) {
   const int HW = H * W, DHW = D * HW;
@@ -117,9 +119,9 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
   const int d0 = chunk * len;
   const int dend = (d0 + len < D) ? d0 + len : D;
   // one descriptor per feature slab [D][H][W] (the range-checked window); all wave-uniform, they live in SGPRs
-  pnsfm_buf gbuf[8];
+  pnsfm_buf gbuf[NF];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) gbuf[f] = pnsfm_make_buf(dout + ((size_t)blockIdx.z * 8 + f) * DHW, (unsigned)DHW * 4u);
+  for (int f = 0; f < NF; ++f) gbuf[f] = pnsfm_make_buf(dout + ((size_t)blockIdx.z * NF + f) * DHW, (unsigned)DHW * 4u);
   float* ob = dp + (size_t)blockIdx.z * DHW + pix;
   const unsigned kOut = 0x7fffffffu;       // out-of-range byte offset -> the load returns 0
   unsigned off[9];                         // in-plane byte offsets of the 9 neighbours (kOut outside the image)
@@ -137,15 +139,15 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
   for (int dd = d0 - 1; dd <= dend; ++dd) {
     const bool dok = dd >= 0 && dd < D;
     const unsigned plane = dok ? (unsigned)dd * (unsigned)HW * 4u : 0u;
-    float g[8][9];
+    float g[NF][9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const unsigned vo = (dok && off[t] != kOut) ? plane + off[t] : kOut;
 #pragma unroll
-      for (int f = 0; f < 8; ++f) g[f][t] = pnsfm_buf_load(gbuf[f], vo, 0u);
+      for (int f = 0; f < NF; ++f) g[f][t] = pnsfm_buf_load(gbuf[f], vo, 0u);
     }
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         a_lo = fmaf(w3[f * 27 + t], g[f][t], a_lo);             // dz = 0: d = dd - 1
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
 // through LDS 16 at a time (conflict-free padded rows, then a 16-lane shuffle), one fp64 atomic per value per block.
 constexpr int kW3Pass = 16, kW3Row = 256 + 16;
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
-                                                            double* __restrict__ ws, int D, int H, int W, int len) {
+                                                            double* __restrict__ ws, int D, int H, int W, int len, int NF) {
   __shared__ float red[kW3Pass * kW3Row];
   const int tid = threadIdx.x;
   const int HW = H * W, DHW = D * HW;
@@ -184,7 +186,7 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restri
   const int d0 = chunk * len;
   const int dend = (d0 + len < D) ? d0 + len : D;
   const float* pb = p + (size_t)b * DHW;
-  const float* gb = dout + ((size_t)b * 8 + fg * 4) * DHW + pix;
+  const float* gb = dout + ((size_t)b * NF + fg * 4) * DHW + pix;
   int off[9];
   bool okp[9];
 #pragma unroll
@@ -266,9 +268,10 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restri
   }
 }
 
-__global__ void conv3d_wgrad_finish_kernel(const double* __restrict__ ws, float* __restrict__ dw3, float* __restrict__ db3) {
+__global__ void conv3d_wgrad_finish_kernel(const double* __restrict__ ws, float* __restrict__ dw3, float* __restrict__ db3,
+                                           int NF) {
   const int i = threadIdx.x;
-  if (i < 8 * 28) {
+  if (i < NF * 28) {
     const int f = i / 28, t = i - f * 28;
     if (t < 27) dw3[f * 27 + t] = (float)ws[i]; else db3[f] = (float)ws[i];
   }
@@ -305,38 +308,63 @@ int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, v
   return check_launch("depth_to_space");
 }
 
-int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W,
-                              void* stream) {
-  PNSFM_LAUNCH(conv3d_fwd_kernel, dim3(ceil_div(D * H * W, 256), 1, B), dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
+static bool nf_ok(int NF, const char* what) {
+  if (NF == 4 || NF == 8) return true;
+  set_error("%s: the gfx950 stencil kernels are built for 4 or 8 3-D feature maps (got %d)", what, NF);
+  return false;
+}
+
+int pnsfm_conv3d_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W, int NF,
+                         void* stream) {
+  if (!nf_ok(NF, "conv3d_forward")) return -1;
+  const dim3 grid(ceil_div(D * H * W, 256), 1, B);
+  if (NF == 8) PNSFM_LAUNCH((conv3d_fwd_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
+  else PNSFM_LAUNCH((conv3d_fwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
   return check_launch("conv3d_forward");
 }
 
-int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
+int pnsfm_conv3d_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, int NF, void* stream) {
+  if (!nf_ok(NF, "conv3d_backward_data")) return -1;
   if ((size_t)D * H * W * 4 >= 0x7fffffffull) { set_error("conv3d_backward_data: feature slab exceeds the 2 GiB buffer window"); return -1; }
   // run length along d: 8 (25 % halo planes) when that still gives every CU a few blocks, shorter for small volumes
   int len = D < 8 ? D : 8;
   while (len > 2 && (long)B * ceil_div(D, len) * H * W < 2L * 256 * 256) len = ceil_div(len, 2);
-  PNSFM_LAUNCH(conv3d_dgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), 1, B), dim3(256), 0,
-               (hipStream_t)stream, dout, w3, dp, D, H, W, len);
+  const dim3 grid(ceil_div(ceil_div(D, len) * H * W, 256), 1, B);
+  if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
+  else PNSFM_LAUNCH((conv3d_dgrad_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
   return check_launch("conv3d_backward_data");
 }
 
-int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws, int B, int D,
-                                      int H, int W, void* stream) {
+int pnsfm_conv3d_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws, int B, int D, int H,
+                                 int W, int NF, void* stream) {
+  if (!nf_ok(NF, "conv3d_backward_weight")) return -1;
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
   if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
   // run length along d per thread: as long as possible (amortises the block reduction) while the grid still gives every
   // CU a few blocks
   int len = D;
-  while (len > 12 && (long)B * 2 * ceil_div(D, len) * H * W < 4L * 256 * 256) len = ceil_div(len, 2);
+  while (len > 12 && (long)B * (NF / 4) * ceil_div(D, len) * H * W < 4L * 256 * 256) len = ceil_div(len, 2);
   len = ceil_div(len, 3) * 3;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), 2, B), dim3(256), 0, s, p, dout, ws, D, H,
-               W, len);
+  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), NF / 4, B), dim3(256), 0, s, p, dout, ws, D,
+               H, W, len, NF);
   e = check_launch("conv3d_backward_weight");
   if (e) return e;
-  PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3);
+  PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3, NF);
   return check_launch("conv3d_backward_weight_finish");
+}
+
+// PackNet01's fixed d = 8 (the original entry points)
+int pnsfm_conv3d_1to8_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W,
+                              void* stream) {
+  return pnsfm_conv3d_forward(p, w3, b3, out, B, D, H, W, 8, stream);
+}
+int pnsfm_conv3d_1to8_backward_data(const float* dout, const float* w3, float* dp, int B, int D, int H, int W, void* stream) {
+  return pnsfm_conv3d_backward_data(dout, w3, dp, B, D, H, W, 8, stream);
+}
+int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* dw3, float* db3, double* ws, int B, int D,
+                                      int H, int W, void* stream) {
+  return pnsfm_conv3d_backward_weight(p, dout, dw3, db3, ws, B, D, H, W, 8, stream);
 }
 
 }  // extern "C"

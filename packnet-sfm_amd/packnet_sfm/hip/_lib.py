@@ -39,6 +39,9 @@ SIGNATURES = {
     "pnsfm_conv3d_1to8_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_conv3d_1to8_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_conv3d_1to8_backward_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_conv3d_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv3d_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv3d_backward_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_invdepth_act_forward": (_i, [_p, _p, _sz, _f, _p]),
     "pnsfm_invdepth_act_backward": (_i, [_p, _p, _p, _sz, _f, _p]),
     "pnsfm_pose_vec2mat_forward": (_i, [_p, _p, _i, _p]),

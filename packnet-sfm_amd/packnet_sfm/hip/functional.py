@@ -183,7 +183,8 @@ def depth_to_space(x):
 
 
 class Conv3d1to8Fn(Function):
-    """[B,D,H,W] -> [B,8*D,H,W]: Conv3d(1,8,3,pad 1) over (channel,y,x), channel index f*D+d."""
+    """[B,D,H,W] -> [B,NF*D,H,W]: Conv3d(1,NF,3,pad 1) over (channel,y,x), channel index f*D+d; NF = 8 (PackNet01)
+    or 4 (PackNetSlim01 / PackNetSAN01)."""
 
     @staticmethod
     def forward(ctx, p, w3, b3):
@@ -233,7 +234,7 @@ class ComposePackWeightFn(Function):
         g = g.contiguous()
         dW2 = dW3 = None
         if ctx.needs_input_grad[0]:
-            dW2 = ops.conv3d_forward(g, w3, torch.zeros(8, device=g.device, dtype=g.dtype))[:, :, 1:-1, 1:-1].contiguous()
+            dW2 = ops.conv3d_forward(g, w3, torch.zeros(w3.shape[0], device=g.device, dtype=g.dtype))[:, :, 1:-1, 1:-1].contiguous()
         if ctx.needs_input_grad[1]:
             dW3, _ = ops.conv3d_backward_weight(g, W2pad)
         return dW2, dW3

@@ -184,21 +184,32 @@ def depth_to_space(x):
     return y
 
 
+def _nf_of(w3):
+    """Number of 3-D feature maps of a Conv3d(1, NF, 3) weight [NF,1,3,3,3] (or [NF,27])."""
+    nf = w3.shape[0]
+    if w3.numel() != nf * 27:
+        raise RuntimeError("conv3d: weight must be [NF,1,3,3,3]")
+    return nf
+
+
 def conv3d_forward(p, w3, b3):
+    """p [B,D,H,W] -> [B,NF*D,H,W] (channel f*D+d), NF = w3.shape[0] in {4, 8}."""
     _chk(p, w3, b3); _f32(p, w3, b3)
     B, D, H, W = p.shape
-    out = torch.empty((B, 8 * D, H, W), dtype=torch.float32, device=p.device)
-    _lib.check(_lib.get().pnsfm_conv3d_1to8_forward(_ptr(p), _ptr(w3), _ptr(b3), _ptr(out), B, D, H, W, _stream(p)),
+    nf = _nf_of(w3)
+    out = torch.empty((B, nf * D, H, W), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.get().pnsfm_conv3d_forward(_ptr(p), _ptr(w3), _ptr(b3), _ptr(out), B, D, H, W, nf, _stream(p)),
                "conv3d_forward")
     return out
 
 
 def conv3d_backward_data(dout, w3):
     _chk(dout, w3); _f32(dout, w3)
-    B, D8, H, W = dout.shape
-    D = D8 // 8
+    B, DF, H, W = dout.shape
+    nf = _nf_of(w3)
+    D = DF // nf
     dp = torch.empty((B, D, H, W), dtype=torch.float32, device=dout.device)
-    _lib.check(_lib.get().pnsfm_conv3d_1to8_backward_data(_ptr(dout), _ptr(w3), _ptr(dp), B, D, H, W, _stream(dout)),
+    _lib.check(_lib.get().pnsfm_conv3d_backward_data(_ptr(dout), _ptr(w3), _ptr(dp), B, D, H, W, nf, _stream(dout)),
                "conv3d_backward_data")
     return dp
 
@@ -206,11 +217,12 @@ def conv3d_backward_data(dout, w3):
 def conv3d_backward_weight(p, dout):
     _chk(p, dout); _f32(p, dout)
     B, D, H, W = p.shape
-    dw3 = torch.empty((8, 1, 3, 3, 3), dtype=torch.float32, device=p.device)
-    db3 = torch.empty((8,), dtype=torch.float32, device=p.device)
+    nf = dout.shape[1] // D
+    dw3 = torch.empty((nf, 1, 3, 3, 3), dtype=torch.float32, device=p.device)
+    db3 = torch.empty((nf,), dtype=torch.float32, device=p.device)
     ws = torch.empty((8 * 28,), dtype=torch.float64, device=p.device)
-    _lib.check(_lib.get().pnsfm_conv3d_1to8_backward_weight(_ptr(p), _ptr(dout), _ptr(dw3), _ptr(db3), _ptr(ws), B, D, H, W,
-                                                            _stream(p)), "conv3d_backward_weight")
+    _lib.check(_lib.get().pnsfm_conv3d_backward_weight(_ptr(p), _ptr(dout), _ptr(dw3), _ptr(db3), _ptr(ws), B, D, H, W, nf,
+                                                       _stream(p)), "conv3d_backward_weight")
     return dw3, db3
 
 

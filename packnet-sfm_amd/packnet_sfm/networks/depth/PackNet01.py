@@ -22,14 +22,21 @@ class PackNet01(nn.Module):
         'XY': X unused, Y = 'A' (skip connections concatenated) or 'B' (added)
     """
 
+    # stem width ni, encoder widths n1..n5, number of 3-D feature maps of the packing blocks (PackNet01.py:32-37);
+    # PackNetSlim01 overrides them (PackNetSlim01.py:33-39)
+    STEM_WIDTH = 64
+    WIDTHS = (64, 64, 128, 256, 512)
+    NUM_3D_FEAT = 8
+
     def __init__(self, dropout=None, version=None, **kwargs):
         super().__init__()
         if version is None or version[1:] not in ('A', 'B'):
             raise ValueError('Unknown PackNet version {}'.format(version))
         self.version = version[1:]
         concat = self.version == 'A'
-        ni, no = 64, 1                          # stem width, inverse-depth channels
-        n = [64, 64, 128, 256, 512]             # encoder widths n1..n5
+        ni, no = self.STEM_WIDTH, 1             # stem width, inverse-depth channels
+        n = list(self.WIDTHS)                   # encoder widths n1..n5
+        d3 = self.NUM_3D_FEAT
         blocks = [2, 2, 3, 3]
         pack_k = [5, 3, 3, 3, 3]
         if concat:
@@ -42,13 +49,13 @@ class PackNet01(nn.Module):
         # registration order follows the reference so that identical seeds give identical initial weights
         self.pre_calc = Conv2D(3, ni, 5, 1)
         for i in range(5):
-            setattr(self, 'pack%d' % (i + 1), PackLayerConv3d(n[i], pack_k[i]))
+            setattr(self, 'pack%d' % (i + 1), PackLayerConv3d(n[i], pack_k[i], d=d3))
         self.conv1 = Conv2D(ni, n[0], 7, 1)
         for i in range(4):
             setattr(self, 'conv%d' % (i + 2), ResidualBlock(n[i], n[i + 1], blocks[i], 1, dropout=dropout))
         unpack_in = [n[1], n[2], n[3], n[4], n[4]]   # inputs of unpack1..unpack5
         for i in (4, 3, 2, 1, 0):
-            setattr(self, 'unpack%d' % (i + 1), UnpackLayerConv3d(unpack_in[i], dec_out[i], 3))
+            setattr(self, 'unpack%d' % (i + 1), UnpackLayerConv3d(unpack_in[i], dec_out[i], 3, d=d3))
         for i in (4, 3, 2, 1, 0):
             setattr(self, 'iconv%d' % (i + 1), Conv2D(dec_in[i], n[i], 3, 1))
         for i in (3, 2, 1, 0):

@@ -147,8 +147,9 @@ class PackLayerConv3d(nn.Module):
 
     def __init__(self, in_channels, kernel_size, r=2, d=8):
         super().__init__()
-        if r != 2 or d != 8:
-            raise NotImplementedError('the gfx950 packing kernels implement r=2, d=8 (PackNet01)')
+        if r != 2 or d not in (4, 8):
+            raise NotImplementedError('the gfx950 packing kernels implement r=2 and d in {4, 8} (PackNet01 / PackNetSlim01)')
+        self.d = d
         self.conv = Conv2D(in_channels * (r ** 2) * d, in_channels, kernel_size, 1)
         self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
         self._eff_packed = HF.PackedConvWeight(volatile=True)
@@ -160,8 +161,8 @@ class PackLayerConv3d(nn.Module):
             return False
         if self.collapse is True:
             return True
-        orig = 8.0 * k * k * h * w
-        strips = 8.0 * k * k * (2 * (2 * r) * w + 2 * h * (2 * r))
+        orig = float(self.d) * k * k * h * w
+        strips = float(self.d) * k * k * (2 * (2 * r) * w + 2 * h * (2 * r))
         return (k + 2) ** 2 * h * w + strips <= 0.7 * orig
 
     def _conv_reference_form(self, P):
@@ -178,7 +179,7 @@ class PackLayerConv3d(nn.Module):
         B, _, h, w = P.shape
         # interior: one (k+2)x(k+2) conv with the composed kernel; its bias is b2 + sum over ALL taps of W2 * b3
         W_eff = HF.compose_pack_weight(W2, W3)
-        bias_eff = b2 + (W2.reshape(C, 8, -1).sum(2) * b3.view(1, 8)).sum(1)
+        bias_eff = b2 + (W2.reshape(C, self.d, -1).sum(2) * b3.view(1, self.d)).sum(1)
         # border frame (r pixels): original formula on strips of 2r+1 packed rows / columns (top+bottom and left+right
         # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept.  The three
         # helper Functions do the strip gather / select / paste without full-size zero-fills and adds in backward.
@@ -200,8 +201,8 @@ class UnpackLayerConv3d(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size, r=2, d=8):
         super().__init__()
-        if r != 2 or d != 8:
-            raise NotImplementedError('the gfx950 unpacking kernels implement r=2, d=8 (PackNet01)')
+        if r != 2 or d not in (4, 8):
+            raise NotImplementedError('the gfx950 unpacking kernels implement r=2 and d in {4, 8} (PackNet01 / PackNetSlim01)')
         self.conv = Conv2D(in_channels, out_channels * (r ** 2) // d, kernel_size, 1)
         self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
 

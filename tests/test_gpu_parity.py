@@ -46,6 +46,20 @@ def test_pack_golden(name, collapse):
     P.case_pack(name, DEV, collapse=collapse)
 
 
+@pytest.mark.parametrize('collapse', [False, True])
+@pytest.mark.parametrize('name', ['pack_d4_k3', 'pack_d4_k5'])
+def test_pack_d4_golden(name, collapse):
+    P.case_pack_d4(name, DEV, collapse)
+
+
+def test_unpack_d4_golden():
+    P.case_unpack_d4(DEV)
+
+
+def test_packnetslim01_golden():
+    P.case_packnetslim01(DEV)
+
+
 def test_unpack_golden():
     P.case_unpack(DEV)
 

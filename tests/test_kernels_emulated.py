@@ -42,6 +42,12 @@ def test_pack_k3(emulated_kernels):
     P.case_pack('pack_k3', 'cpu')
 
 
+def test_pack_unpack_d4(emulated_kernels):
+    """d = 4 3-D feature maps (PackNetSlim01): reference-form packing block and unpacking block vs the reference golden."""
+    P.case_pack_d4('pack_d4_k3', 'cpu')
+    P.case_unpack_d4('cpu')
+
+
 def test_compose_pack_weight(emulated_kernels):
     """Kernel composition used by the collapsed packing block (and its gradients) vs the oracle's formula.
     (The full collapsed block is checked against the reference golden in the -m gpu tests; too slow to emulate.)"""
@@ -100,8 +106,9 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     P.check(db, br.grad, 1e-5, 'dbias')
 
 
+@pytest.mark.parametrize('nf', [8, 4])
 @pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3)])
-def test_conv3d_raw(emulated_kernels, shape):
+def test_conv3d_raw(emulated_kernels, shape, nf):
     """3x3x3 1->8 stencil: forward, data gradient (column-sliding kernel, ragged run lengths along d) and weight/bias
     gradient (register accumulation + LDS block reduction) vs the oracle on small odd volumes."""
     from oracle import packnet_oracle as O
@@ -109,8 +116,8 @@ def test_conv3d_raw(emulated_kernels, shape):
     B, D, H, W = shape
     g = torch.Generator().manual_seed(sum(shape))
     p = torch.randn(B, D, H, W, generator=g)
-    w3 = 0.3 * torch.randn(8, 1, 3, 3, 3, generator=g)
-    b3 = torch.randn(8, generator=g)
+    w3 = 0.3 * torch.randn(nf, 1, 3, 3, 3, generator=g)
+    b3 = torch.randn(nf, generator=g)
     pr, wr, br = (t.clone().requires_grad_(True) for t in (p, w3, b3))
     pd, wd, bd = (t.clone().requires_grad_(True) for t in (p, w3, b3))
     yr = O.conv3d_1to8(pr, wr, br)

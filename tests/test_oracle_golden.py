@@ -32,6 +32,21 @@ def test_oracle_packing_blocks():
     P.check(O.unpack_layer_conv3d(fx['x'], _sd(fx), 'l', 3), fx['y'], 2e-5, 'unpack')
 
 
+def test_oracle_d4_blocks_and_packnetslim01():
+    """d = 4 packing / unpacking blocks and PackNetSlim01 (reference: PackNetSlim01.py, num_3d_feat = 4)."""
+    S = P.golden('slim')
+    for name in ('pack_d4_k3', 'pack_d4_k5'):
+        fx = S[name]
+        P.check(O.pack_layer_conv3d(fx['x'], _sd(fx), 'l', fx['k']), fx['y'], 2e-5, name)
+    fx = S['unpack_d4']
+    P.check(O.unpack_layer_conv3d(fx['x'], _sd(fx), 'l', 3), fx['y'], 2e-5, 'unpack_d4')
+    fx = S['packnetslim01']
+    sd = O.init_params(O.packnet01_param_shapes('1A', ni=32, n1=32, d=4), seed=fx['seed'], randomize_affine=True)
+    disps = O.packnet01_forward(sd, fx['rgb'], '1A', True)
+    for a, b in zip(disps, fx['disps']):
+        P.check(a, b, 5e-5, 'packnetslim01 disp')
+
+
 def test_oracle_loss_and_grads():
     for name, fx in P.golden('loss').items():
         inv = [t.clone().requires_grad_(True) for t in fx['inv_depths']]

@@ -137,6 +137,17 @@ int pnsfm_invdepth_conv_backward(const float* x, const float* w, const float* dz
 int pnsfm_pose_vec2mat_forward(const float* vec, float* mat, int N, void* stream);
 int pnsfm_pose_vec2mat_backward(const float* vec, const float* dmat, float* dvec, int N, void* stream);
 
+/* ---- supervised inverse-depth loss of the semi-supervised models, ONE scale ---------------------------------------
+ * replaces SupervisedLoss.calculate_loss for one scale (losses/supervised_loss.py:138-149) with the loss functions of
+ * get_loss_func (:70-84): method 0 = l1 (nn.L1Loss), 1 = mse, 2 = abs_rel (mean |x-y| / x), 3 = berhu (BerHuLoss :11-53,
+ * threshold 0.2), 4 = silog (SilogLoss :55-67, ratio 10, ratio2 0.85); sparse != 0 keeps only pixels with gt > 0 (the
+ * 'sparse-*' methods).  pred, gt: n floats (same resolution); loss: 1 float; ws: double[8 + 1024] scratch that the
+ * backward call reads again.  backward: grad_out: 1 float (dL/dloss) -> dpred: n floats (zero at masked pixels). */
+int pnsfm_supervised_loss_forward(const float* pred, const float* gt, float* loss, double* ws, size_t n, int method,
+                                  int sparse, void* stream);
+int pnsfm_supervised_loss_backward(const float* pred, const float* gt, const double* ws, const float* grad_out,
+                                   float* dpred, size_t n, int method, int sparse, void* stream);
+
 /* ---- view synthesis: inv2depth -> Camera.reconstruct -> Camera.project -> grid_sample ------
  * replaces MultiViewPhotometricLoss.warp_ref_image for ONE scale and J context images:
  *   losses/multiview_photometric_loss.py:127-165, utils/depth.py:103-120 (inv2depth),
@@ -154,7 +165,7 @@ int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth,
 
 /* ---- photometric loss of one scale: SSIM + L1, automask, min/mean reduce -------------------
  * replaces SSIM() :14-53, MultiViewPhotometricLoss.SSIM :169-186, calc_photometric_loss :188-223
- * (clip_loss == 0 only) and the per-scale body of reduce_photometric_loss :225-253.
+ * and the per-scale body of reduce_photometric_loss :225-253 (clip_loss > 0: the _clip variants below).
  * Candidates per pixel, in the reference's order (:321-334): warped[0], ref[0], warped[1], ref[1], ...
  * (ref[j] entries only when automask != 0).  reduce_op: 0 = 'min', 1 = 'mean'.
  * loss_sum: double[1], receives sum over pixels of the reduced per-pixel loss (caller divides by B*H*W);
@@ -166,6 +177,17 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
 int pnsfm_photometric_backward(const float* warped, const float* target, const uint8_t* argmin,
                                float* d_warped, float grad_scale, int J, int B, int H, int W,
                                float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
+/* clip_loss > 0 (:214-219): every candidate map is clamped at mean + clip_loss * std of itself (torch.std: unbiased; the
+ * threshold is a float in the reference, so no gradient flows through it).  Three launches: statistics pass, threshold
+ * kernel, clamped pass.  stats_ws: double[12], thr_ws: float[6] scratch.  The per-pixel byte then also records clamping
+ * (min: argmin | clamped << 7; mean: bit mask of clamped candidates) and MUST go to pnsfm_photometric_backward_clip. */
+int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target,
+                                   double* loss_sum, uint8_t* argmin, int J, int B, int H, int W,
+                                   float ssim_weight, float C1, float C2, int automask, int reduce_op,
+                                   float clip_loss, double* stats_ws, float* thr_ws, void* stream);
+int pnsfm_photometric_backward_clip(const float* warped, const float* target, const uint8_t* argmin,
+                                    float* d_warped, float grad_scale, int J, int B, int H, int W,
+                                    float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
 
 /* ---- edge-aware smoothness of one scale ------------------------------------------------------
  * replaces calc_smoothness utils/depth.py:165-198 (after inv_depths_normalize :146-162) with

@@ -289,13 +289,20 @@ def match_scales(image, targets):
 
 def multiview_photometric_loss(image, context, inv_depths, K, ref_K, pose_mats, num_scales=4, ssim_loss_weight=0.85,
                                smooth_loss_weight=0.001, C1=1e-4, C2=9e-4, photometric_reduce_op='min',
-                               automask_loss=True, padding_mode='zeros'):
-    """MultiViewPhotometricLoss.forward (clip_loss = 0, progressive_scaling = 0).  :287-344
+                               automask_loss=True, padding_mode='zeros', clip_loss=0.0):
+    """MultiViewPhotometricLoss.forward (progressive_scaling = 0).  :287-344; clip_loss: :214-219 (each candidate map is
+    clamped at the float mean + clip_loss * std of itself).
     pose_mats: list of [B,4,4] (Pose.mat of the target->context transforms).  Returns (loss[1], photo, smooth)."""
     n = num_scales
     H, W = image.shape[-2:]
     images = match_scales(image, inv_depths[:n])
     cands = [[] for _ in range(n)]
+
+    def clip(m):
+        if clip_loss > 0.0:
+            return torch.clamp(m, max=float((m.mean() + clip_loss * m.std()).detach()))
+        return m
+
     for ref_image, T in zip(context, pose_mats):
         ref_images = match_scales(ref_image, inv_depths[:n])
         for i in range(n):
@@ -304,9 +311,9 @@ def multiview_photometric_loss(image, context, inv_depths, K, ref_K, pose_mats, 
             Ki = K.float() if s == 1. else scale_intrinsics(K.float(), s, s)          # :153-157, camera.py:84-108
             rKi = ref_K.float() if s == 1. else scale_intrinsics(ref_K.float(), s, s)
             warped = view_synthesis(ref_images[i], inv_depths[i], Ki, rKi, T, padding_mode)
-            cands[i].append(photometric_map(warped, images[i], ssim_loss_weight, C1, C2))
+            cands[i].append(clip(photometric_map(warped, images[i], ssim_loss_weight, C1, C2)))
             if automask_loss:
-                cands[i].append(photometric_map(ref_images[i], images[i], ssim_loss_weight, C1, C2))
+                cands[i].append(clip(photometric_map(ref_images[i], images[i], ssim_loss_weight, C1, C2)))
     photo = sum(reduce_candidates(cands[i], photometric_reduce_op) for i in range(n)) / n
     loss = photo
     smooth = torch.zeros((), dtype=image.dtype, device=image.device)
@@ -353,10 +360,42 @@ def _xavier(shape, gen):
     return (torch.rand(shape, generator=gen) * 2 - 1) * a
 
 
+def supervised_loss(inv_depths, gt_inv_depth, supervised_method='sparse-l1', num_scales=4):
+    """SupervisedLoss.forward / calculate_loss with the loss functions of get_loss_func.
+    losses/supervised_loss.py:11-88 (BerHuLoss threshold 0.2, SilogLoss ratio 10 / ratio2 0.85) and :138-181."""
+    def match(gt, target):
+        if tuple(gt.shape[-2:]) == tuple(target.shape[-2:]):
+            return gt
+        return F.interpolate(gt, size=target.shape[-2:], mode='nearest')
+
+    def one(pred, gt):
+        if supervised_method.startswith('sparse'):
+            mask = gt > 0.
+            pred, gt = pred[mask], gt[mask]
+        if supervised_method.endswith('abs_rel'):
+            return torch.mean(torch.abs(pred - gt) / pred)
+        if supervised_method.endswith('l1'):
+            return torch.mean(torch.abs(pred - gt))
+        if supervised_method.endswith('mse'):
+            return torch.mean((pred - gt) ** 2)
+        if supervised_method.endswith('berhu'):
+            c = 0.2 * torch.max(pred - gt)
+            diff = (pred - gt).abs()
+            diff2 = diff[(diff > c).detach()] ** 2
+            return torch.cat((diff.flatten(), diff2.flatten())).mean()
+        if supervised_method.endswith('silog'):
+            ld = torch.log(pred * 10) - torch.log(gt * 10)
+            return torch.sqrt(torch.mean(ld ** 2) - 0.85 * ld.mean() ** 2) * 10
+        raise ValueError(supervised_method)
+
+    return sum(one(inv_depths[i], match(gt_inv_depth, inv_depths[i])) for i in range(num_scales)) / num_scales
+
+
 def packnet01_param_shapes(version='1A', ni=64, n1=64, d=8):
     """Every parameter of PackNet01 with the reference's key and shape.  PackNet01.py:25-96, layers01.py
     (ni = n1 = 32, d = 4 gives PackNetSlim01: PackNetSlim01.py:33-39)."""
-    assert version[1:] == 'A', 'only the concatenation variant is tabulated here'
+    assert version[1:] in ('A', 'B')
+    concat = version[1:] == 'A'                 # 'B': skip connections are added (PackNet01.py:46-52)
     no = 1
     n2, n3, n4, n5 = 64, 128, 256, 512
     shapes = {}
@@ -393,15 +432,21 @@ def packnet01_param_shapes(version='1A', ni=64, n1=64, d=8):
     resblock('conv3', n2, n3, 2)
     resblock('conv4', n3, n4, 3)
     resblock('conv5', n4, n5, 3)
-    for name, cin, cout in (('unpack5', n5, n5), ('unpack4', n5, n4), ('unpack3', n4, n3), ('unpack2', n3, n2),
-                            ('unpack1', n2, n1)):
+    if concat:
+        n1o, n2o, n3o, n4o, n5o = n1, n2, n3, n4, n5
+        n1i, n2i, n3i, n4i, n5i = n1 + ni + no, n2 + n1 + no, n3 + n2 + no, n4 + n3, n5 + n4
+    else:
+        n1o, n2o, n3o, n4o, n5o = n1, n2, n3 // 2, n4 // 2, n5 // 2
+        n1i, n2i, n3i, n4i, n5i = n1 + no, n2 + no, n3 // 2 + no, n4 // 2, n5 // 2
+    for name, cin, cout in (('unpack5', n5, n5o), ('unpack4', n5, n4o), ('unpack3', n4, n3o), ('unpack2', n3, n2o),
+                            ('unpack1', n2, n1o)):
         conv2D(name + '.conv', cin, cout * 4 // d, 3)
         conv3d(name)
-    conv2D('iconv5', n5 + n4, n5, 3)
-    conv2D('iconv4', n4 + n3, n4, 3)
-    conv2D('iconv3', n3 + n2 + no, n3, 3)
-    conv2D('iconv2', n2 + n1 + no, n2, 3)
-    conv2D('iconv1', n1 + ni + no, n1, 3)
+    conv2D('iconv5', n5i, n5, 3)
+    conv2D('iconv4', n4i, n4, 3)
+    conv2D('iconv3', n3i, n3, 3)
+    conv2D('iconv2', n2i, n2, 3)
+    conv2D('iconv1', n1i, n1, 3)
     for name, c in (('disp4_layer', n4), ('disp3_layer', n3), ('disp2_layer', n2), ('disp1_layer', n1)):
         shapes[name + '.conv1.weight'] = (no, c, 3, 3)
         shapes[name + '.conv1.bias'] = (no,)

@@ -28,6 +28,7 @@ from packnet_sfm.networks.depth.PackNetSlim01 import PackNetSlim01 as RefPackNet
 from packnet_sfm.networks.pose.PoseNet import PoseNet as RefPoseNet  # noqa: E402
 from packnet_sfm.losses.multiview_photometric_loss import MultiViewPhotometricLoss as RefLoss  # noqa: E402
 from packnet_sfm.geometry.pose import Pose as RefPose  # noqa: E402
+from packnet_sfm.losses.supervised_loss import SupervisedLoss as RefSupervisedLoss  # noqa: E402
 from packnet_sfm.models.SelfSupModel import SelfSupModel as RefSelfSup  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
@@ -148,16 +149,16 @@ def kitti_K(B, H, W):
     return torch.tensor([[0.58 * W, 0., 0.5 * W], [0., 1.92 * H, 0.5 * H], [0., 0., 1.]], dtype=torch.float64).repeat(B, 1, 1)
 
 
-def case_loss(gen):
+def case_loss(gen, cases=None, keep_clip=False):
     """MultiViewPhotometricLoss fixtures: default config (upsampled scales, min+automask) and the
-    non-upsampled / mean variants."""
+    non-upsampled / mean variants (or the given `cases`; keep_clip: clip_loss stays in the stored kwargs)."""
     import torch.nn.functional as F
     fx = {}
     B, H, W = 2, 48, 64
     image, context = smooth_images(B, H, W, gen)
     K = kitti_K(B, H, W)
     pose_vec = torch.cat([0.05 * torch.randn(B, 2, 3, generator=gen), 0.01 * torch.randn(B, 2, 3, generator=gen)], 2)
-    for name, kwargs, upsample in (
+    for name, kwargs, upsample in cases or (
             ('loss_default', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
                                   automask_loss=True, clip_loss=0.0), True),
             ('loss_multires_mean', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.1,
@@ -177,7 +178,7 @@ def case_loss(gen):
         inv_o = [t.detach().clone().requires_grad_(True) for t in inv]
         pv_o = pose_vec.clone().requires_grad_(True)
         mats = [O.pose_vec2mat44(pv_o[:, i]) for i in range(2)]
-        okw = {k: v for k, v in kwargs.items() if k != 'clip_loss'}
+        okw = {k: v for k, v in kwargs.items() if keep_clip or k != 'clip_loss'}
         lo, po, so = O.multiview_photometric_loss(image, context, inv_o, K, K, mats, **okw)
         go = grads_of(lo.sum(), inv_o + [pv_o])
         close(lo, loss.detach(), 1e-5, name + '.loss')
@@ -349,6 +350,62 @@ def case_slim(gen):
                                disps_f64=[d.detach() for d in disps64],
                                grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},
                                grad_norms={n: float(t.norm()) for n, t in zip(names, g)})
+    # PackNet01 version '1B' (skip connections added instead of concatenated, PackNet01.py:46-52,142-176)
+    shapes = O.packnet01_param_shapes('1B')
+    sd = O.init_params(shapes, seed=1357, randomize_affine=True)
+    net = RefPackNet01(dropout=0.0, version='1B')
+    ref_sd = net.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), 'state-dict key mismatch (1B)'
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd)
+    net.train()
+    rgb = torch.rand(1, 3, 32, 64, generator=gen)
+    disps = net(rgb)['inv_depths']
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    disps_o = O.packnet01_forward(sdo, rgb, '1B', True)
+    for a, b in zip(disps_o, disps):
+        close(a, b.detach(), 5e-5, 'packnet01-1B.disp')
+    dys = [torch.randn(d.shape, generator=gen) for d in disps]
+    names = [n for n, _ in net.named_parameters()]
+    g = grads_of(sum((d * dy).sum() for d, dy in zip(disps, dys)), list(net.parameters()))
+    net64 = RefPackNet01(dropout=0.0, version='1B').double()
+    net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    net64.train()
+    disps64 = net64(rgb.double())['inv_depths']
+    g64 = grads_of(sum((d * dy.double()).sum() for d, dy in zip(disps64, dys)), list(net64.parameters()))
+    # SupervisedLoss: every method, sparse and dense, 2 scales (second scale exercises the nearest-resized ground truth)
+    sup = {}
+    pred0 = (0.05 + torch.rand(2, 1, 12, 20, generator=gen))
+    pred1 = (0.05 + torch.rand(2, 1, 6, 10, generator=gen))
+    gt_dense = (0.05 + torch.rand(2, 1, 12, 20, generator=gen))
+    gt_sparse = gt_dense * (torch.rand(2, 1, 12, 20, generator=gen) > 0.6).float()      # ~40 % valid (lidar-like zeros)
+    # ('dense-berhu' raises inside the reference itself: BerHuLoss concatenates a 4-D with a 1-D tensor, :53)
+    for method in ('sparse-l1', 'sparse-mse', 'sparse-berhu', 'sparse-silog', 'sparse-abs_rel', 'dense-l1', 'dense-mse',
+                   'dense-silog'):
+        gt = gt_sparse if method.startswith('sparse') else gt_dense
+        p = [pred0.clone().requires_grad_(True), pred1.clone().requires_grad_(True)]
+        ref = RefSupervisedLoss(supervised_method=method, supervised_num_scales=2)
+        out = ref(list(p), gt.clone())
+        gr = grads_of(out['loss'].sum(), p)
+        po = [pred0.clone().requires_grad_(True), pred1.clone().requires_grad_(True)]
+        lo = O.supervised_loss(po, gt, method, 2)
+        close(lo, out['loss'][0].detach(), 1e-6, 'supervised.' + method)
+        go = grads_of(lo, po)
+        for a, b in zip(go, gr):
+            close(a, b, 1e-5, 'supervised.grad.' + method)
+        sup[method] = dict(pred=[pred0, pred1], gt=gt, loss=out['loss'].detach(), dpred=gr)
+    fx['supervised'] = sup
+    # clip_loss > 0 (the constructor default of the reference's loss class is 0.5; its YAML default is 0.0)
+    fx['loss_clip'] = case_loss(gen, cases=(
+        ('loss_clip_min', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                               automask_loss=True, clip_loss=0.5), True),
+        ('loss_clip_mean', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.1, photometric_reduce_op='mean',
+                                automask_loss=False, clip_loss=0.5), False)), keep_clip=True)
+    fx['packnet01_1B'] = dict(seed=1357, rgb=rgb, disps=[d.detach() for d in disps], dys=dys,
+                              disps_f64=[d.detach() for d in disps64],
+                              grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},
+                              grad_norms={n: float(t.norm()) for n, t in zip(names, g)})
     return fx
 
 

@@ -259,10 +259,16 @@ __device__ __forceinline__ SsimTerms ssim_terms(const WinStats& w, float C1, flo
 #define PH_S2 (PH_T + 4)  // with 2-pixel halo
 
 // grid: (ceil(W/16), ceil(H/16), B); block 256 = 16x16 pixels. LDS: (1 + 2J) images x 3 ch x 18x18.
+// clip_loss > 0 (multiview_photometric_loss.py:214-219: every candidate map is clamped at mean + clip*std of ITSELF, a
+// float, so no gradient flows through the statistics) needs those statistics first: with `stats` != null the kernel only
+// accumulates sum / sum-of-squares per candidate (double[2*ncand]); a finish kernel turns them into thresholds `clip_thr`
+// [ncand] for the real pass, which clamps and records which candidates were clamped in the per-pixel byte
+// (min: argmin | clamped << 7; mean: bit mask of clamped candidates) so that backward can zero their gradient.
 __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __restrict__ warped, const float* __restrict__ ref,
                                                                const float* __restrict__ target, double* __restrict__ loss_sum,
                                                                uint8_t* __restrict__ argmin, int J, int B, int H, int W,
-                                                               float ssim_w, float C1, float C2, int automask, int reduce_op) {
+                                                               float ssim_w, float C1, float C2, int automask, int reduce_op,
+                                                               const float* __restrict__ clip_thr, double* __restrict__ stats) {
   PNSFM_DYN_SMEM(float, smem);
   __shared__ double red[4];
   const int HW = H * W;
@@ -294,7 +300,8 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
   const bool valid = gy < H && gx < W;
   const int cpos = (ly + 1) * PH_S1 + lx + 1;
   float best = 0.f, sum = 0.f;
-  int best_i = 0, ncand = 0;
+  int best_i = 0, ncand = 0, clamp_mask = 0;
+  float cl[6];
   const float* tgt = smem;
   for (int j = 0; j < J; ++j) {
     for (int id = 0; id < (automask ? 2 : 1); ++id) {
@@ -309,16 +316,28 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
         ssim_acc += fminf(fmaxf((1.f - t.ssim) * 0.5f, 0.f), 1.f);
         l1_acc += fabsf(xs[cpos] - ys[cpos]);
       }
-      const float l = ssim_w * (ssim_acc / 3.f) + (1.f - ssim_w) * (l1_acc / 3.f);
+      float l = ssim_w * (ssim_acc / 3.f) + (1.f - ssim_w) * (l1_acc / 3.f);
+      cl[ncand] = l;
+      if (clip_thr != nullptr && l > clip_thr[ncand]) { l = clip_thr[ncand]; clamp_mask |= 1 << ncand; }
       if (ncand == 0 || l < best) { best = l; best_i = ncand; }
       sum += l;
       ncand++;
     }
   }
+  if (stats != nullptr) {   // statistics pre-pass of clip_loss: nothing else is produced
+    for (int c = 0; c < ncand; ++c) {
+      const double v = valid ? (double)cl[c] : 0.0;
+      const double s1 = block_sum_256d(v, red);
+      const double s2 = block_sum_256d(v * v, red);
+      if (threadIdx.x == 0) { atomicAdd(&stats[2 * c], s1); atomicAdd(&stats[2 * c + 1], s2); }
+    }
+    return;
+  }
   float contrib = 0.f;
   if (valid) {
     contrib = reduce_op == 0 ? best : sum / (float)ncand;
-    if (reduce_op == 0) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)best_i;
+    if (reduce_op == 0) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)(best_i | (((clamp_mask >> best_i) & 1) << 7));
+    else if (clip_thr != nullptr) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)clamp_mask;
   }
   const double s = block_sum_256d((double)contrib, red);
   if (threadIdx.x == 0) atomicAdd(loss_sum, s);
@@ -330,7 +349,7 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
 __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __restrict__ warped, const float* __restrict__ target,
                                                                const uint8_t* __restrict__ argmin, float* __restrict__ d_warped,
                                                                float grad_scale, int J, int B, int H, int W, float ssim_w,
-                                                               float C1, float C2, int automask, int reduce_op) {
+                                                               float C1, float C2, int automask, int reduce_op, int clip) {
   PNSFM_DYN_SMEM(float, smem);
   const int HW = H * W;
   const int b = blockIdx.z;
@@ -357,11 +376,13 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
     const bool inside = py >= 0 && py < H && px >= 0 && px < W;
     const int cpos = (ly + 1) * PH_S2 + lx + 1;
     int sel = -1;
-    if (inside && reduce_op == 0) sel = (int)argmin[(size_t)b * HW + py * W + px];
+    if (inside && (reduce_op == 0 || clip)) sel = (int)argmin[(size_t)b * HW + py * W + px];
     for (int j = 0; j < J; ++j) {
       const int cand = j * (automask ? 2 : 1);
       float up = 0.f;
-      if (inside) up = reduce_op == 0 ? (sel == cand ? grad_scale : 0.f) : grad_scale / (float)ncand;
+      // min: the byte is argmin | clamped << 7 (a clamped winner has no gradient); mean: a bit mask of clamped candidates
+      if (inside) up = reduce_op == 0 ? (sel == cand ? grad_scale : 0.f)
+                                      : ((clip && ((sel >> cand) & 1)) ? 0.f : grad_scale / (float)ncand);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float ca = 0.f, cb = 0.f, cg = 0.f;
@@ -393,10 +414,11 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
   if (qy >= H || qx >= W) return;
   const int q2 = (ly + 2) * PH_S2 + lx + 2;
   int selq = -1;
-  if (reduce_op == 0) selq = (int)argmin[(size_t)b * HW + qy * W + qx];
+  if (reduce_op == 0 || clip) selq = (int)argmin[(size_t)b * HW + qy * W + qx];
   for (int j = 0; j < J; ++j) {
     const int cand = j * (automask ? 2 : 1);
-    const float uq = reduce_op == 0 ? (selq == cand ? grad_scale : 0.f) : grad_scale / (float)ncand;
+    const float uq = reduce_op == 0 ? (selq == cand ? grad_scale : 0.f)
+                                    : ((clip && ((selq >> cand) & 1)) ? 0.f : grad_scale / (float)ncand);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float* cp = coef + ((j * 3 + c) * 3) * plane1;
@@ -505,6 +527,40 @@ int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth,
   return check_launch("view_synthesis_backward_finish");
 }
 
+__global__ void photometric_clip_finish_kernel(const double* __restrict__ stats, float* __restrict__ thr, int ncand, double n,
+                                               float clip) {
+  const int c = threadIdx.x;
+  if (c < ncand) {
+    const double mean = stats[2 * c] / n;
+    double var = (stats[2 * c + 1] - n * mean * mean) / (n - 1.0);     // torch.std: unbiased
+    if (var < 0.0) var = 0.0;
+    thr[c] = (float)(mean + (double)clip * sqrt(var));
+  }
+}
+
+int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target, double* loss_sum,
+                                   uint8_t* argmin, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
+                                   int automask, int reduce_op, float clip_loss, double* stats_ws, float* thr_ws, void* stream) {
+  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
+  if (!(ssim_weight > 0.f)) { set_error("photometric_forward: ssim_weight must be > 0"); return -1; }
+  if (automask && reduce_op != 0) { set_error("photometric_forward: automask requires the 'min' reduce op"); return -1; }
+  if (!(clip_loss > 0.f) || !stats_ws || !thr_ws) { set_error("photometric_forward_clip: clip_loss must be > 0 with scratch buffers"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int ncand = J * (automask ? 2 : 1);
+  int e = (int)hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+  if (!e) e = (int)hipMemsetAsync(stats_ws, 0, 12 * sizeof(double), s);
+  if (e) { set_error("photometric_forward: memset failed"); return e; }
+  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+               C1, C2, automask, reduce_op, (const float*)nullptr, stats_ws);
+  PNSFM_LAUNCH(photometric_clip_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)stats_ws, thr_ws, ncand,
+               (double)B * H * W, clip_loss);
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+               C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr);
+  return check_launch("photometric_forward_clip");
+}
+
 int pnsfm_photometric_forward(const float* warped, const float* ref, const float* target, double* loss_sum, uint8_t* argmin,
                               int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
                               void* stream) {
@@ -517,19 +573,33 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op);
+               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
   return check_launch("photometric_forward");
+}
+
+static int photometric_backward_impl(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
+                                     float grad_scale, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
+                                     int automask, int reduce_op, int clip, void* stream) {
+  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_backward: bad shape (J<=3)"); return -1; }
+  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
+  PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, warped, target, argmin, d_warped,
+               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op, clip);
+  return check_launch("photometric_backward");
 }
 
 int pnsfm_photometric_backward(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
                                float grad_scale, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
                                int automask, int reduce_op, void* stream) {
-  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_backward: bad shape (J<=3)"); return -1; }
-  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
-  const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
-  PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, warped, target, argmin, d_warped,
-               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op);
-  return check_launch("photometric_backward");
+  return photometric_backward_impl(warped, target, argmin, d_warped, grad_scale, J, B, H, W, ssim_weight, C1, C2, automask,
+                                   reduce_op, 0, stream);
+}
+
+int pnsfm_photometric_backward_clip(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
+                                    float grad_scale, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
+                                    int automask, int reduce_op, void* stream) {
+  return photometric_backward_impl(warped, target, argmin, d_warped, grad_scale, J, B, H, W, ssim_weight, C1, C2, automask,
+                                   reduce_op, 1, stream);
 }
 
 int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums, int B, int H, int W, void* stream) {

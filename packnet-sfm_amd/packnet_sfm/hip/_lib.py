@@ -46,12 +46,16 @@ SIGNATURES = {
     "pnsfm_invdepth_act_backward": (_i, [_p, _p, _p, _sz, _f, _p]),
     "pnsfm_pose_vec2mat_forward": (_i, [_p, _p, _i, _p]),
     "pnsfm_pose_vec2mat_backward": (_i, [_p, _p, _p, _i, _p]),
+    "pnsfm_supervised_loss_forward": (_i, [_p, _p, _p, _p, _sz, _i, _i, _p]),
+    "pnsfm_supervised_loss_backward": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _p]),
     "pnsfm_invdepth_conv_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "pnsfm_invdepth_conv_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_photometric_forward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "pnsfm_photometric_backward": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
+    "pnsfm_photometric_forward_clip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _f, _p, _p, _p]),
+    "pnsfm_photometric_backward_clip": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "pnsfm_smoothness_forward": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_smoothness_backward": (_i, [_p, _p, _p, _f, _f, _i, _i, _i, _p]),
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),

@@ -417,6 +417,30 @@ def pose_vec2mat44(vec):
     return PoseVec2MatFn.apply(vec)
 
 
+class SupervisedLossFn(Function):
+    """One scale of the supervised inverse-depth loss (l1 / mse / abs_rel / berhu / silog, optionally only where gt > 0)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, method, sparse):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        loss, ws = ops.supervised_loss_forward(pred, gt, method, sparse)
+        ctx.save_for_backward(pred, gt, ws)
+        ctx.meta = (method, sparse)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        pred, gt, ws = ctx.saved_tensors
+        method, sparse = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        return ops.supervised_loss_backward(pred, gt, ws, g, method, sparse), None, None, None
+
+
+def supervised_loss(pred, gt, method, sparse):
+    return SupervisedLossFn.apply(pred, gt, method, sparse)
+
+
 class ViewSynthesisFn(Function):
     """warped[j] = grid_sample(ref[j], project(reconstruct(1/inv_depth))) for the J context views of one scale.
     Differentiable w.r.t. inv_depth and the [J,B,4,4] pose matrices (the context image is data)."""
@@ -447,25 +471,25 @@ class PhotometricFn(Function):
     """mean over pixels of min/mean over candidates of (w*SSIM-loss + (1-w)*L1); scalar float32."""
 
     @staticmethod
-    def forward(ctx, warped, ref, target, ssim_w, C1, C2, automask, reduce_op):
+    def forward(ctx, warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):
         warped, ref, target = warped.contiguous(), ref.contiguous(), target.contiguous()
-        loss_sum, argmin = ops.photometric_forward(warped, ref, target, ssim_w, C1, C2, automask, reduce_op)
+        loss_sum, argmin = ops.photometric_forward(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
         J, B, _, H, W = warped.shape
         ctx.save_for_backward(warped, target, argmin)
-        ctx.meta = (ssim_w, C1, C2, automask, reduce_op, B * H * W)
+        ctx.meta = (ssim_w, C1, C2, automask, reduce_op, B * H * W, clip_loss > 0.0)
         return (loss_sum / float(B * H * W)).to(torch.float32).reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         warped, target, argmin = ctx.saved_tensors
-        ssim_w, C1, C2, automask, reduce_op, n = ctx.meta
-        d = ops.photometric_backward(warped, target, argmin, 1.0 / n, ssim_w, C1, C2, automask, reduce_op)
-        return d * g, None, None, None, None, None, None, None
+        ssim_w, C1, C2, automask, reduce_op, n, clip = ctx.meta
+        d = ops.photometric_backward(warped, target, argmin, 1.0 / n, ssim_w, C1, C2, automask, reduce_op, clip)
+        return d * g, None, None, None, None, None, None, None, None
 
 
-def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op):
-    return PhotometricFn.apply(warped, ref, target, ssim_w, C1, C2, automask, reduce_op)
+def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):
+    return PhotometricFn.apply(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
 
 
 class SmoothnessFn(Function):

@@ -307,23 +307,32 @@ def view_synthesis_backward(d_warped, inv_depth, ref, K, refK, T):
     return d_inv, dT
 
 
-def photometric_forward(warped, ref, target, ssim_weight, C1, C2, automask, reduce_op):
-    """-> (loss_sum float64[1], argmin uint8[B,H,W])."""
+def photometric_forward(warped, ref, target, ssim_weight, C1, C2, automask, reduce_op, clip_loss=0.0):
+    """-> (loss_sum float64[1], argmin uint8[B,H,W]).  clip_loss > 0: candidates clamped at mean + clip_loss*std."""
     _chk(warped, ref, target); _f32(warped, ref, target)
     J, B, _, H, W = warped.shape
     loss_sum = torch.empty((1,), dtype=torch.float64, device=warped.device)
     argmin = torch.empty((B, H, W), dtype=torch.uint8, device=warped.device)
+    if clip_loss > 0.0:
+        stats = torch.empty((12,), dtype=torch.float64, device=warped.device)
+        thr = torch.empty((6,), dtype=torch.float32, device=warped.device)
+        _lib.check(_lib.get().pnsfm_photometric_forward_clip(
+            _ptr(warped), _ptr(ref), _ptr(target), _ptr(loss_sum), _ptr(argmin), J, B, H, W, float(ssim_weight), float(C1),
+            float(C2), int(automask), int(reduce_op), float(clip_loss), _ptr(stats), _ptr(thr), _stream(warped)),
+            "photometric_forward_clip")
+        return loss_sum, argmin
     _lib.check(_lib.get().pnsfm_photometric_forward(_ptr(warped), _ptr(ref), _ptr(target), _ptr(loss_sum), _ptr(argmin), J, B, H,
                                                     W, float(ssim_weight), float(C1), float(C2), int(automask), int(reduce_op),
                                                     _stream(warped)), "photometric_forward")
     return loss_sum, argmin
 
 
-def photometric_backward(warped, target, argmin, grad_scale, ssim_weight, C1, C2, automask, reduce_op):
+def photometric_backward(warped, target, argmin, grad_scale, ssim_weight, C1, C2, automask, reduce_op, clip=False):
     _chk(warped, target, argmin); _f32(warped, target)
     J, B, _, H, W = warped.shape
     d_warped = torch.empty_like(warped)
-    _lib.check(_lib.get().pnsfm_photometric_backward(_ptr(warped), _ptr(target), _ptr(argmin), _ptr(d_warped), float(grad_scale),
+    fn = _lib.get().pnsfm_photometric_backward_clip if clip else _lib.get().pnsfm_photometric_backward
+    _lib.check(fn(_ptr(warped), _ptr(target), _ptr(argmin), _ptr(d_warped), float(grad_scale),
                                                      J, B, H, W, float(ssim_weight), float(C1), float(C2), int(automask),
                                                      int(reduce_op), _stream(warped)), "photometric_backward")
     return d_warped
@@ -345,6 +354,31 @@ def smoothness_backward(inv_norm, image, gx, gy):
     _lib.check(_lib.get().pnsfm_smoothness_backward(_ptr(inv_norm), _ptr(image), _ptr(d), float(gx), float(gy), B, H, W,
                                                     _stream(image)), "smoothness_backward")
     return d
+
+
+# ---------------------------------------------------------------------------------- supervised loss
+SUP_METHODS = {'l1': 0, 'mse': 1, 'abs_rel': 2, 'berhu': 3, 'silog': 4}
+
+
+def supervised_loss_forward(pred, gt, method, sparse):
+    """pred, gt: same-shape fp32 tensors -> (loss [1] fp32, ws for the backward call)."""
+    _chk(pred, gt); _f32(pred, gt)
+    if pred.shape != gt.shape:
+        raise RuntimeError("supervised_loss: prediction %s and ground truth %s differ in shape" % (tuple(pred.shape), tuple(gt.shape)))
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    ws = torch.empty((8 + 1024,), dtype=torch.float64, device=pred.device)
+    _lib.check(_lib.get().pnsfm_supervised_loss_forward(_ptr(pred), _ptr(gt), _ptr(loss), _ptr(ws), pred.numel(), int(method),
+                                                        int(bool(sparse)), _stream(pred)), "supervised_loss_forward")
+    return loss, ws
+
+
+def supervised_loss_backward(pred, gt, ws, grad_out, method, sparse):
+    _chk(pred, gt, ws, grad_out); _f32(pred, gt, grad_out)
+    dpred = torch.empty_like(pred)
+    _lib.check(_lib.get().pnsfm_supervised_loss_backward(_ptr(pred), _ptr(gt), _ptr(ws), _ptr(grad_out), _ptr(dpred),
+                                                         pred.numel(), int(method), int(bool(sparse)), _stream(pred)),
+               "supervised_loss_backward")
+    return dpred
 
 
 # ---------------------------------------------------------------------------------------------- adam

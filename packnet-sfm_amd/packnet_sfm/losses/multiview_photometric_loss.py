@@ -50,9 +50,6 @@ class MultiViewPhotometricLoss(LossBase):
         if photometric_reduce_op not in ('min', 'mean'):
             raise NotImplementedError('Unknown photometric_reduce_op: {}'.format(photometric_reduce_op))
         # configurations the fused kernels do not cover fail loudly instead of silently taking another path
-        if clip_loss > 0.0:
-            raise NotImplementedError('clip_loss > 0 needs a global mean/std pass that the fused gfx950 photometric '
-                                      'kernel does not implement yet (all shipped self-sup configs use clip_loss: 0.0)')
         if padding_mode != 'zeros':
             raise NotImplementedError("the gfx950 view-synthesis kernel implements padding_mode='zeros' only")
         if not ssim_loss_weight > 0.0:
@@ -86,7 +83,8 @@ class MultiViewPhotometricLoss(LossBase):
                 Ki, rKi = scale_intrinsics(K32.clone(), s, s), scale_intrinsics(rK32.clone(), s, s)
             warped = HF.view_synthesis(inv_depths[i], refs_i, Ki.contiguous(), rKi.contiguous(), T)
             photometric_loss = photometric_loss + HF.photometric(
-                warped, refs_i, images[i], self.ssim_loss_weight, self.C1, self.C2, bool(self.automask_loss), reduce_op)
+                warped, refs_i, images[i], self.ssim_loss_weight, self.C1, self.C2, bool(self.automask_loss), reduce_op,
+                float(self.clip_loss))
         photometric_loss = photometric_loss / n
         self.add_metric('photometric_loss', photometric_loss)
         loss = photometric_loss

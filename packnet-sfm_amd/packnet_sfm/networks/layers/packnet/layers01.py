@@ -57,21 +57,26 @@ class ResidualConv(nn.Module):
         self.conv2 = Conv2D(out_channels, out_channels, 3, 1)
         self.conv3 = _HipConv2d(in_channels, out_channels, 1, stride)
         self.normalize = nn.GroupNorm(16, out_channels)
-        self.dropout = dropout if dropout else None
+        if dropout:
+            # as the reference (layers01.py:64-65): the shortcut becomes Sequential(conv3, Dropout2d), so the state-dict
+            # keys are conv3.0.weight / conv3.0.bias exactly like checkpoints trained with dropout
+            self.conv3 = nn.Sequential(self.conv3, nn.Dropout2d(dropout))
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        # reference checkpoints trained with dropout hold the shortcut as nn.Sequential(conv3, Dropout2d): conv3.0.*
+        # accept either key layout (conv3.* <-> conv3.0.*) so that a checkpoint trained with dropout loads into a model
+        # built without it and vice versa
+        has_seq = isinstance(self.conv3, nn.Sequential)
         for name in ('weight', 'bias'):
-            old = prefix + 'conv3.0.' + name
-            if old in state_dict:
-                state_dict[prefix + 'conv3.' + name] = state_dict.pop(old)
+            plain, seq = prefix + 'conv3.' + name, prefix + 'conv3.0.' + name
+            if has_seq and plain in state_dict and seq not in state_dict:
+                state_dict[seq] = state_dict.pop(plain)
+            elif not has_seq and seq in state_dict and plain not in state_dict:
+                state_dict[plain] = state_dict.pop(seq)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x):
         main = self.conv2(self.conv1(x))
         shortcut = self.conv3(x)
-        if self.dropout and self.training:
-            shortcut = F.dropout2d(shortcut, self.dropout, True)
         return HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
                                 res=shortcut)
 

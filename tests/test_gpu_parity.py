@@ -60,11 +60,40 @@ def test_packnetslim01_golden():
     P.case_packnetslim01(DEV)
 
 
+def test_packnet01_version_1B_golden():
+    """Skip connections added instead of concatenated (PackNet01.py:46-52,142-176)."""
+    P.case_packnetslim01(DEV, variant='1B')
+
+
+def test_dropout_and_eval_contract():
+    """dropout > 0 drops whole shortcut channels in training only (layers01.py:64-65); eval returns ONE tensor and is
+    dropout-free (PackNet01.py:178-185)."""
+    from packnet_sfm.networks.depth.PackNetSlim01 import PackNetSlim01
+    torch.manual_seed(0)
+    net = PackNetSlim01(dropout=0.5, version='1A').to(DEV)
+    rgb = torch.rand(1, 3, 64, 96, device=DEV)
+    net.train()
+    a = net(rgb=rgb)['inv_depths']
+    b = net(rgb=rgb)['inv_depths']
+    assert isinstance(a, list) and len(a) == 4
+    assert not torch.equal(a[0], b[0])                      # two different dropout masks
+    net.eval()
+    with torch.no_grad():
+        e1, e2 = net(rgb=rgb)['inv_depths'], net(rgb=rgb)['inv_depths']
+    assert torch.is_tensor(e1) and tuple(e1.shape) == (1, 1, 64, 96)
+    P.check(e1, e2, 1e-5, 'eval is dropout-free (equal up to the fp32 atomics order of split-K layers)')
+    assert any(k.startswith('conv2.0.conv3.0.') for k in net.state_dict())   # reference key layout with dropout
+
+
+def test_supervised_loss_golden():
+    P.case_supervised_loss(DEV)
+
+
 def test_unpack_golden():
     P.case_unpack(DEV)
 
 
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean'])
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean'])
 def test_loss_golden(name):
     P.case_loss(name, DEV)
 

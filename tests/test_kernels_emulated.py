@@ -75,7 +75,7 @@ def test_compose_pack_weight(emulated_kernels):
     P.check(col[:, :, r:-r, r:-r], ref[:, :, r:-r, r:-r], 1e-5, 'interior equality')
 
 
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean'])
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean'])
 def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
@@ -152,6 +152,48 @@ def test_invdepth_conv_raw(emulated_kernels, shape):
     P.check(xd.grad, xr.grad, 1e-5, 'invdepth dx')
     P.check(wd.grad, wr.grad, 1e-5, 'invdepth dw')
     P.check(bd.grad, br.grad, 1e-5, 'invdepth db')
+
+
+def test_supervised_loss(emulated_kernels):
+    P.case_supervised_loss('cpu')
+
+
+def test_semisup_model_plumbing(emulated_kernels):
+    """SemiSupModel with supervised_loss_weight = 1 (no pose network): loss == SupervisedLoss on the depth net's output,
+    metrics merged, eval returns the plain SfmModel output.  A stub depth network keeps the emulation fast."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.models.SemiSupModel import SemiSupModel
+
+    class StubDepth(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor(0.7))
+
+        def forward(self, rgb):
+            d = 0.1 + self.w * rgb.mean(1, keepdim=True)
+            scales = [d, d[:, :, ::2, ::2], d[:, :, ::4, ::4], d[:, :, ::8, ::8]]
+            return {'inv_depths': scales if self.training else d}
+
+    g = torch.Generator().manual_seed(5)
+    model = SemiSupModel(supervised_loss_weight=1.0, supervised_method='sparse-l1', supervised_num_scales=4,
+                         flip_lr_prob=0.0, upsample_depth_maps=True)
+    assert 'pose_net' not in model.network_requirements and 'gt_depth' in model.train_requirements
+    model.add_depth_net(StubDepth())
+    batch = {'rgb': torch.rand(2, 3, 16, 24, generator=g),
+             'depth': 5.0 * torch.rand(2, 1, 16, 24, generator=g) * (torch.rand(2, 1, 16, 24, generator=g) > 0.5).float()}
+    model.train()
+    out = model(batch)
+    assert set(out['metrics']) == {'supervised_loss'} and out['poses'] is None
+    inv = [t.detach() for t in out['inv_depths']]
+    gt_inv = 1. / batch['depth'].clamp(min=1e-6)
+    gt_inv[batch['depth'] <= 0] = 0.
+    P.check(out['loss'], O.supervised_loss(inv, gt_inv, 'sparse-l1', 4).reshape(1), 1e-5, 'semi-sup loss')
+    out['loss'].sum().backward()
+    assert model.depth_net.w.grad is not None and torch.isfinite(model.depth_net.w.grad)
+    model.eval()
+    with torch.no_grad():
+        ev = model(batch)
+    assert torch.is_tensor(ev['inv_depths']) and 'loss' not in ev
 
 
 def test_pose_vec2mat(emulated_kernels):

@@ -45,10 +45,24 @@ def test_oracle_d4_blocks_and_packnetslim01():
     disps = O.packnet01_forward(sd, fx['rgb'], '1A', True)
     for a, b in zip(disps, fx['disps']):
         P.check(a, b, 5e-5, 'packnetslim01 disp')
+    fx = S['packnet01_1B']
+    sd = O.init_params(O.packnet01_param_shapes('1B'), seed=fx['seed'], randomize_affine=True)
+    for a, b in zip(O.packnet01_forward(sd, fx['rgb'], '1B', True), fx['disps']):
+        P.check(a, b, 5e-5, 'packnet01 1B disp')
+
+
+def test_oracle_supervised_loss():
+    for method, fx in P.golden('slim')['supervised'].items():
+        pred = [t.clone().requires_grad_(True) for t in fx['pred']]
+        loss = O.supervised_loss(pred, fx['gt'], method, 2)
+        P.check(loss, fx['loss'][0], 1e-6, 'supervised ' + method)
+        loss.backward()
+        for p, g in zip(pred, fx['dpred']):
+            P.check(p.grad, g, 1e-5, 'supervised grad ' + method)
 
 
 def test_oracle_loss_and_grads():
-    for name, fx in P.golden('loss').items():
+    for name, fx in list(P.golden('loss').items()) + list(P.golden('slim')['loss_clip'].items()):
         inv = [t.clone().requires_grad_(True) for t in fx['inv_depths']]
         pv = fx['pose_vec'].clone().requires_grad_(True)
         mats = [O.pose_vec2mat44(pv[:, i]) for i in range(2)]

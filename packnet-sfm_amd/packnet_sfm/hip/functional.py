@@ -56,6 +56,104 @@ class PackedConvWeight:
         return self.wp_fwd, (self.wp_bwd if need_bwd else None)
 
 
+class _WgradStream:
+    """Weight gradients on a side HIP stream (PNSFM_WGRAD_STREAM=1).
+
+    Within a layer's backward the data gradient is on the critical path (the next layer waits for it) while the weight
+    gradient is only needed by the optimizer / the gradient all-reduce.  With a second stream the GPU can co-schedule
+    the two kernels -- the low-resolution layers cannot fill 256 CUs on their own -- and the tail of one hides under
+    the other.  Ordering: the side stream waits for the compute stream before each weight gradient (dy is ready), the
+    inputs are `record_stream`-ed so the caching allocator does not recycle them early, and the compute stream joins the
+    side stream once, from an autograd-engine callback at the end of the backward pass (before any optimizer / reducer
+    kernel can touch the gradients).
+
+    Only gradients of LEAF parameters that are used ONCE in the step go to the side stream: their sole consumer is the
+    engine's AccumulateGrad (a pointer hand-over, no kernel).  A non-leaf weight (the composed kernel of the collapsed
+    packing block) or a parameter used by several nodes (that block's Conv2d / Conv3d weights) has its gradient read or
+    accumulated by compute-stream kernels during the same backward pass: for those the weight gradient still runs on the
+    side stream next to the node's own data gradient, but the compute stream waits for it before the node returns.
+    """
+    import os as _os
+    enabled = _os.environ.get('PNSFM_WGRAD_STREAM', '1') == '1'
+    _streams = {}
+    _pending = set()
+    _uses = {}          # id(parameter) -> [forward uses whose backward has not run yet, shared-in-this-step flag]
+
+    @classmethod
+    def note_use(cls, *params):
+        """Called in forward for every parameter a node will produce a gradient for."""
+        for p in params:
+            if p is not None:
+                u = cls._uses.setdefault(id(p), [0, False])
+                u[0] += 1
+                if u[0] > 1:
+                    u[1] = True
+
+    @classmethod
+    def side_ok(cls, *params):
+        """Called once in backward: may this node's parameter gradients be left in flight on the side stream until the
+        end-of-backward join (True), or must the node wait for them itself (False)?"""
+        ok = True
+        for p in params:
+            if p is None:
+                continue
+            u = cls._uses.get(id(p))
+            if not p.is_leaf or u is None or u[1]:
+                ok = False
+            if u is not None:
+                u[0] -= 1
+                if u[0] <= 0:
+                    del cls._uses[id(p)]
+        return ok
+
+    @classmethod
+    def get(cls, device):
+        st = cls._streams.get(device)
+        if st is None:
+            st = cls._streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    @classmethod
+    def run(cls, fn, *tensors, detached=True):
+        """fn() -> outputs, executed on the side stream of tensors[0].device.  detached: nothing on the compute stream
+        will touch the outputs before the end-of-backward join; otherwise returns (outputs, wait) and the caller must
+        call wait() on the compute stream after it has enqueued its own independent work."""
+        dev = tensors[0].device
+        side, main = cls.get(dev), torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+            ev = None if detached else side.record_event()
+        for t in tensors:
+            t.record_stream(side)
+        if not detached:
+            for o in out:
+                if o is not None:
+                    o.record_stream(main)
+            return out, (lambda: main.wait_event(ev))
+        if dev not in cls._pending:
+            cls._pending.add(dev)
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(lambda: cls.join(dev))
+        return out
+
+    @classmethod
+    def join(cls, dev):
+        cls._pending.discard(dev)
+        torch.cuda.current_stream(dev).wait_stream(cls.get(dev))
+
+
+def set_wgrad_stream(on):
+    _WgradStream.enabled = bool(on)
+
+
+def join_wgrad_stream(device):
+    """Make the current stream of `device` wait for every weight gradient launched so far (no-op when unused).
+    The gradient all-reduce calls this before it gathers a bucket in the middle of the backward pass."""
+    if device.type == 'cuda' and device in _WgradStream._streams:
+        torch.cuda.current_stream(device).wait_stream(_WgradStream._streams[device])
+
+
 class Conv2dFn(Function):
     """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (exact-fp32 MFMA implicit GEMM)."""
 
@@ -70,6 +168,8 @@ class Conv2dFn(Function):
         y = ops.conv2d_forward(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
+        ctx.params = (weight, bias)
+        _WgradStream.note_use(weight, bias)
         return y
 
     @staticmethod
@@ -79,10 +179,19 @@ class Conv2dFn(Function):
         Cin, Cout, ks, has_bias = ctx.meta
         dy = dy.contiguous()
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        detached = _WgradStream.side_ok(*ctx.params)
+        wait = None
+        if want_w and _WgradStream.enabled and dy.is_cuda:
+            r = _WgradStream.run(lambda: ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias), x, dy, detached=detached)
+            (dw, db), wait = (r, None) if detached else r
+            want_w = False
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        if want_w:
             dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias)
+        if wait is not None:
+            wait()
         return dx, dw, db, None
 
 
@@ -103,6 +212,8 @@ class Conv2dStride2Fn(Function):
         y = ops.conv2d_forward_strided(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks, 2)
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
+        ctx.params = (weight, bias)
+        _WgradStream.note_use(weight, bias)
         return y
 
     @staticmethod
@@ -112,13 +223,23 @@ class Conv2dStride2Fn(Function):
         Cin, Cout, ks, has_bias = ctx.meta
         dy = dy.contiguous()
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        detached = _WgradStream.side_ok(*ctx.params)
+        wait = None
+        if want_w and _WgradStream.enabled and dy.is_cuda:
+            r = _WgradStream.run(lambda: ops.conv2d_backward_weight_strided(x, dy, ks, 2, want_bias=has_bias), x, dy,
+                                 detached=detached)
+            (dw, db), wait = (r, None) if detached else r
+            want_w = False
         if ctx.needs_input_grad[0]:
             B, _, H, W = x.shape
             up = dy.new_zeros((B, Cout, H, W))
             up[:, :, ::2, ::2] = dy                      # dy[y][x] sits at (2y, 2x) of the input grid
             dx = ops.conv2d_backward_data(up, wp_bwd, Cin, ks)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        if want_w:
             dw, db = ops.conv2d_backward_weight_strided(x, dy, ks, 2, want_bias=has_bias)
+        if wait is not None:
+            wait()
         return dx, dw, db, None
 
 
@@ -191,6 +312,8 @@ class Conv3d1to8Fn(Function):
         p = p.contiguous()
         out = ops.conv3d_forward(p, w3.detach().contiguous(), b3.detach().contiguous())
         ctx.save_for_backward(p, w3)
+        ctx.params = (w3, b3)
+        _WgradStream.note_use(w3, b3)
         return out
 
     @staticmethod
@@ -199,10 +322,19 @@ class Conv3d1to8Fn(Function):
         p, w3 = ctx.saved_tensors
         dout = dout.contiguous()
         dp = dw3 = db3 = None
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        detached = _WgradStream.side_ok(*ctx.params)
+        wait = None
+        if want_w and _WgradStream.enabled and dout.is_cuda:
+            r = _WgradStream.run(lambda: ops.conv3d_backward_weight(p, dout), p, dout, detached=detached)
+            (dw3, db3), wait = (r, None) if detached else r
+            want_w = False
         if ctx.needs_input_grad[0]:
             dp = ops.conv3d_backward_data(dout, w3.detach().contiguous())
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if want_w:
             dw3, db3 = ops.conv3d_backward_weight(p, dout)
+        if wait is not None:
+            wait()
         return dp, dw3, db3
 
 
@@ -225,6 +357,8 @@ class ComposePackWeightFn(Function):
         w3 = W3.detach().contiguous()
         Weff = ops.conv3d_backward_data(W2pad, w3)                                    # [C, D, k+2, k+2]
         ctx.save_for_backward(W2pad, w3)
+        ctx.params = (W2, W3)
+        _WgradStream.note_use(W2, W3)
         return Weff
 
     @staticmethod
@@ -232,6 +366,7 @@ class ComposePackWeightFn(Function):
     def backward(ctx, g):
         W2pad, w3 = ctx.saved_tensors
         g = g.contiguous()
+        _WgradStream.side_ok(*ctx.params)            # bookkeeping only: this node always runs on the compute stream
         dW2 = dW3 = None
         if ctx.needs_input_grad[0]:
             dW2 = ops.conv3d_forward(g, w3, torch.zeros(w3.shape[0], device=g.device, dtype=g.dtype))[:, :, 1:-1, 1:-1].contiguous()

@@ -119,6 +119,9 @@ class GradBucketReducer:
     @staticmethod
     def _gather(bucket):
         """Copy the bucket's gradients into its flat buffer with one multi-tensor launch and alias p.grad to the views."""
+        # weight gradients may still be in flight on the side stream of hip/functional.py:_WgradStream
+        from packnet_sfm.hip import functional as HF
+        HF.join_wgrad_stream(bucket.flat.device)
         src, dst = [], []
         for p, v in zip(bucket.params, bucket.views):
             g = p.grad

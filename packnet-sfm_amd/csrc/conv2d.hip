@@ -468,11 +468,10 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
 // forward:  wp[tap][ci][co]            = w[co][ci][tap]                (K = Cin,  M = Cout)
 // backward: wp[tap][co][ci]            = w[co][ci][KK-1-tap]           (K = Cout, M = Cin; taps flipped)
 // Both go through LDS so that global reads (tap fastest) and writes (M fastest) are both contiguous.
-__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                        int Cin, int Cout, int KK, int KP, int MP) {
-  __shared__ float tile[64 * 49];
-  const int ci = blockIdx.x;       // < KP
-  const int co0 = blockIdx.y * 64;
+__device__ __forceinline__ void pack_fwd_block(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                                int KK, int KP, int MP, int bx, int by, float* tile) {
+  const int ci = bx;       // < KP
+  const int co0 = by * 64;
   const int n = 64 * KK;
   for (int e = threadIdx.x; e < n; e += 256) {
     const int col = e / KK, tap = e - col * KK;  // read order: tap fastest
@@ -489,11 +488,10 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(256) pack_bwd_kernel(const float* __restrict__ w, float* __restrict__ wp,
-                                                        int Cin, int Cout, int KK, int KP, int MP) {
-  __shared__ float tile[64 * 49];
-  const int co = blockIdx.x;       // < KP (K dimension = Cout)
-  const int ci0 = blockIdx.y * 64;
+__device__ __forceinline__ void pack_bwd_block(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                                int KK, int KP, int MP, int bx, int by, float* tile) {
+  const int co = bx;       // < KP (K dimension = Cout)
+  const int ci0 = by * 64;
   const int n = 64 * KK;
   for (int e = threadIdx.x; e < n; e += 256) {
     const int col = e / KK, tap = e - col * KK;
@@ -507,6 +505,21 @@ __global__ void __launch_bounds__(256) pack_bwd_kernel(const float* __restrict__
     const int tap = e >> 6, col = e & 63;
     const int ci = ci0 + col;
     if (ci < MP) wp[((size_t)(KK - 1 - tap) * KP + co) * MP + ci] = tile[col * KK + tap];
+  }
+}
+
+// One launch packs both layouts: the first nf = KPf * ceil(MPf/64) blocks write the forward layout, the following
+// KPb * ceil(MPb/64) blocks the backward layout (nf = 0 / no further blocks when a pointer is null).
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp_fwd,
+                                                            float* __restrict__ wp_bwd, int Cin, int Cout, int KK, int KPf,
+                                                            int MPf, int KPb, int MPb, int nf) {
+  __shared__ float tile[64 * 49];
+  int blk = blockIdx.x;
+  if (blk < nf) {
+    pack_fwd_block(w, wp_fwd, Cin, Cout, KK, KPf, MPf, blk % KPf, blk / KPf, tile);
+  } else {
+    blk -= nf;
+    pack_bwd_block(w, wp_bwd, Cin, Cout, KK, KPb, MPb, blk % KPb, blk / KPb, tile);
   }
 }
 
@@ -747,19 +760,11 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("pack_weights: unsupported kernel size %d", ks); return -1; }
   hipStream_t s = (hipStream_t)stream;
   const int KK = ks * ks;
-  if (wp_fwd) {
-    const int KP = conv_pack_KP(Cin), MP = conv_pack_MP(Cout);
-    PNSFM_LAUNCH(pack_fwd_kernel, dim3(KP, ceil_div(MP, 64)), dim3(256), 0, s, w, wp_fwd, Cin, Cout, KK, KP, MP);
-    int e = check_launch("pack_fwd");
-    if (e) return e;
-  }
-  if (wp_bwd) {
-    const int KP = conv_pack_KP(Cout), MP = conv_pack_MP(Cin);
-    PNSFM_LAUNCH(pack_bwd_kernel, dim3(KP, ceil_div(MP, 64)), dim3(256), 0, s, w, wp_bwd, Cin, Cout, KK, KP, MP);
-    int e = check_launch("pack_bwd");
-    if (e) return e;
-  }
-  return 0;
+  if (!wp_fwd && !wp_bwd) return 0;
+  const int KPf = conv_pack_KP(Cin), MPf = conv_pack_MP(Cout), KPb = conv_pack_KP(Cout), MPb = conv_pack_MP(Cin);
+  const int nf = wp_fwd ? KPf * ceil_div(MPf, 64) : 0, nb = wp_bwd ? KPb * ceil_div(MPb, 64) : 0;
+  PNSFM_LAUNCH(pack_weights_kernel, dim3(nf + nb), dim3(256), 0, s, w, wp_fwd, wp_bwd, Cin, Cout, KK, KPf, MPf, KPb, MPb, nf);
+  return check_launch("pack_weights");
 }
 
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin, int Cout,

@@ -18,6 +18,19 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+# Fused / multi-tensor optimizers (torch.optim.Adam(fused=True), the one bench.py uses) update parameters WITHOUT bumping
+# tensor._version, so the version alone cannot tell a packed weight copy is stale.  Every optimizer step of any
+# torch.optim optimizer therefore advances the epoch (global post-step hook), which re-packs each conv weight on its next
+# use: one read + two writes of the weight per step (~1.5 GB for PackNet01), inside the timed region of the bench.
+# (Re-packing all weights right away on a side stream, underneath the next forward pass, measured slower: 82.7 vs 84.7
+# img/s -- ~110 tiny launches contending with the first layers -- so packing stays lazy, in front of each conv.)
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(lambda optimizer, args, kwargs: bump_weight_epoch())
+except ImportError:      # older torch: callers must invalidate themselves (FlatAdam does)
+    pass
+
+
 class PackedConvWeight:
     """Per-layer cache of the MFMA-friendly weight layouts ([k*k][K][M], see csrc/conv2d.hip).
 

@@ -244,6 +244,32 @@ def test_conv3d_vs_cpu_oracle():
         P.check(bd.grad, br.grad, 1e-4, 'conv3d dbias')
 
 
+@pytest.mark.parametrize('opt_kw', [dict(fused=True), dict(foreach=True), dict()])
+def test_packed_weights_follow_the_optimizer(opt_kw):
+    """The conv layers keep MFMA-packed copies of their weights; they must be refreshed after EVERY optimizer step, also
+    for fused optimizers that do not bump tensor._version.  Three Adam steps of a Conv2D block (HIP) vs the same block in
+    the oracle's math under an identical optimizer."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    torch.manual_seed(3)
+    m = Conv2D(8, 32, 3, 1).to(DEV)      # 2 channels per GroupNorm group: the conv bias has a real (non-zero) gradient
+    sd = {'l.' + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = torch.randn(2, 8, 24, 32, device=DEV)
+    tgt = torch.randn(2, 32, 24, 32, device=DEV)
+    oa = torch.optim.Adam(m.parameters(), lr=1e-2, **opt_kw)
+    ob = torch.optim.Adam(list(sd.values()), lr=1e-2, **opt_kw)
+    for step in range(3):
+        la = ((m(x) - tgt) ** 2).mean()
+        lb = ((O.conv2d_gn_elu(x, sd, 'l', 3) - tgt) ** 2).mean()
+        P.check(la, lb, 1e-5, 'loss at step %d' % step)
+        oa.zero_grad(); ob.zero_grad()
+        la.backward(); lb.backward()
+        oa.step(); ob.step()
+    for k, v in m.state_dict().items():
+        P.check(v, sd['l.' + k], 1e-4, 'parameter ' + k)
+    P.check(m(x), O.conv2d_gn_elu(x, sd, 'l', 3), 1e-4, 'forward after 3 steps')
+
+
 def test_adam_vs_torch():
     from packnet_sfm.hip import ops
     g = torch.Generator().manual_seed(3)

@@ -183,14 +183,33 @@ def main():
 
     if rank == 0 and args.layer_table and not args.no_prof:
         ops.prof_dump(args.layer_table)
+    timed = None
+    if not args.no_prof:
+        timed = (ops.prof_collect(0), ops.prof_collect(1))
+        # The timed region overlaps every weight-gradient kernel with the data-gradient chain on a second HIP stream
+        # (DESIGN.md 3e), so its per-launch durations are those of kernels SHARING the GPU.  Two extra, untimed steps
+        # with the side stream off give the same kernels' durations in isolation (kernel quality, not step throughput).
+        from packnet_sfm.hip import functional as HF
+        was = HF._WgradStream.enabled
+        HF.set_wgrad_stream(False)
+        step()
+        fence()
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(2):
+            step()
+        fence()
+        ops.prof_enable(False)
+        HF.set_wgrad_stream(was)
     if rank == 0:
         images = B * world * args.steps
         value = images / elapsed
         scale = (H * W) / (192.0 * 640.0)
         roofline = None
         if not args.no_prof:
-            ms0, fl0, n0 = ops.prof_collect(0)   # conv2d_mfma_kernel (forward + backward-data)
-            ms1, fl1, n1 = ops.prof_collect(1)   # conv2d_wgrad_kernel
+            (ms0, fl0, n0), (ms1, fl1, n1) = timed     # conv2d_mfma_kernel (forward + backward-data), conv2d_wgrad_kernel
+            ims0, ifl0, in0 = ops.prof_collect(0)
+            ims1, ifl1, in1 = ops.prof_collect(1)
             if n0 > 0 and ms0 > 0:
                 ach = fl0 / (ms0 * 1e-3) / 1e12
                 roofline = {
@@ -201,7 +220,12 @@ def main():
                     'flop_per_launch_avg': round(fl0 / n0, 1),
                     'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,
                                      'launches': int(n1), 'avg_launch_ms': round(ms1 / max(n1, 1), 4)},
-                    'conv_time_share_of_step': round((ms0 + ms1) * 1e-3 / elapsed, 4),
+                    'conv_kernel_time_over_step_time': round((ms0 + ms1) * 1e-3 / elapsed, 4),   # > 1: the two streams overlap
+                    'isolated': {       # same kernels, 2 extra steps with the weight-gradient side stream off
+                        'achieved': round(ifl0 / (ims0 * 1e-3) / 1e12, 2) if ims0 > 0 else None,
+                        'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
+                        'avg_launch_ms': round(ims0 / max(in0, 1), 4),
+                        'wgrad_achieved': round(ifl1 / (ims1 * 1e-3) / 1e12, 2) if ims1 > 0 else None},
                     'whole_step_vs_mfma_peak': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                 }
         result = {

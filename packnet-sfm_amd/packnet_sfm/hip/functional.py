@@ -91,12 +91,17 @@ class _WgradStream:
     _streams = {}
     _pending = set()
     _uses = {}          # id(parameter) -> [forward uses whose backward has not run yet, shared-in-this-step flag]
+    _cb_queued = False
 
     @classmethod
-    def note_use(cls, *params):
-        """Called in forward for every parameter a node will produce a gradient for."""
+    def note_use(cls, ctx, *params):
+        """Called in forward for every parameter a node will produce a gradient for (no-op when the node is not being
+        recorded, e.g. validation under torch.no_grad()).  Entries of graphs that are never back-propagated make the next
+        step fall back to the in-node wait and are dropped at the end of that step's backward pass."""
+        if not any(ctx.needs_input_grad):
+            return
         for p in params:
-            if p is not None:
+            if p is not None and p.requires_grad:
                 u = cls._uses.setdefault(id(p), [0, False])
                 u[0] += 1
                 if u[0] > 1:
@@ -107,6 +112,10 @@ class _WgradStream:
         """Called once in backward: may this node's parameter gradients be left in flight on the side stream until the
         end-of-backward join (True), or must the node wait for them itself (False)?"""
         ok = True
+        if not cls._cb_queued:          # first parameter gradient of this backward pass: arrange the end-of-pass clean-up
+            cls._cb_queued = True
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(cls._end_of_backward)
         for p in params:
             if p is None:
                 continue
@@ -144,16 +153,18 @@ class _WgradStream:
                 if o is not None:
                     o.record_stream(main)
             return out, (lambda: main.wait_event(ev))
-        if dev not in cls._pending:
-            cls._pending.add(dev)
-            from torch.autograd import Variable
-            Variable._execution_engine.queue_callback(lambda: cls.join(dev))
+        cls._pending.add(dev)            # joined by _end_of_backward (queued by side_ok, which every caller ran first)
         return out
 
     @classmethod
-    def join(cls, dev):
-        cls._pending.discard(dev)
-        torch.cuda.current_stream(dev).wait_stream(cls.get(dev))
+    def _end_of_backward(cls):
+        """Autograd-engine callback at the end of a backward pass: the compute streams wait for the weight gradients
+        still in flight, and the per-pass use counts are dropped."""
+        cls._cb_queued = False
+        for dev in list(cls._pending):
+            torch.cuda.current_stream(dev).wait_stream(cls.get(dev))
+        cls._pending.clear()
+        cls._uses.clear()
 
 
 def set_wgrad_stream(on):
@@ -182,7 +193,7 @@ class Conv2dFn(Function):
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
-        _WgradStream.note_use(weight, bias)
+        _WgradStream.note_use(ctx, weight, bias)
         return y
 
     @staticmethod
@@ -226,7 +237,7 @@ class Conv2dStride2Fn(Function):
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
-        _WgradStream.note_use(weight, bias)
+        _WgradStream.note_use(ctx, weight, bias)
         return y
 
     @staticmethod
@@ -326,7 +337,7 @@ class Conv3d1to8Fn(Function):
         out = ops.conv3d_forward(p, w3.detach().contiguous(), b3.detach().contiguous())
         ctx.save_for_backward(p, w3)
         ctx.params = (w3, b3)
-        _WgradStream.note_use(w3, b3)
+        _WgradStream.note_use(ctx, w3, b3)
         return out
 
     @staticmethod
@@ -371,7 +382,7 @@ class ComposePackWeightFn(Function):
         Weff = ops.conv3d_backward_data(W2pad, w3)                                    # [C, D, k+2, k+2]
         ctx.save_for_backward(W2pad, w3)
         ctx.params = (W2, W3)
-        _WgradStream.note_use(W2, W3)
+        _WgradStream.note_use(ctx, W2, W3)
         return Weff
 
     @staticmethod

@@ -206,6 +206,7 @@ def main():
         value = images / elapsed
         scale = (H * W) / (192.0 * 640.0)
         roofline = None
+        traffic = measured_traffic()
         if not args.no_prof:
             (ms0, fl0, n0), (ms1, fl1, n1) = timed     # conv2d_mfma_kernel (forward + backward-data), conv2d_wgrad_kernel
             ims0, ifl0, in0 = ops.prof_collect(0)
@@ -215,7 +216,9 @@ def main():
                 roofline = {
                     'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)',
                     'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': measured_traffic(),
+                    'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
+                    'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
                     'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4),
                     'flop_per_launch_avg': round(fl0 / n0, 1),
                     'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,

@@ -147,11 +147,11 @@ class _WgradStream:
             out = fn()
             ev = None if detached else side.record_event()
         for t in tensors:
-            t.record_stream(side)
+            t.record_stream(side)           # inputs live in the compute stream's pool but are read here
+        for o in out:
+            if o is not None:
+                o.record_stream(main)       # outputs live in the side stream's pool but are consumed on the compute stream
         if not detached:
-            for o in out:
-                if o is not None:
-                    o.record_stream(main)
             return out, (lambda: main.wait_event(ev))
         cls._pending.add(dev)            # joined by _end_of_backward (queued by side_ok, which every caller ran first)
         return out

@@ -162,6 +162,14 @@ int pnsfm_view_synthesis_forward(const float* inv_depth, const float* ref, const
 int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth, const float* ref,
                                   const float* K, const float* refK, const float* T,
                                   float* d_inv_depth, float* dT, double* ws, int J, int B, int H, int W, void* stream);
+/* The same with grid_sample's other padding modes (camera_utils.py:58-59, `padding_mode` of the loss config):
+ * padding_mode 0 = 'zeros' (the two entry points above), 1 = 'border', 2 = 'reflection' (align_corners=True). */
+int pnsfm_view_synthesis_forward_pad(const float* inv_depth, const float* ref, const float* K, const float* refK,
+                                     const float* T, float* warped, int J, int B, int H, int W, int padding_mode,
+                                     void* stream);
+int pnsfm_view_synthesis_backward_pad(const float* d_warped, const float* inv_depth, const float* ref,
+                                      const float* K, const float* refK, const float* T, float* d_inv_depth, float* dT,
+                                      double* ws, int J, int B, int H, int W, int padding_mode, void* stream);
 
 /* ---- photometric loss of one scale: SSIM + L1, automask, min/mean reduce -------------------
  * replaces SSIM() :14-53, MultiViewPhotometricLoss.SSIM :169-186, calc_photometric_loss :188-223

@@ -402,6 +402,12 @@ def case_slim(gen):
                                automask_loss=True, clip_loss=0.5), True),
         ('loss_clip_mean', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.1, photometric_reduce_op='mean',
                                 automask_loss=False, clip_loss=0.5), False)), keep_clip=True)
+    # grid_sample padding modes other than the YAML default 'zeros'
+    fx['loss_padding'] = case_loss(gen, cases=(
+        ('loss_border', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                             automask_loss=True, clip_loss=0.0, padding_mode='border'), True),
+        ('loss_reflection', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='mean',
+                                 automask_loss=False, clip_loss=0.0, padding_mode='reflection'), False)), keep_clip=True)
     fx['packnet01_1B'] = dict(seed=1357, rgb=rgb, disps=[d.detach() for d in disps], dys=dys,
                               disps_f64=[d.detach() for d in disps64],
                               grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},

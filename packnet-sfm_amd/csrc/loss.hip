@@ -70,11 +70,33 @@ __device__ __forceinline__ void project_pixel(const Cam& c, const float* T, floa
   q.iy = ((yn + 1.f) * 0.5f) * (float)(H - 1);
 }
 
+// grid_sample padding modes (align_corners=True), ATen's grid_sampler_compute_source_index_set_grad:
+//   0 zeros      : coordinates are used as they are, out-of-image corners contribute 0
+//   1 border     : clip to [0, size-1]; d(clipped)/d(coordinate) = 0 outside
+//   2 reflection : reflect about 0 and size-1 (period 2(size-1)), then clip; the multiplier carries the reflection's sign
+__device__ __forceinline__ float pad_coordinate(float x, int size, int mode, float& mult) {
+  mult = 1.f;
+  if (mode == 0) return x;
+  const float hi = (float)(size - 1);
+  if (mode == 2) {
+    if (hi <= 0.f) { mult = 0.f; return 0.f; }
+    float m = 1.f;
+    if (x < 0.f) { x = -x; m = -1.f; }
+    const float extra = fmodf(x, hi);
+    const int flips = (int)floorf(x / hi);
+    if (flips & 1) { x = hi - extra; m = -m; } else { x = extra; }
+    mult = m;
+  }
+  if (x <= 0.f) { mult = 0.f; return 0.f; }      // clip (ATen: gradient 0 at and beyond the border)
+  if (x >= hi) { mult = 0.f; return hi; }
+  return x;
+}
+
 // grid: (ceil(HW/256), B, J)
 __global__ void __launch_bounds__(256) view_synthesis_fwd_kernel(const float* __restrict__ inv_depth, const float* __restrict__ ref,
                                                                   const float* __restrict__ K, const float* __restrict__ refK,
                                                                   const float* __restrict__ T, float* __restrict__ warped,
-                                                                  int B, int H, int W) {
+                                                                  int B, int H, int W, int pad_mode) {
   const int HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y, j = blockIdx.z;
@@ -88,6 +110,9 @@ __global__ void __launch_bounds__(256) view_synthesis_fwd_kernel(const float* __
   Proj q;
   project_pixel(cam, Tm, inv_depth[(size_t)b * HW + pix], u, v, H, W, q);
   float out[3] = {0.f, 0.f, 0.f};
+  float mx, my;
+  q.ix = pad_coordinate(q.ix, W, pad_mode, mx);
+  q.iy = pad_coordinate(q.iy, H, pad_mode, my);
   if (q.ix > -1.f && q.ix < (float)W && q.iy > -1.f && q.iy < (float)H) {
     const float fx0 = floorf(q.ix), fy0 = floorf(q.iy);
     const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
@@ -117,7 +142,7 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
                                                                   const float* __restrict__ ref, const float* __restrict__ K,
                                                                   const float* __restrict__ refK, const float* __restrict__ T,
                                                                   float* __restrict__ d_inv_depth, double* __restrict__ ws,
-                                                                  int J, int B, int H, int W) {
+                                                                  int J, int B, int H, int W, int pad_mode) {
   __shared__ float redT[4][12];
   const int HW = H * W;
   const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -139,6 +164,9 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
       Proj q;
       project_pixel(cam, Tm, rho, u, v, H, W, q);
       float gix = 0.f, giy = 0.f;
+      float mx, my;
+      q.ix = pad_coordinate(q.ix, W, pad_mode, mx);
+      q.iy = pad_coordinate(q.iy, H, pad_mode, my);
       if (q.ix > -1.f && q.ix < (float)W && q.iy > -1.f && q.iy < (float)H) {
         const float fx0 = floorf(q.ix), fy0 = floorf(q.iy);
         const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
@@ -159,6 +187,8 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
           giy += g * ((sw - nw) * (1.f - ax) + (se - ne) * ax);
         }
       }
+      gix *= mx;       // d(padded coordinate) / d(coordinate)
+      giy *= my;
       // ix = p.x / z, iy = p.y / z (the (W-1)/2 factors of normalise/un-normalise cancel)
       const float iz = 1.f / q.z;
       float gp[3];
@@ -504,23 +534,39 @@ using namespace pnsfm;
 
 extern "C" {
 
+int pnsfm_view_synthesis_forward_pad(const float* inv_depth, const float* ref, const float* K, const float* refK,
+                                     const float* T, float* warped, int J, int B, int H, int W, int padding_mode,
+                                     void* stream) {
+  if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_forward: bad shape"); return -1; }
+  if (padding_mode < 0 || padding_mode > 2) { set_error("view_synthesis_forward: padding_mode must be 0 (zeros), 1 (border) or 2 (reflection)"); return -1; }
+  dim3 grid(ceil_div(H * W, 256), B, J);
+  PNSFM_LAUNCH(view_synthesis_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, inv_depth, ref, K, refK, T, warped, B, H, W,
+               padding_mode);
+  return check_launch("view_synthesis_forward");
+}
+
 int pnsfm_view_synthesis_forward(const float* inv_depth, const float* ref, const float* K, const float* refK, const float* T,
                                  float* warped, int J, int B, int H, int W, void* stream) {
-  if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_forward: bad shape"); return -1; }
-  dim3 grid(ceil_div(H * W, 256), B, J);
-  PNSFM_LAUNCH(view_synthesis_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, inv_depth, ref, K, refK, T, warped, B, H, W);
-  return check_launch("view_synthesis_forward");
+  return pnsfm_view_synthesis_forward_pad(inv_depth, ref, K, refK, T, warped, J, B, H, W, 0, stream);
 }
 
 int pnsfm_view_synthesis_backward(const float* d_warped, const float* inv_depth, const float* ref, const float* K,
                                   const float* refK, const float* T, float* d_inv_depth, float* dT, double* ws, int J, int B,
                                   int H, int W, void* stream) {
+  return pnsfm_view_synthesis_backward_pad(d_warped, inv_depth, ref, K, refK, T, d_inv_depth, dT, ws, J, B, H, W, 0, stream);
+}
+
+int pnsfm_view_synthesis_backward_pad(const float* d_warped, const float* inv_depth, const float* ref, const float* K,
+                                      const float* refK, const float* T, float* d_inv_depth, float* dT, double* ws, int J,
+                                      int B, int H, int W, int padding_mode, void* stream) {
   if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_backward: bad shape"); return -1; }
+  if (padding_mode < 0 || padding_mode > 2) { set_error("view_synthesis_backward: bad padding_mode"); return -1; }
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(ws, 0, (size_t)J * B * 12 * sizeof(double), s);
   if (e) { set_error("view_synthesis_backward: memset failed"); return e; }
   dim3 grid(ceil_div(H * W, 256), B);
-  PNSFM_LAUNCH(view_synthesis_bwd_kernel, grid, dim3(256), 0, s, d_warped, inv_depth, ref, K, refK, T, d_inv_depth, ws, J, B, H, W);
+  PNSFM_LAUNCH(view_synthesis_bwd_kernel, grid, dim3(256), 0, s, d_warped, inv_depth, ref, K, refK, T, d_inv_depth, ws, J, B, H, W,
+               padding_mode);
   e = check_launch("view_synthesis_backward");
   if (e) return e;
   PNSFM_LAUNCH(view_synthesis_bwd_finish_kernel, dim3(ceil_div(J * B * 16, 256)), dim3(256), 0, s, (const double*)ws, dT, J * B);

@@ -21,9 +21,10 @@ def view_synthesis(ref_image, depth, ref_cam, cam, mode='bilinear', padding_mode
     """Warp `ref_image` into the view of `cam` given that view's depth map -- ONE fused gfx950 kernel
     (reconstruct -> rigid transform -> project -> bilinear gather) instead of the reference's ~25 ATen ops.
     The fused kernel takes inverse depth; 1/depth here is the exact inverse of inv2depth for depth >= 1e-6."""
-    if mode != 'bilinear' or padding_mode != 'zeros':
-        raise NotImplementedError('the gfx950 view-synthesis kernel implements bilinear / zeros padding')
+    if mode != 'bilinear':
+        raise NotImplementedError('the gfx950 view-synthesis kernel implements bilinear sampling')
     assert depth.size(1) == 1
     T = ref_cam.Tcw.mat.bmm(cam.Twc.mat)          # target camera -> world -> reference camera
-    warped = HF.view_synthesis(1.0 / depth, ref_image.unsqueeze(0), cam.K.float(), ref_cam.K.float(), T.unsqueeze(0))
+    warped = HF.view_synthesis(1.0 / depth, ref_image.unsqueeze(0), cam.K.float(), ref_cam.K.float(), T.unsqueeze(0),
+                               padding_mode)
     return warped[0]

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pnsfm_invdepth_conv_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_view_synthesis_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_view_synthesis_forward_pad": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_view_synthesis_backward_pad": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_photometric_forward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "pnsfm_photometric_backward": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "pnsfm_photometric_forward_clip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _f, _p, _p, _p]),

@@ -605,22 +605,26 @@ class ViewSynthesisFn(Function):
     Differentiable w.r.t. inv_depth and the [J,B,4,4] pose matrices (the context image is data)."""
 
     @staticmethod
-    def forward(ctx, inv_depth, ref, K, refK, T):
+    def forward(ctx, inv_depth, ref, K, refK, T, padding_mode=0):
         inv_depth, ref, K, refK, T = (t.contiguous() for t in (inv_depth, ref, K, refK, T))
-        warped = ops.view_synthesis_forward(inv_depth, ref, K, refK, T.detach())
+        warped = ops.view_synthesis_forward(inv_depth, ref, K, refK, T.detach(), padding_mode)
         ctx.save_for_backward(inv_depth, ref, K, refK, T)
+        ctx.padding_mode = padding_mode
         return warped
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_warped):
         inv_depth, ref, K, refK, T = ctx.saved_tensors
-        d_inv, dT = ops.view_synthesis_backward(d_warped.contiguous(), inv_depth, ref, K, refK, T.detach())
-        return d_inv, None, None, None, dT
+        d_inv, dT = ops.view_synthesis_backward(d_warped.contiguous(), inv_depth, ref, K, refK, T.detach(), ctx.padding_mode)
+        return d_inv, None, None, None, dT, None
 
 
-def view_synthesis(inv_depth, ref, K, refK, T):
-    return ViewSynthesisFn.apply(inv_depth, ref, K, refK, T)
+def view_synthesis(inv_depth, ref, K, refK, T, padding_mode='zeros'):
+    """padding_mode: 'zeros' | 'border' | 'reflection' (F.grid_sample semantics, align_corners=True)."""
+    if padding_mode not in ops.PADDING_MODES:
+        raise ValueError('Unknown padding_mode {}'.format(padding_mode))
+    return ViewSynthesisFn.apply(inv_depth, ref, K, refK, T, ops.PADDING_MODES[padding_mode])
 
 
 REDUCE_MIN, REDUCE_MEAN = 0, 1

@@ -285,25 +285,28 @@ def pose_vec2mat_backward(vec, dmat):
 
 
 # ---------------------------------------------------------------------------------------------- loss
-def view_synthesis_forward(inv_depth, ref, K, refK, T):
+PADDING_MODES = {'zeros': 0, 'border': 1, 'reflection': 2}     # F.grid_sample's padding_mode (align_corners=True)
+
+
+def view_synthesis_forward(inv_depth, ref, K, refK, T, padding_mode=0):
     """inv_depth [B,1,H,W]; ref [J,B,3,H,W]; K, refK [B,3,3]; T [J,B,4,4] -> warped [J,B,3,H,W]."""
     _chk(inv_depth, ref, K, refK, T); _f32(inv_depth, ref, K, refK, T)
     J, B, _, H, W = ref.shape
     warped = torch.empty_like(ref)
-    _lib.check(_lib.get().pnsfm_view_synthesis_forward(_ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK), _ptr(T), _ptr(warped),
-                                                       J, B, H, W, _stream(ref)), "view_synthesis_forward")
+    _lib.check(_lib.get().pnsfm_view_synthesis_forward_pad(_ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK), _ptr(T), _ptr(warped),
+                                                           J, B, H, W, int(padding_mode), _stream(ref)), "view_synthesis_forward")
     return warped
 
 
-def view_synthesis_backward(d_warped, inv_depth, ref, K, refK, T):
+def view_synthesis_backward(d_warped, inv_depth, ref, K, refK, T, padding_mode=0):
     _chk(d_warped, inv_depth, ref, K, refK, T); _f32(d_warped, inv_depth, ref, K, refK, T)
     J, B, _, H, W = ref.shape
     d_inv = torch.empty_like(inv_depth)
     dT = torch.empty_like(T)
     ws = torch.empty((J * B * 12,), dtype=torch.float64, device=ref.device)
-    _lib.check(_lib.get().pnsfm_view_synthesis_backward(_ptr(d_warped), _ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK), _ptr(T),
-                                                        _ptr(d_inv), _ptr(dT), _ptr(ws), J, B, H, W, _stream(ref)),
-               "view_synthesis_backward")
+    _lib.check(_lib.get().pnsfm_view_synthesis_backward_pad(_ptr(d_warped), _ptr(inv_depth), _ptr(ref), _ptr(K), _ptr(refK),
+                                                            _ptr(T), _ptr(d_inv), _ptr(dT), _ptr(ws), J, B, H, W,
+                                                            int(padding_mode), _stream(ref)), "view_synthesis_backward")
     return d_inv, dT
 
 

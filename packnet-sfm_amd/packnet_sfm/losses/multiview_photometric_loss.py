@@ -50,8 +50,8 @@ class MultiViewPhotometricLoss(LossBase):
         if photometric_reduce_op not in ('min', 'mean'):
             raise NotImplementedError('Unknown photometric_reduce_op: {}'.format(photometric_reduce_op))
         # configurations the fused kernels do not cover fail loudly instead of silently taking another path
-        if padding_mode != 'zeros':
-            raise NotImplementedError("the gfx950 view-synthesis kernel implements padding_mode='zeros' only")
+        if padding_mode not in ('zeros', 'border', 'reflection'):
+            raise ValueError('Unknown padding_mode {}'.format(padding_mode))
         if not ssim_loss_weight > 0.0:
             raise NotImplementedError('ssim_loss_weight must be > 0 for the fused gfx950 photometric kernel')
 
@@ -81,7 +81,7 @@ class MultiViewPhotometricLoss(LossBase):
                 refs_i = torch.stack(match_scales_list(context, inv_depths[i]), 0).contiguous()
                 s = w / float(W)
                 Ki, rKi = scale_intrinsics(K32.clone(), s, s), scale_intrinsics(rK32.clone(), s, s)
-            warped = HF.view_synthesis(inv_depths[i], refs_i, Ki.contiguous(), rKi.contiguous(), T)
+            warped = HF.view_synthesis(inv_depths[i], refs_i, Ki.contiguous(), rKi.contiguous(), T, self.padding_mode)
             photometric_loss = photometric_loss + HF.photometric(
                 warped, refs_i, images[i], self.ssim_loss_weight, self.C1, self.C2, bool(self.automask_loss), reduce_op,
                 float(self.clip_loss))

@@ -93,7 +93,8 @@ def test_unpack_golden():
     P.case_unpack(DEV)
 
 
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean'])
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
+                                  'loss_reflection'])
 def test_loss_golden(name):
     P.case_loss(name, DEV)
 

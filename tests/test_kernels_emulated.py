@@ -75,7 +75,8 @@ def test_compose_pack_weight(emulated_kernels):
     P.check(col[:, :, r:-r, r:-r], ref[:, :, r:-r, r:-r], 1e-5, 'interior equality')
 
 
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean'])
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
+                                  'loss_reflection'])
 def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 

@@ -1,38 +1,44 @@
-"""Pose: a batch of [4,4] rigid transforms.  API of the reference's packnet_sfm/geometry/pose.py."""
+"""Pose: a batch of 4x4 rigid transforms (names of the reference's packnet_sfm/geometry/pose.py).
+
+`Pose.from_vec(vec, 'euler')` -- the only constructor on the training path -- is ONE launch of the fused pose kernel
+(csrc/elementwise.hip) instead of ~85 tiny ATen ops; everything else is host-side bookkeeping on [B,4,4] tensors."""
 import torch
 
 from packnet_sfm.geometry.pose_utils import invert_pose, pose_vec2mat
 
 
+def _is_transform_stack(t):
+    return torch.is_tensor(t) and t.dim() == 3 and tuple(t.shape[-2:]) == (4, 4)
+
+
 class Pose:
     def __init__(self, mat):
-        assert tuple(mat.shape[-2:]) == (4, 4)
-        if mat.dim() == 2:
-            mat = mat.unsqueeze(0)
-        assert mat.dim() == 3
+        if torch.is_tensor(mat) and mat.dim() == 2:
+            mat = mat[None]
+        assert _is_transform_stack(mat), 'Pose expects [B,4,4] (or a single [4,4]) matrices'
         self.mat = mat
 
-    def __len__(self):
-        return len(self.mat)
-
+    # ---- constructors ------------------------------------------------------------------------------------------------
     @classmethod
     def identity(cls, N=1, device=None, dtype=torch.float):
-        return cls(torch.eye(4, device=device, dtype=dtype).repeat([N, 1, 1]))
+        return cls(torch.eye(4, device=device, dtype=dtype).expand(N, 4, 4).clone())
 
     @classmethod
     def from_vec(cls, vec, mode):
-        """[B,6] pose vector -> Pose (bottom row [0,0,0,1])."""
-        if mode == 'euler' and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[1] == 6:
-            from packnet_sfm.hip import functional as HF      # one launch each way instead of ~85 tiny ATen kernels
+        """[B,6] = (tx, ty, tz, rx, ry, rz) -> Pose; the last row of every matrix is (0, 0, 0, 1)."""
+        fused = mode == 'euler' and vec.dtype == torch.float32 and vec.dim() == 2 and vec.shape[1] == 6
+        if fused:
+            from packnet_sfm.hip import functional as HF
             return cls(HF.pose_vec2mat44(vec))
-        top = pose_vec2mat(vec, mode)
-        bottom = torch.zeros((len(vec), 1, 4), device=vec.device, dtype=vec.dtype)
-        bottom[:, 0, 3] = 1.0
-        return cls(torch.cat([top, bottom], dim=1))
+        rt = pose_vec2mat(vec, mode)                                     # [B,3,4]
+        last = rt.new_tensor([0., 0., 0., 1.]).expand(len(vec), 1, 4)
+        return cls(torch.cat((rt, last), dim=1))
 
-    @property
-    def shape(self):
-        return self.mat.shape
+    # ---- container protocol ------------------------------------------------------------------------------------------
+    def __len__(self):
+        return self.mat.shape[0]
+
+    shape = property(lambda self: self.mat.shape)
 
     def item(self):
         return self.mat
@@ -41,30 +47,32 @@ class Pose:
         self.mat = self.mat.repeat(*args, **kwargs)
         return self
 
-    def inverse(self):
-        return Pose(invert_pose(self.mat))
-
     def to(self, *args, **kwargs):
         self.mat = self.mat.to(*args, **kwargs)
         return self
 
+    # ---- algebra -----------------------------------------------------------------------------------------------------
+    def inverse(self):
+        return Pose(invert_pose(self.mat))
+
     def transform_pose(self, pose):
-        """self * pose"""
-        assert tuple(pose.shape[-2:]) == (4, 4)
-        return Pose(self.mat.bmm(pose.item()))
+        """Composition self * pose."""
+        other = pose.item()
+        assert _is_transform_stack(other)
+        return Pose(torch.bmm(self.mat, other))
 
     def transform_points(self, points):
-        """[B,3,H,W] points -> R @ points + t"""
+        """R @ p + t for a [B,3,H,W] (or [B,3,N]) point map."""
         assert points.shape[1] == 3
-        B, _, H, W = points.shape
-        out = self.mat[:, :3, :3].bmm(points.reshape(B, 3, -1)) + self.mat[:, :3, 3:]
-        return out.view(B, 3, H, W)
+        flat = points.flatten(2)                                         # [B,3,N]
+        moved = torch.baddbmm(self.mat[:, :3, 3:], self.mat[:, :3, :3], flat)
+        return moved.view_as(points)
 
     def __matmul__(self, other):
         if isinstance(other, Pose):
             return self.transform_pose(other)
-        if isinstance(other, torch.Tensor):
-            if other.shape[1] == 3 and other.dim() in (3, 4):
-                return self.transform_points(other)
-            raise ValueError('Unknown tensor dimensions {}'.format(other.shape))
-        raise NotImplementedError()
+        if not torch.is_tensor(other):
+            raise NotImplementedError()
+        if other.dim() in (3, 4) and other.shape[1] == 3:
+            return self.transform_points(other)
+        raise ValueError('Unknown tensor dimensions {}'.format(other.shape))

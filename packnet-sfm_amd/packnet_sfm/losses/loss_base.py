@@ -1,18 +1,19 @@
-"""LossBase + ProgressiveScaling (API of the reference's packnet_sfm/losses/loss_base.py)."""
+"""LossBase + ProgressiveScaling (names of the reference's packnet_sfm/losses/loss_base.py)."""
 import numpy as np
 import torch.nn as nn
 
+from packnet_sfm.utils.reporting import Reporting
+
 
 class ProgressiveScaling:
-    """Drops one loss scale each time training progress passes a multiple of `progressive_scaling` (0 = off)."""
+    """Number of loss scales as training progresses: one scale fewer each time `progress` passes a multiple of
+    `progressive_scaling` (0 disables the schedule)."""
 
     def __init__(self, progressive_scaling, num_scales=4):
         self.num_scales = num_scales
+        self.thresholds = None
         if progressive_scaling > 0.0:
-            steps = [progressive_scaling * (i + 1) for i in range(num_scales - 1)] + [1.0]
-            self.thresholds = np.float32(steps)
-        else:
-            self.thresholds = None
+            self.thresholds = np.float32([progressive_scaling * (i + 1) for i in range(num_scales - 1)] + [1.0])
 
     def __call__(self, progress):
         if self.thresholds is None:
@@ -20,19 +21,12 @@ class ProgressiveScaling:
         return int(self.num_scales - np.searchsorted(self.thresholds, progress))
 
 
-class LossBase(nn.Module):
+class LossBase(Reporting, nn.Module):
     def __init__(self):
-        super().__init__()
-        self._logs = {}
-        self._metrics = {}
+        nn.Module.__init__(self)
 
-    @property
-    def logs(self):
-        return self._logs
-
-    @property
-    def metrics(self):
-        return self._metrics
+    logs = property(lambda self: self._report('logs'))
+    metrics = property(lambda self: self._report('metrics'))
 
     def add_metric(self, key, val):
-        self._metrics[key] = val.detach()
+        self._record('metrics', key, val)

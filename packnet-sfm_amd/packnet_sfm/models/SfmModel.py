@@ -1,4 +1,6 @@
-"""SfmModel: depth network + pose network (API of the reference's packnet_sfm/models/SfmModel.py)."""
+"""SfmModel: a depth network and a pose network behind one `forward(batch)` (contract of the reference's
+packnet_sfm/models/SfmModel.py: `add_depth_net`, `add_pose_net`, `compute_depth_net`, `compute_pose_net`,
+`depth_net_flipping`, output dict {'inv_depths', 'poses'})."""
 import random
 
 from packnet_sfm.geometry.pose import Pose
@@ -9,21 +11,19 @@ from packnet_sfm.utils.misc import filter_dict
 
 class SfmModel(BaseModel):
     """
-    depth_net / pose_net : nn.Module
-    rotation_mode : str            pose-vector rotation parametrisation ('euler')
-    flip_lr_prob : float           probability of running the depth network on a mirrored batch (training)
-    upsample_depth_maps : bool     nearest-upsample all predicted scales to full resolution (training)
+    depth_net / pose_net : nn.Module   (usually attached later through add_depth_net / add_pose_net)
+    rotation_mode : str                pose-vector rotation parametrisation ('euler')
+    flip_lr_prob : float               probability of running the depth network on a mirrored batch (training only)
+    upsample_depth_maps : bool         nearest-upsample all predicted scales to full resolution (training only)
     """
 
     def __init__(self, depth_net=None, pose_net=None, rotation_mode='euler', flip_lr_prob=0.0,
                  upsample_depth_maps=False, **kwargs):
         super().__init__()
-        self.depth_net = depth_net
-        self.pose_net = pose_net
-        self.rotation_mode = rotation_mode
-        self.flip_lr_prob = flip_lr_prob
+        self._network_requirements.extend(('depth_net', 'pose_net'))
+        self.depth_net, self.pose_net = depth_net, pose_net
+        self.rotation_mode, self.flip_lr_prob = rotation_mode, flip_lr_prob
         self.upsample_depth_maps = upsample_depth_maps
-        self._network_requirements = ['depth_net', 'pose_net']
 
     def add_depth_net(self, depth_net):
         self.depth_net = depth_net
@@ -31,28 +31,34 @@ class SfmModel(BaseModel):
     def add_pose_net(self, pose_net):
         self.pose_net = pose_net
 
+    # ---- depth -------------------------------------------------------------------------------------------------------
     def depth_net_flipping(self, batch, flip):
-        """Depth network on the batch, or on its mirror image with the prediction mirrored back."""
+        """The depth network on the batch -- or, when `flip`, on its mirror image with the prediction mirrored back."""
         net_input = {key: batch[key] for key in filter_dict(batch, self._input_keys)}
-        if not flip:
-            return self.depth_net(**net_input)
-        return flip_output(self.depth_net(**flip_batch_input(net_input)))
+        if flip:
+            return flip_output(self.depth_net(**flip_batch_input(net_input)))
+        return self.depth_net(**net_input)
+
+    def _draw_flip(self, force_flip):
+        # ONE python-RNG draw per training batch (replicas agree because their seeds agree); evaluation never draws
+        if not self.training:
+            return force_flip
+        return random.random() < self.flip_lr_prob
 
     def compute_depth_net(self, batch, force_flip=False):
-        # one python-RNG draw per batch, exactly like the reference (replicas agree because seeds agree)
-        flip = random.random() < self.flip_lr_prob if self.training else force_flip
-        output = self.depth_net_flipping(batch, flip)
+        output = self.depth_net_flipping(batch, self._draw_flip(force_flip))
         if self.training and self.upsample_depth_maps:
             output = upsample_output(output, mode='nearest', align_corners=None)
         return output
 
+    # ---- pose --------------------------------------------------------------------------------------------------------
     def compute_pose_net(self, image, contexts):
-        pose_vec = self.pose_net(image, contexts)
-        return [Pose.from_vec(pose_vec[:, i], self.rotation_mode) for i in range(pose_vec.shape[1])]
+        """[B,J,6] pose vectors -> one Pose (target -> context j) per context image."""
+        vectors = self.pose_net(image, contexts)
+        return [Pose.from_vec(v, self.rotation_mode) for v in vectors.unbind(1)]
 
     def forward(self, batch, return_logs=False, force_flip=False):
-        depth_output = self.compute_depth_net(batch, force_flip=force_flip)
-        pose_output = None
-        if 'rgb_context' in batch and self.pose_net is not None:
-            pose_output = self.compute_pose_net(batch['rgb'], batch['rgb_context'])
-        return {**depth_output, 'poses': pose_output}
+        output = dict(self.compute_depth_net(batch, force_flip=force_flip))
+        has_contexts = 'rgb_context' in batch and self.pose_net is not None
+        output['poses'] = self.compute_pose_net(batch['rgb'], batch['rgb_context']) if has_contexts else None
+        return output

@@ -1,41 +1,28 @@
-"""BaseModel: the model-plugin contract the wrapper/trainer relies on (API of the reference's
-packnet_sfm/models/base_model.py)."""
+"""BaseModel: the plugin contract `setup_model` / the trainers rely on (reference: packnet_sfm/models/base_model.py) --
+`network_requirements`, `train_requirements`, `add_net`, `add_loss`, `logs`, `losses`, `forward(batch, ...)`."""
 import torch.nn as nn
 
+from packnet_sfm.utils.reporting import Reporting
 
-class BaseModel(nn.Module):
+
+class BaseModel(Reporting, nn.Module):
     def __init__(self, **kwargs):
-        super().__init__()
-        self._logs = {}
-        self._losses = {}
-        self._network_requirements = []     # networks the model needs ('depth_net', 'pose_net', ...)
-        self._train_requirements = []       # ground truth needed at training time
-        self._input_keys = ['rgb']          # batch keys handed to the depth network
+        nn.Module.__init__(self)
+        # subclasses edit these lists in place (SfmModel adds its two networks, SemiSupModel drops the pose network)
+        self._network_requirements, self._train_requirements = [], []
+        self._input_keys = ['rgb']                      # batch entries forwarded to the depth network
 
-    def _forward_unimplemented(self, *args):
-        pass
-
-    @property
-    def logs(self):
-        return self._logs
-
-    @property
-    def losses(self):
-        return self._losses
+    logs = property(lambda self: self._report('logs'))
+    losses = property(lambda self: self._report('losses'))
+    network_requirements = property(lambda self: self._network_requirements, doc="networks the model needs, by attribute name")
+    train_requirements = property(lambda self: self._train_requirements, doc="ground truth needed at training time")
 
     def add_loss(self, key, val):
-        self._losses[key] = val.detach()
-
-    @property
-    def network_requirements(self):
-        return self._network_requirements
-
-    @property
-    def train_requirements(self):
-        return self._train_requirements
+        self._record('losses', key, val)
 
     def add_net(self, network_module, network_name):
-        assert network_name in self._network_requirements, "Network module not required!"
+        if network_name not in self._network_requirements:
+            raise AssertionError("Network module not required!")
         setattr(self, network_name, network_module)
 
     def forward(self, batch, return_logs=False, **kwargs):

@@ -21,37 +21,35 @@ def sample_to_cuda(data, dtype=None):
 
 
 class BaseTrainer:
+    """Epoch bounds, checkpoint hook and rank-aware progress bars; subclasses provide `proc_rank` / `world_size`."""
+
     def __init__(self, min_epochs=0, max_epochs=50, validate_first=False, checkpoint=None, **kwargs):
-        self.min_epochs = min_epochs
-        self.max_epochs = max_epochs
+        self.min_epochs, self.max_epochs = min_epochs, max_epochs
         self.validate_first = validate_first
         self.checkpoint = checkpoint
         self.module = None
 
-    @property
-    def proc_rank(self):
+    def _abstract(self):
         raise NotImplementedError('Not implemented for BaseTrainer')
 
-    @property
-    def world_size(self):
-        raise NotImplementedError('Not implemented for BaseTrainer')
-
-    @property
-    def is_rank_0(self):
-        return self.proc_rank == 0
+    proc_rank = property(_abstract)
+    world_size = property(_abstract)
+    is_rank_0 = property(lambda self: self.proc_rank == 0)
 
     def check_and_save(self, module, output):
         if self.checkpoint:
             self.checkpoint.check_and_save(module, output)
 
     def _bar(self, dataloader, config, desc=None, ncols=120):
-        batch = getattr(config, 'batch_size', 1)
-        if isinstance(batch, (list, tuple)):
-            batch = batch[0]
+        """enumerate(dataloader), wrapped in a tqdm bar (images/s over all ranks) on rank 0 when tqdm is installed."""
+        steps = enumerate(dataloader, 0)
         if tqdm is None:
-            return enumerate(dataloader, 0)
-        return tqdm(enumerate(dataloader, 0), unit=' images', unit_scale=self.world_size * batch, total=len(dataloader),
-                    smoothing=0, disable=not self.is_rank_0, ncols=ncols, desc=desc)
+            return steps
+        per_rank = getattr(config, 'batch_size', 1)
+        if isinstance(per_rank, (list, tuple)):
+            per_rank = per_rank[0]
+        return tqdm(steps, total=len(dataloader), unit=' images', unit_scale=self.world_size * per_rank, smoothing=0,
+                    disable=not self.is_rank_0, ncols=ncols, desc=desc)
 
     def train_progress_bar(self, dataloader, config, ncols=120):
         return self._bar(dataloader, config, ncols=ncols)

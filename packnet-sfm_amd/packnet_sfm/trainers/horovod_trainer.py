@@ -38,65 +38,65 @@ class HorovodTrainer(BaseTrainer):
         self.dtype = kwargs.get('dtype', None)
         self.log_every = int(kwargs.get('log_every', 1))   # host sync for the loss readout every N steps (reference: 1)
 
-    @property
-    def proc_rank(self):
-        return hvd.rank()
+    proc_rank = property(lambda self: hvd.rank())
+    world_size = property(lambda self: hvd.size())
 
-    @property
-    def world_size(self):
-        return hvd.size()
-
+    # ---- training ----------------------------------------------------------------------------------------------------
     def fit(self, module):
+        """Train `module` from its current epoch to `max_epochs`, validating (and checkpointing) after every epoch."""
         module.trainer = self
         module = module.to('cuda')
         module.configure_optimizers()
+        # gradient averaging over RCCL: bucketed all-reduce on a side stream, overlapped with backward
         optimizer = hvd.DistributedOptimizer(module.optimizer, named_parameters=module.named_parameters(),
                                              compression=hvd.Compression.none)
-        scheduler = module.scheduler
-        train_dataloader = module.train_dataloader()
-        val_dataloaders = module.val_dataloader()
+        loaders = {'train': module.train_dataloader(), 'val': module.val_dataloader()}
+
+        def validate_and_save():
+            self.check_and_save(module, self.validate(loaders['val'], module))
+
         if self.validate_first:
-            self.check_and_save(module, self.validate(val_dataloaders, module))
-        for _ in range(module.current_epoch, self.max_epochs):
-            self.train(train_dataloader, module, optimizer)
-            self.check_and_save(module, self.validate(val_dataloaders, module))
+            validate_and_save()
+        while module.current_epoch < self.max_epochs:
+            self.train(loaders['train'], module, optimizer)
+            validate_and_save()
             module.current_epoch += 1
-            scheduler.step()
+            module.scheduler.step()
+
+    def _train_step(self, module, optimizer, batch, index):
+        optimizer.zero_grad()
+        output = module.training_step(sample_to_cuda(batch), index)
+        output['loss'].backward()           # a bucket's all-reduce starts as soon as its last gradient exists
+        optimizer.step()                    # joins the side streams, then the optimizer update
+        output['loss'] = output['loss'].detach()
+        return output
 
     def train(self, dataloader, module, optimizer):
         module.train()
-        if hasattr(dataloader.sampler, 'set_epoch'):
-            dataloader.sampler.set_epoch(module.current_epoch)
-        progress_bar = self.train_progress_bar(dataloader, module.config.datasets.train)
+        sampler = getattr(dataloader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(module.current_epoch)
+        bar = self.train_progress_bar(dataloader, module.config.datasets.train)
+        show = self.is_rank_0 and hasattr(bar, 'set_description')
         outputs = []
-        for i, batch in progress_bar:
-            optimizer.zero_grad()
-            batch = sample_to_cuda(batch)
-            output = module.training_step(batch, i)
-            output['loss'].backward()       # bucketed RCCL all-reduces start as soon as a bucket's gradients exist
-            optimizer.step()                # joins the side stream, averages, then the optimizer update
-            output['loss'] = output['loss'].detach()
-            outputs.append(output)
-            if self.is_rank_0 and hasattr(progress_bar, 'set_description') and i % self.log_every == 0:
-                progress_bar.set_description('Epoch {} | Avg.Loss {:.4f}'.format(
-                    module.current_epoch, self.avg_loss(output['loss'].item())))
+        for i, batch in bar:
+            outputs.append(self._train_step(module, optimizer, batch, i))
+            if show and i % self.log_every == 0:
+                mean = self.avg_loss(outputs[-1]['loss'].item())
+                bar.set_description('Epoch {} | Avg.Loss {:.4f}'.format(module.current_epoch, mean))
         return module.training_epoch_end(outputs)
 
-    def _run_eval(self, dataloaders, module, step_name, config, dtype=None):
+    # ---- evaluation --------------------------------------------------------------------------------------------------
+    def _sweep(self, dataloaders, module, step, bar_config, dtype=None):
+        """outputs[n][i] = module.<step>(batch i of dataloader n, i, n), in eval mode."""
         module.eval()
-        all_outputs = []
-        for n, dataloader in enumerate(dataloaders):
-            bar = self.val_progress_bar(dataloader, config, n)
-            outputs = []
-            for i, batch in bar:
-                batch = sample_to_cuda(batch, dtype)
-                outputs.append(getattr(module, step_name)(batch, i, n))
-            all_outputs.append(outputs)
-        return all_outputs
+        return [[getattr(module, step)(sample_to_cuda(batch, dtype), i, n)
+                 for i, batch in self.val_progress_bar(loader, bar_config, n)]
+                for n, loader in enumerate(dataloaders)]
 
     def validate(self, dataloaders, module):
-        outputs = self._run_eval(dataloaders, module, 'validation_step', module.config.datasets.validation)
-        return module.validation_epoch_end(outputs)
+        return module.validation_epoch_end(
+            self._sweep(dataloaders, module, 'validation_step', module.config.datasets.validation))
 
     def test(self, module):
         module = module.to('cuda', dtype=self.dtype)
@@ -104,5 +104,4 @@ class HorovodTrainer(BaseTrainer):
 
     @torch.no_grad()
     def evaluate(self, dataloaders, module):
-        outputs = self._run_eval(dataloaders, module, 'test_step', module.config.datasets.test, self.dtype)
-        return module.test_epoch_end(outputs)
+        return module.test_epoch_end(self._sweep(dataloaders, module, 'test_step', module.config.datasets.test, self.dtype))

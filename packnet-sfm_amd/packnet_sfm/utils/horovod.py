@@ -1,27 +1,26 @@
-"""rank / world-size helpers with the API of the reference's packnet_sfm/utils/horovod.py, on RCCL."""
+"""Process-group helpers under the names of the reference's packnet_sfm/utils/horovod.py, served by the RCCL facade
+(`packnet_sfm.rccl.hvd`, one process per GPU)."""
+import functools
+
 from packnet_sfm.rccl import hvd
 
-HAS_HOROVOD = True   # the RCCL facade is always available
+HAS_HOROVOD = True      # the facade is part of this package, so the "horovod present?" switch is always on
+
+rank = hvd.rank
+world_size = hvd.size
 
 
 def hvd_init():
     hvd.init()
-    return True
+    return HAS_HOROVOD
 
 
 def on_rank_0(func):
-    def wrapper(*args, **kwargs):
-        if rank() == 0:
-            func(*args, **kwargs)
-    return wrapper
-
-
-def rank():
-    return hvd.rank()
-
-
-def world_size():
-    return hvd.size()
+    """Decorator: run `func` on rank 0 only (other ranks return None)."""
+    @functools.wraps(func)
+    def only_first_rank(*args, **kwargs):
+        return func(*args, **kwargs) if hvd.rank() == 0 else None
+    return only_first_rank
 
 
 @on_rank_0
@@ -30,5 +29,5 @@ def print0(string='\n'):
 
 
 def reduce_value(value, average, name):
-    """Mean (or sum) of a tensor over all ranks."""
+    """All-reduce a tensor over the ranks (mean when `average`, else sum)."""
     return hvd.allreduce(value, average=average, name=name)

@@ -39,30 +39,30 @@ def interpolate_scales(images, shape=None, mode='bilinear', align_corners=False)
 
 
 def match_scales(image, targets, num_scales, mode='bilinear', align_corners=True):
-    """One copy of `image` per target resolution (the same tensor when the resolution already matches)."""
-    out = []
-    for i in range(num_scales):
-        tshape = targets[i].shape
-        if same_shape(image.shape[-2:], tshape[-2:]):
-            out.append(image)
-        else:
-            out.append(interpolate_image(image, tshape, mode=mode, align_corners=align_corners))
-    return out
+    """`image` resized to each of the first `num_scales` target resolutions; where the resolution already matches, the
+    tensor itself is returned (no copy)."""
+    def at_scale(target):
+        if same_shape(image.shape[-2:], target.shape[-2:]):
+            return image
+        return interpolate_image(image, target.shape, mode=mode, align_corners=align_corners)
+    return [at_scale(t) for t in targets[:num_scales]]
+
+
+def _axis(n, normalized, dtype, device):
+    lo, hi = (-1., 1.) if normalized else (0., float(n - 1))
+    return torch.linspace(lo, hi, n, device=device, dtype=dtype)
 
 
 @lru_cache(maxsize=None)
 def meshgrid(B, H, W, dtype, device, normalized=False):
-    if normalized:
-        xs = torch.linspace(-1, 1, W, device=device, dtype=dtype)
-        ys = torch.linspace(-1, 1, H, device=device, dtype=dtype)
-    else:
-        xs = torch.linspace(0, W - 1, W, device=device, dtype=dtype)
-        ys = torch.linspace(0, H - 1, H, device=device, dtype=dtype)
-    ys, xs = torch.meshgrid([ys, xs], indexing='ij')
-    return xs.repeat([B, 1, 1]), ys.repeat([B, 1, 1])
+    """x and y coordinate planes, each [B,H,W] (pixel centres 0..W-1 / 0..H-1, or [-1, 1] when `normalized`)."""
+    xs = _axis(W, normalized, dtype, device).view(1, 1, W).expand(B, H, W)
+    ys = _axis(H, normalized, dtype, device).view(1, H, 1).expand(B, H, W)
+    return xs.contiguous(), ys.contiguous()
 
 
 @lru_cache(maxsize=None)
 def image_grid(B, H, W, dtype, device, normalized=False):
+    """Homogeneous pixel grid [B,3,H,W] = (x, y, 1)."""
     xs, ys = meshgrid(B, H, W, dtype, device, normalized=normalized)
-    return torch.stack([xs, ys, torch.ones_like(xs)], dim=1)
+    return torch.stack((xs, ys, torch.ones_like(xs)), dim=1)

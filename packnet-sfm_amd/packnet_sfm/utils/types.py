@@ -1,35 +1,37 @@
-"""Type predicates (API of the reference's packnet_sfm/utils/types.py, minus the yacs dependency)."""
+"""Type predicates with the names the reference's packnet_sfm/utils/types.py exports (minus its yacs `is_cfg`).
+
+Table-driven: one closure per python / numpy container kind; tensors are matched on the exact class (a Parameter or
+another Tensor subclass is not "a tensor" for the callers that branch on this, e.g. batch stacking)."""
 import numpy as np
 import torch
 
+_CONTAINER_KINDS = {
+    'numpy': np.ndarray,
+    'tuple': tuple,
+    'list': list,
+    'dict': dict,
+    'str': str,
+    'int': int,
+}
 
-def is_numpy(data):
-    return isinstance(data, np.ndarray)
+
+def _predicate(kind):
+    cls = _CONTAINER_KINDS[kind]
+
+    def check(data):
+        return isinstance(data, cls)
+    check.__name__ = 'is_' + kind
+    check.__doc__ = 'True when `data` is a %s.' % cls.__name__
+    return check
+
+
+is_numpy, is_tuple, is_list, is_dict, is_str, is_int = (_predicate(k) for k in ('numpy', 'tuple', 'list', 'dict', 'str', 'int'))
 
 
 def is_tensor(data):
-    return type(data) == torch.Tensor
-
-
-def is_tuple(data):
-    return isinstance(data, tuple)
-
-
-def is_list(data):
-    return isinstance(data, list)
-
-
-def is_dict(data):
-    return isinstance(data, dict)
-
-
-def is_str(data):
-    return isinstance(data, str)
-
-
-def is_int(data):
-    return isinstance(data, int)
+    return type(data) is torch.Tensor
 
 
 def is_seq(data):
-    return is_tuple(data) or is_list(data)
+    """list or tuple"""
+    return isinstance(data, (list, tuple))

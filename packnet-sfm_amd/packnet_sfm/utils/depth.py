@@ -25,35 +25,55 @@ def inv_depths_normalize(inv_depths):
     return [d / m.clamp(min=1e-6) for d, m in zip(inv_depths, means)]
 
 
-def compute_depth_metrics(config, gt, pred, use_gt_scale=True):
-    """abs_rel, sqr_rel, rmse, rmse_log, a1, a2, a3 averaged over the batch (reference: utils/depth.py:258-324).
-    config needs .crop ('' | 'garg'), .min_depth, .max_depth; gt, pred: [B,1,H,W] (pred is resized to gt)."""
+# Evaluation crop of Garg et al. (fractions of the image height / width), used by the KITTI protocol when config.crop == 'garg'
+_GARG_ROWS, _GARG_COLS = (0.40810811, 0.99189189), (0.03594771, 0.96405229)
+
+# name -> f(gt, pred) on the 1-D vectors of valid pixels; order = the reference's metric vector
+_DEPTH_METRICS = (
+    ('abs_rel', lambda g, p: ((g - p).abs() / g).mean()),
+    ('sqr_rel', lambda g, p: ((g - p) ** 2 / g).mean()),
+    ('rmse', lambda g, p: ((g - p) ** 2).mean().sqrt()),
+    ('rmse_log', lambda g, p: ((g.log() - p.log()) ** 2).mean().sqrt()),
+    ('a1', lambda g, p: (torch.maximum(g / p, p / g) < 1.25).float().mean()),
+    ('a2', lambda g, p: (torch.maximum(g / p, p / g) < 1.25 ** 2).float().mean()),
+    ('a3', lambda g, p: (torch.maximum(g / p, p / g) < 1.25 ** 3).float().mean()),
+)
+
+
+def _to_gt_resolution(pred, gt, how):
+    """'resize': bilinear (align_corners) to the ground-truth size; 'top-center': paste into a zero map, flush with the
+    bottom edge and centred horizontally (predictions made on a top-cropped image)."""
     import torch.nn.functional as funct
-    crop = config.crop == 'garg'
-    batch_size, _, gt_height, gt_width = gt.shape
-    abs_diff = abs_rel = sq_rel = rmse = rmse_log = a1 = a2 = a3 = 0.0
-    pred = funct.interpolate(pred, gt.shape[-2:], mode='bilinear', align_corners=True)
-    if crop:
-        crop_mask = torch.zeros(gt.shape[-2:], dtype=torch.bool, device=gt.device)
-        y1, y2 = int(0.40810811 * gt_height), int(0.99189189 * gt_height)
-        x1, x2 = int(0.03594771 * gt_width), int(0.96405229 * gt_width)
-        crop_mask[y1:y2, x1:x2] = True
-    for pred_i, gt_i in zip(pred, gt):
-        gt_i, pred_i = torch.squeeze(gt_i), torch.squeeze(pred_i)
-        valid = (gt_i > config.min_depth) & (gt_i < config.max_depth)
-        valid = valid & crop_mask if crop else valid
-        gt_i, pred_i = gt_i[valid], pred_i[valid]
-        if use_gt_scale:
-            pred_i = pred_i * torch.median(gt_i) / torch.median(pred_i)
-        pred_i = pred_i.clamp(config.min_depth, config.max_depth)
-        thresh = torch.max((gt_i / pred_i), (pred_i / gt_i))
-        a1 += (thresh < 1.25).float().mean()
-        a2 += (thresh < 1.25 ** 2).float().mean()
-        a3 += (thresh < 1.25 ** 3).float().mean()
-        diff_i = gt_i - pred_i
-        abs_diff += torch.mean(torch.abs(diff_i))
-        abs_rel += torch.mean(torch.abs(diff_i) / gt_i)
-        sq_rel += torch.mean(diff_i ** 2 / gt_i)
-        rmse += torch.sqrt(torch.mean(diff_i ** 2))
-        rmse_log += torch.sqrt(torch.mean((torch.log(gt_i) - torch.log(pred_i)) ** 2))
-    return torch.tensor([a / batch_size for a in [abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3]]).type_as(gt)
+    if how == 'resize':
+        if tuple(pred.shape[-2:]) == tuple(gt.shape[-2:]):
+            return pred
+        return funct.interpolate(pred, size=gt.shape[-2:], mode='bilinear', align_corners=True)
+    if how != 'top-center':
+        raise NotImplementedError('Depth scale function {} not implemented.'.format(how))
+    canvas = pred.new_zeros(gt.shape)
+    dh, dw = gt.shape[2] - pred.shape[2], (gt.shape[3] - pred.shape[3]) // 2
+    canvas[:, :, dh:dh + pred.shape[2], dw:dw + pred.shape[3]] = pred
+    return canvas
+
+
+def compute_depth_metrics(config, gt, pred, use_gt_scale=True):
+    """[abs_rel, sqr_rel, rmse, rmse_log, a1, a2, a3], summed over the images that have valid pixels and divided by the
+    batch size (the reference's convention, utils/depth.py:258-324).  config: .min_depth, .max_depth, .crop ('' | 'garg')
+    and optionally .scale_output ('resize' | 'top-center'); gt, pred: [B,1,H,W] depth maps."""
+    B, _, H, W = gt.shape
+    pred = _to_gt_resolution(pred, gt, getattr(config, 'scale_output', 'resize'))
+    inside = torch.ones((H, W), dtype=torch.bool, device=gt.device)
+    if config.crop == 'garg':
+        inside.zero_()
+        inside[int(_GARG_ROWS[0] * H):int(_GARG_ROWS[1] * H), int(_GARG_COLS[0] * W):int(_GARG_COLS[1] * W)] = True
+    totals = torch.zeros(len(_DEPTH_METRICS), dtype=torch.float64)
+    for g_img, p_img in zip(gt[:, 0], pred[:, 0]):
+        keep = inside & (g_img > config.min_depth) & (g_img < config.max_depth)
+        if not bool(keep.any()):
+            continue
+        g, p = g_img[keep], p_img[keep]
+        if use_gt_scale:                                  # median scaling of the (scale-ambiguous) prediction
+            p = p * (g.median() / p.median())
+        p = p.clamp(config.min_depth, config.max_depth)
+        totals += torch.stack([fn(g, p) for _, fn in _DEPTH_METRICS]).double().cpu()
+    return (totals / B).type_as(gt)

@@ -291,6 +291,57 @@ def case_step(gen):
     return fx
 
 
+def case_host(gen):
+    """Outputs of the reference's host-side helpers on small inputs (batch plumbing, depth utilities, camera / pose
+    algebra, evaluation metrics): the drop-in modules must reproduce them."""
+    import types
+    import torch.nn.functional as F
+    from packnet_sfm.geometry.camera import Camera as RefCamera
+    from packnet_sfm.geometry.camera_utils import scale_intrinsics as ref_scale_intrinsics
+    from packnet_sfm.geometry.pose_utils import invert_pose as ref_invert_pose
+    from packnet_sfm.losses.loss_base import ProgressiveScaling as RefProgressiveScaling
+    from packnet_sfm.models import model_utils as RMU
+    from packnet_sfm.utils import depth as RD
+    from packnet_sfm.utils import image as RI
+    fx = {}
+    B, H, W = 2, 16, 24
+    rgb = torch.rand(B, 3, H, W, generator=gen)
+    ctx = [torch.rand(B, 3, H, W, generator=gen) for _ in range(2)]
+    K = kitti_K(B, H, W).float()
+    batch = {'rgb': rgb, 'rgb_context': ctx, 'intrinsics': K}
+    flipped = RMU.flip_batch_input({k: (list(v) if isinstance(v, list) else v.clone()) for k, v in batch.items()})
+    inv = [torch.rand(B, 1, H >> i, W >> i, generator=gen) + 0.05 for i in range(4)]
+    out = RMU.flip_output({'inv_depths': [t.clone() for t in inv]})
+    up = RMU.upsample_output({'inv_depths': [t.clone() for t in inv]}, mode='nearest', align_corners=None)
+    fx['model_utils'] = dict(batch=batch, flipped=flipped, inv_depths=inv, flipped_output=out['inv_depths'],
+                             upsampled=up['inv_depths'])
+    depth = 10 * torch.rand(B, 1, H, W, generator=gen)
+    depth[depth < 2] = 0.
+    fx['depth'] = dict(depth=depth, depth2inv=RD.depth2inv(depth.clone()), inv2depth=RD.inv2depth(inv[0]),
+                       normalized=RD.inv_depths_normalize([t.clone() for t in inv]))
+    fx['image'] = dict(match_bilinear=RI.match_scales(rgb, inv, 4), match_nearest=RI.match_scales(inv[0], inv, 4, mode='nearest', align_corners=None),
+                       scaled_K=ref_scale_intrinsics(K.clone(), 0.5, 0.25))
+    fx['progressive'] = {ps: [RefProgressiveScaling(ps, 4)(p) for p in (0.0, 0.1, 0.26, 0.5, 0.76, 1.0)] for ps in (0.0, 0.25)}
+    vec = torch.cat([0.1 * torch.randn(B, 3, generator=gen), 0.05 * torch.randn(B, 3, generator=gen)], 1).double()
+    T = RefPose.from_vec(vec, 'euler')
+    cam = RefCamera(K.double(), Tcw=T)
+    d64 = (1 + torch.rand(B, 1, H, W, generator=gen)).double()
+    Xw = cam.reconstruct(d64, 'w')
+    fx['camera'] = dict(K=K.double(), vec=vec, T=T.mat, Tinv=ref_invert_pose(T.mat), depth=d64, Xc=cam.reconstruct(d64, 'c'),
+                        Xw=Xw, uv_w=cam.project(Xw, 'w'), uv_c=cam.project(Xw, 'c'), Kinv=cam.Kinv,
+                        K_half=cam.scaled(0.5).K, TT=(T @ T).mat)
+    gt = 80 * torch.rand(3, 1, 40, 60, generator=gen)
+    gt[gt < 10] = 0
+    pred = 5 + 60 * torch.rand(3, 1, 20, 30, generator=gen)
+    mets = {}
+    for crop in ('', 'garg'):
+        for ugs in (True, False):
+            cfg = types.SimpleNamespace(crop=crop, min_depth=0.0, max_depth=80.0, scale_output='resize')
+            mets[(crop, ugs)] = RD.compute_depth_metrics(cfg, gt, pred, ugs)
+    fx['metrics'] = dict(gt=gt, pred=pred, values=mets)
+    return fx
+
+
 def case_slim(gen):
     """The d = 4 (`num_3d_feat`) variants of the packing / unpacking blocks and PackNetSlim01('1A') at 32x64."""
     fx = {}
@@ -408,6 +459,7 @@ def case_slim(gen):
                              automask_loss=True, clip_loss=0.0, padding_mode='border'), True),
         ('loss_reflection', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='mean',
                                  automask_loss=False, clip_loss=0.0, padding_mode='reflection'), False)), keep_clip=True)
+    fx['host'] = case_host(gen)
     fx['packnet01_1B'] = dict(seed=1357, rgb=rgb, disps=[d.detach() for d in disps], dys=dys,
                               disps_f64=[d.detach() for d in disps64],
                               grad_norms_f64={n: float(t.norm()) for n, t in zip(names, g64)},

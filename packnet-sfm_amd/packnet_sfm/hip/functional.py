@@ -94,11 +94,13 @@ class _WgradStream:
     _cb_queued = False
 
     @classmethod
-    def note_use(cls, ctx, *params):
-        """Called in forward for every parameter a node will produce a gradient for (no-op when the node is not being
-        recorded, e.g. validation under torch.no_grad()).  Entries of graphs that are never back-propagated make the next
-        step fall back to the in-node wait and are dropped at the end of that step's backward pass."""
-        if not any(ctx.needs_input_grad):
+    def note_use(cls, recording, *params):
+        """Called in forward for every parameter a node will produce a gradient for.  `recording`: autograd was recording
+        when the op was CALLED (torch.is_grad_enabled() outside the Function -- inside forward grad mode is always off and
+        needs_input_grad ignores no_grad), so validation under torch.no_grad() is not counted.  Entries of graphs that are
+        never back-propagated make the next step fall back to the in-node wait and are dropped at the end of that step's
+        backward pass."""
+        if not recording:
             return
         for p in params:
             if p is not None and p.requires_grad:
@@ -182,7 +184,7 @@ class Conv2dFn(Function):
     """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (exact-fp32 MFMA implicit GEMM)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, recording=True):
         x = x.contiguous()
         need_dx = ctx.needs_input_grad[0]
         wp_fwd, wp_bwd = cache.get(weight, need_dx)
@@ -193,7 +195,7 @@ class Conv2dFn(Function):
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
-        _WgradStream.note_use(ctx, weight, bias)
+        _WgradStream.note_use(recording, weight, bias)
         return y
 
     @staticmethod
@@ -216,11 +218,11 @@ class Conv2dFn(Function):
             dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias)
         if wait is not None:
             wait()
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def conv2d(x, weight, bias, cache):
-    return Conv2dFn.apply(x, weight, bias, cache)
+    return Conv2dFn.apply(x, weight, bias, cache, torch.is_grad_enabled())
 
 
 class Conv2dStride2Fn(Function):
@@ -228,7 +230,7 @@ class Conv2dStride2Fn(Function):
     data-gradient is the stride-1 backward-data kernel on dy zero-upsampled onto the input grid."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache):
+    def forward(ctx, x, weight, bias, cache, recording=True):
         x = x.contiguous()
         need_dx = ctx.needs_input_grad[0]
         wp_fwd, wp_bwd = cache.get(weight, need_dx)
@@ -237,7 +239,7 @@ class Conv2dStride2Fn(Function):
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
-        _WgradStream.note_use(ctx, weight, bias)
+        _WgradStream.note_use(recording, weight, bias)
         return y
 
     @staticmethod
@@ -264,11 +266,11 @@ class Conv2dStride2Fn(Function):
             dw, db = ops.conv2d_backward_weight_strided(x, dy, ks, 2, want_bias=has_bias)
         if wait is not None:
             wait()
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def conv2d_stride2(x, weight, bias, cache):
-    return Conv2dStride2Fn.apply(x, weight, bias, cache)
+    return Conv2dStride2Fn.apply(x, weight, bias, cache, torch.is_grad_enabled())
 
 
 class GroupNormActFn(Function):
@@ -332,12 +334,12 @@ class Conv3d1to8Fn(Function):
     or 4 (PackNetSlim01 / PackNetSAN01)."""
 
     @staticmethod
-    def forward(ctx, p, w3, b3):
+    def forward(ctx, p, w3, b3, recording=True):
         p = p.contiguous()
         out = ops.conv3d_forward(p, w3.detach().contiguous(), b3.detach().contiguous())
         ctx.save_for_backward(p, w3)
         ctx.params = (w3, b3)
-        _WgradStream.note_use(ctx, w3, b3)
+        _WgradStream.note_use(recording, w3, b3)
         return out
 
     @staticmethod
@@ -359,11 +361,11 @@ class Conv3d1to8Fn(Function):
             dw3, db3 = ops.conv3d_backward_weight(p, dout)
         if wait is not None:
             wait()
-        return dp, dw3, db3
+        return dp, dw3, db3, None
 
 
 def conv3d_1to8(p, w3, b3):
-    return Conv3d1to8Fn.apply(p, w3, b3)
+    return Conv3d1to8Fn.apply(p, w3, b3, torch.is_grad_enabled())
 
 
 class ComposePackWeightFn(Function):
@@ -376,13 +378,13 @@ class ComposePackWeightFn(Function):
     kernels do the composition and its two gradients (dW2 = forward stencil of dW_eff, dW3 = weight-gradient stencil)."""
 
     @staticmethod
-    def forward(ctx, W2, W3):
+    def forward(ctx, W2, W3, recording=True):
         W2pad = torch.nn.functional.pad(W2.detach(), (1, 1, 1, 1)).contiguous()      # [C, 8D, k+2, k+2]
         w3 = W3.detach().contiguous()
         Weff = ops.conv3d_backward_data(W2pad, w3)                                    # [C, D, k+2, k+2]
         ctx.save_for_backward(W2pad, w3)
         ctx.params = (W2, W3)
-        _WgradStream.note_use(ctx, W2, W3)
+        _WgradStream.note_use(recording, W2, W3)
         return Weff
 
     @staticmethod
@@ -396,11 +398,11 @@ class ComposePackWeightFn(Function):
             dW2 = ops.conv3d_forward(g, w3, torch.zeros(w3.shape[0], device=g.device, dtype=g.dtype))[:, :, 1:-1, 1:-1].contiguous()
         if ctx.needs_input_grad[1]:
             dW3, _ = ops.conv3d_backward_weight(g, W2pad)
-        return dW2, dW3
+        return dW2, dW3, None
 
 
 def compose_pack_weight(W2, W3):
-    return ComposePackWeightFn.apply(W2, W3)
+    return ComposePackWeightFn.apply(W2, W3, torch.is_grad_enabled())
 
 
 class PackBorderSplitFn(Function):

@@ -197,6 +197,51 @@ def test_semisup_model_plumbing(emulated_kernels):
     assert torch.is_tensor(ev['inv_depths']) and 'loss' not in ev
 
 
+def test_side_stream_bookkeeping(emulated_kernels):
+    """The per-pass use counts behind the weight-gradient side stream (hip/functional.py:_WgradStream): recorded only for
+    nodes that will be back-propagated, a parameter used twice or a non-leaf weight is never left in flight, and the
+    end-of-backward callback drops everything -- also after a no_grad evaluation or a graph that is never
+    back-propagated.  (On CPU tensors no stream is involved; the decisions are the same code.)"""
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    WS = HF._WgradStream
+    WS._uses.clear()
+    decisions = []
+    orig = WS.side_ok.__func__
+
+    def spy(cls, *params):
+        ok = orig(cls, *params)
+        decisions.append(ok)
+        return ok
+    WS.side_ok = classmethod(spy)
+    try:
+        torch.manual_seed(0)
+        m = Conv2D(4, 16, 3, 1)
+        x = torch.randn(1, 4, 6, 8)
+        with torch.no_grad():
+            m(x)
+        assert not WS._uses, 'evaluation under no_grad must not be counted'
+        m(x).sum().backward()                              # weight used once: may stay in flight
+        assert decisions == [True] and not WS._uses
+        decisions.clear()
+        (m(x).sum() + m(2 * x).sum()).backward()           # the same weight used twice in one graph: wait in the node
+        assert decisions == [False, False] and not WS._uses
+        decisions.clear()
+        m(x)                                               # graph that is never back-propagated leaves a stale count ...
+        assert WS._uses
+        m(x).sum().backward()                              # ... which only makes the next pass conservative, then clears
+        assert decisions == [False] and not WS._uses
+        decisions.clear()
+        m(x).sum().backward()
+        assert decisions == [True]
+        decisions.clear()
+        w_eff = m.conv_base.weight * 2.0                   # a non-leaf weight is consumed by compute-stream kernels
+        HF.conv2d(x, w_eff, m.conv_base.bias, HF.PackedConvWeight(volatile=True)).sum().backward()
+        assert decisions == [False] and not WS._uses
+    finally:
+        WS.side_ok = classmethod(orig)
+
+
 def test_pose_vec2mat(emulated_kernels):
     """Pose.from_vec on the fused kernel vs the oracle's euler2mat composition (forward and gradient)."""
     from oracle import packnet_oracle as O

@@ -27,6 +27,8 @@ def _worker(rank, world, port, q):
     assert hvd.size() == world and hvd.rank() == rank
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    net.add_module('unused', torch.nn.Linear(3, 3))        # never reached by the loss: its bucket slots must reduce as zeros
+    used = lambda t: net[3](net[2](net[1](net[0](t))))     # noqa: E731
     opt = hvd.DistributedOptimizer(torch.optim.Adam(net.parameters(), lr=1e-2), named_parameters=net.named_parameters(),
                                    compression=hvd.Compression.none, bucket_bytes=300)   # tiny buckets -> several collectives
     data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
@@ -35,13 +37,18 @@ def _worker(rank, world, port, q):
     grads = None
     for it in range(3):
         opt.zero_grad()
-        loss = ((net(data[shard]) - target[shard]) ** 2).mean()
+        loss = ((used(data[shard]) - target[shard]) ** 2).mean()
         loss.backward()
         opt.synchronize()
         if it == 0:
+            assert all(p.grad is not None for p in net.parameters()), 'unused parameters must still hold a (zero) gradient'
+            assert float(net.unused.weight.grad.abs().sum()) == 0.0
             grads = [p.grad.clone() for p in net.parameters()]
         opt.step()
     val = hvd.allreduce(torch.tensor([float(rank)]), average=True, name='x')
+    from packnet_sfm.utils.horovod import reduce_value, world_size
+    assert world_size() == world
+    assert abs(float(reduce_value(torch.tensor([1.0 + rank]), average=False, name='s')) - 3.0) < 1e-6
     q.put((rank, [g.tolist() for g in grads], [p.detach().tolist() for p in net.parameters()], float(val)))
     dist.destroy_process_group()
 
@@ -60,15 +67,17 @@ def test_gloo_world2_gradient_average():
     # single-process reference on the whole batch
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+    net.add_module('unused', torch.nn.Linear(3, 3))
+    used = lambda t: net[3](net[2](net[1](net[0](t))))     # noqa: E731
     opt = torch.optim.Adam(net.parameters(), lr=1e-2)
     data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
     target = torch.randn(8, 1, generator=torch.Generator().manual_seed(2))
     ref_grads = None
     for it in range(3):
         opt.zero_grad()
-        ((net(data) - target) ** 2).mean().backward()
+        ((used(data) - target) ** 2).mean().backward()
         if it == 0:
-            ref_grads = [p.grad.clone() for p in net.parameters()]
+            ref_grads = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in net.parameters()]
         opt.step()
     for rank, grads, params, val in results:
         assert abs(val - 0.5) < 1e-6

@@ -253,6 +253,8 @@ def ssim(x, y, C1=1e-4, C2=9e-4):
 def photometric_map(est, image, ssim_w=0.85, C1=1e-4, C2=9e-4):
     """calc_photometric_loss for one (estimate, image) pair, clip_loss == 0.  :188-223 and :169-186"""
     l1 = (est - image).abs()
+    if not ssim_w > 0.0:
+        return l1                       # L1 only: the reference keeps the 3-channel map (:205-213)
     s = torch.clamp((1. - ssim(est, image, C1, C2)) / 2., 0., 1.)
     return ssim_w * s.mean(1, True) + (1 - ssim_w) * l1.mean(1, True)
 

@@ -458,7 +458,9 @@ def case_slim(gen):
         ('loss_border', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='min',
                              automask_loss=True, clip_loss=0.0, padding_mode='border'), True),
         ('loss_reflection', dict(num_scales=4, ssim_loss_weight=0.85, smooth_loss_weight=0.001, photometric_reduce_op='mean',
-                                 automask_loss=False, clip_loss=0.0, padding_mode='reflection'), False)), keep_clip=True)
+                                 automask_loss=False, clip_loss=0.0, padding_mode='reflection'), False),
+        ('loss_l1_only', dict(num_scales=4, ssim_loss_weight=0.0, smooth_loss_weight=0.01, photometric_reduce_op='mean',
+                              automask_loss=False, clip_loss=0.0), False)), keep_clip=True)
     fx['host'] = case_host(gen)
     fx['packnet01_1B'] = dict(seed=1357, rgb=rgb, disps=[d.detach() for d in disps], dys=dys,
                               disps_f64=[d.detach() for d in disps64],

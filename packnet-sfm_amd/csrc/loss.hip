@@ -611,7 +611,12 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
                               int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
                               void* stream) {
   if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
-  if (!(ssim_weight > 0.f)) { set_error("photometric_forward: ssim_weight must be > 0"); return -1; }
+  // ssim_weight == 0 is the reference's L1-only loss, whose per-CHANNEL maps only coincide with this kernel's channel
+  // mean under the 'mean' reduce without clipping (multiview_photometric_loss.py:205-219, 238-246)
+  if (!(ssim_weight >= 0.f) || (ssim_weight == 0.f && reduce_op == 0)) {
+    set_error("photometric_forward: ssim_weight must be > 0 (or == 0 with the 'mean' reduce op)");
+    return -1;
+  }
   if (automask && reduce_op != 0) { set_error("photometric_forward: automask requires the 'min' reduce op"); return -1; }
   hipStream_t s = (hipStream_t)stream;
   int e = (int)hipMemsetAsync(loss_sum, 0, sizeof(double), s);

@@ -52,8 +52,13 @@ class MultiViewPhotometricLoss(LossBase):
         # configurations the fused kernels do not cover fail loudly instead of silently taking another path
         if padding_mode not in ('zeros', 'border', 'reflection'):
             raise ValueError('Unknown padding_mode {}'.format(padding_mode))
-        if not ssim_loss_weight > 0.0:
-            raise NotImplementedError('ssim_loss_weight must be > 0 for the fused gfx950 photometric kernel')
+        if ssim_loss_weight < 0.0:
+            raise ValueError('ssim_loss_weight must be >= 0')
+        if ssim_loss_weight == 0.0 and (photometric_reduce_op == 'min' or clip_loss > 0.0):
+            # L1-only: the reference then reduces / clips per-CHANNEL maps (:205-219, :238-246), which only coincides
+            # with the kernel's channel mean under the plain 'mean' reduce
+            raise NotImplementedError("ssim_loss_weight == 0 is supported with photometric_reduce_op='mean' and "
+                                      "clip_loss == 0 only")
 
     @property
     def logs(self):

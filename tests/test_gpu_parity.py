@@ -94,7 +94,7 @@ def test_unpack_golden():
 
 
 @pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
-                                  'loss_reflection'])
+                                  'loss_reflection', 'loss_l1_only'])
 def test_loss_golden(name):
     P.case_loss(name, DEV)
 

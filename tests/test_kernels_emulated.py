@@ -76,7 +76,7 @@ def test_compose_pack_weight(emulated_kernels):
 
 
 @pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
-                                  'loss_reflection'])
+                                  'loss_reflection', 'loss_l1_only'])
 def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 

@@ -2,8 +2,10 @@
 """bench.py -- images/sec of the PackNet01(+PoseNet) self-supervised TRAINING step on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # spawns its own N ranks (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --height 384 --width 1280 --batch 2    # BASELINE.json configs[2] shape
 
 One "step" = zero_grad -> PackNet01 + PoseNet forward -> multi-view photometric loss (4 scales, SSIM+L1, automask,
 smoothness) -> backward -> (N>1: RCCL gradient all-reduce, overlapped with backward) -> Adam, on a synthetic
@@ -61,34 +63,58 @@ def build_model(device, depth_net='PackNet01'):
     return model.to(device).train()
 
 
-def cpu_baseline(H, W, seconds_budget=30.0):
+def _cpu_baseline_one(H, W, threads, batch_size, steps):
     """The oracle (oracle/packnet_oracle.py: the reference's algorithm restated on stock torch CPU ops) timed on
-    this box's host cores: full training steps (fwd + loss + bwd + Adam) at batch 1, 1 warm-up + up to 2 timed."""
+    this box's host cores with `threads` intra-op threads: full training steps (fwd + loss + bwd + Adam), 1 warm-up +
+    `steps` timed; returns the best step time in seconds."""
     from oracle import packnet_oracle as O
-    threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     sd = {k: v.requires_grad_(True) for k, v in O.init_params(O.packnet01_param_shapes('1A'), seed=42).items()}
     psd = {k: v.requires_grad_(True) for k, v in O.init_params(O.posenet_param_shapes(2), seed=43).items()}
     opt = torch.optim.Adam([{'params': list(sd.values()), 'lr': 2e-4}, {'params': list(psd.values()), 'lr': 2e-4}])
-    batch = synthetic_batch(1, H, W, 1234, 'cpu')
+    batch = synthetic_batch(batch_size, H, W, 1234, 'cpu')
     kw = {k: LOSS_DEFAULTS[k] for k in ('num_scales', 'ssim_loss_weight', 'smooth_loss_weight', 'C1', 'C2',
                                          'photometric_reduce_op', 'automask_loss')}
     times = []
-    t_start = time.time()
-    for i in range(3):
+    for i in range(1 + steps):
         t0 = time.time()
         opt.zero_grad()
         out = O.selfsup_forward(sd, psd, batch, flip=False, **kw)
         out['loss'].sum().backward()
         opt.step()
-        dt = time.time() - t0
         if i > 0:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and times:
+            times.append(time.time() - t0)
+    return min(times)
+
+
+def cpu_baseline(H, W, seconds_budget=45.0):
+    """CPU baseline = the oracle's training step on the host cores of this box (rank 0, N=1 only).  The intra-op thread
+    count is SWEPT (8/16/32/64, capped at the cores present: oversubscribing all 128+ hardware threads measured 3x slower
+    than 8 threads in round 1) at batch 1, the best count is re-timed at batch 4 (SURVEY.md 8d asks for both), and the
+    best images/sec is reported with `cores` = the threads that produced it.  Bounded sample: every leg is 1 warm-up + 1
+    timed step and the sweep stops when the time budget is spent."""
+    ncpu = os.cpu_count() or 8
+    saved = torch.get_num_threads()
+    t_start = time.time()
+    sweep = {}
+    for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+        sweep[th] = 1.0 / _cpu_baseline_one(H, W, th, 1, 1)
+        if time.time() - t_start > seconds_budget:
             break
-    best = min(times)
-    return {'value': round(1.0 / best, 4), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle (torch CPU fp32 restatement of the reference path), full train step, batch 1, %dx%d, '
-                      '1 warm-up + %d timed steps, best' % (H, W, len(times))}
+    best_th = max(sweep, key=sweep.get)
+    best, best_b = sweep[best_th], 1
+    b4 = None
+    if time.time() - t_start < seconds_budget:
+        b4 = 4.0 / _cpu_baseline_one(H, W, best_th, 4, 1)
+        if b4 > best:
+            best, best_b = b4, 4
+    torch.set_num_threads(saved)
+    return {'value': round(best, 4), 'unit': 'images/sec', 'cores': best_th, 'kind': 'port',
+            'thread_sweep_batch1': {str(k): round(v, 4) for k, v in sweep.items()},
+            'batch4_at_best_threads': round(b4, 4) if b4 else None, 'host_cpus': ncpu,
+            'sample': 'oracle (torch CPU fp32 restatement of the reference path), full train step (fwd+loss+bwd+Adam), %dx%d, '
+                      '1 warm-up + 1 timed step per leg; best of the thread sweep at batch 1 and of batch 4 at that thread '
+                      'count (batch %d won)' % (H, W, best_b)}
 
 
 def measured_traffic():
@@ -106,6 +132,22 @@ def measured_traffic():
         return None
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) -- the analogue of the reference's `mpirun -np NGPUS` (Makefile:42-53)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: the only mode the host driver supports
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -117,40 +159,51 @@ def main():
     ap.add_argument('--depth-net', default='PackNet01', choices=['PackNet01', 'PackNetSlim01'],
                     help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-prof', action='store_true', help='do not bracket the conv kernels with events')
+    ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
     ap.add_argument('--optimizer', default='torch', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
-    ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the timed region here')
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='replay the whole step as a hipGraph (packnet_sfm/hip/graph.py); auto = on for 1 GPU, off for N>1 '
+                         '(the per-bucket RCCL all-reduce is launched from autograd hooks while backward runs)')
+    ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps here')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(_self_launch(args))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP kernels have no CPU fallback')
+    from packnet_sfm.hip import functional as HF
     from packnet_sfm.hip import ops
     from packnet_sfm.rccl import hvd
 
     hvd.init()
     rank, world = hvd.rank(), hvd.size()
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
-    device = torch.device('cuda', hvd.local_rank() % torch.cuda.device_count())
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    device = torch.device('cuda', hvd.local_rank() % ndev)
     torch.cuda.set_device(device)
 
     H, W, B = args.height, args.width, args.batch
     model = build_model(device, args.depth_net)
     batch = synthetic_batch(B, H, W, 1234 + rank, device)
+    force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
+    ddp = world > 1 or force_ddp
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and not ddp)
+    if use_graph and ddp:
+        raise SystemExit('--graph on is for 1 GPU (collectives are launched from autograd hooks, outside any capture)')
     groups = [{'name': 'Depth', 'params': list(model.depth_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0},
               {'name': 'Pose', 'params': list(model.pose_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0}]
     if args.optimizer == 'flat':
         from packnet_sfm.rccl.flat_adam import FlatAdam
         optimizer = FlatAdam(groups)
     else:
-        optimizer = torch.optim.Adam(groups, fused=True)
-    force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
-    if world > 1 or force_ddp:
+        optimizer = torch.optim.Adam(groups, fused=True, capturable=use_graph)
+    if ddp:
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                              compression=hvd.Compression.none, force_collectives=force_ddp)
 
-    def step():
+    def eager_step():
         optimizer.zero_grad()
         out = model(batch, progress=0.0)
         out['loss'].backward()
@@ -158,52 +211,57 @@ def main():
         return out['loss']
 
     def fence():
-        if world > 1 or force_ddp:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the library autotunes every layer shape on first use and the caching allocator settles over the first steps: at
-    # least two untimed steps always run, whatever --warmup says
-    for _ in range(max(0, 2 - args.warmup)):
-        step()
+    # The library autotunes every layer shape on first use (timing synchronises, so it cannot happen inside a capture) and
+    # the caching allocator settles over the first steps: two untimed EAGER steps always run first, whatever --warmup says.
+    for _ in range(2):
+        eager_step()
+    fence()
+    step = eager_step
+    if use_graph:
+        from packnet_sfm.hip.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, batch, progress=0.0)
+        step = lambda: graphed(batch)      # noqa: E731  (copies the batch into the static inputs, draws the flip, replays)
     for _ in range(args.warmup):
         loss = step()
     fence()
-    if not args.no_prof:
-        ops.prof_reset()
-        ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if not args.no_prof:
-        ops.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.detach().float().item())
 
-    if rank == 0 and args.layer_table and not args.no_prof:
-        ops.prof_dump(args.layer_table)
-    timed = None
+    # ---- roofline of the dominant kernel: per-launch hipEvent timing inside the library (pnsfm_prof_*), on the stream
+    # each kernel is launched on.  Events cannot bracket the nodes of a replayed graph, so the SAME step is run eagerly
+    # for a few extra steps right after the timed region: (a) as trained -- weight gradients overlapped with the
+    # data-gradient chain on the side stream, i.e. durations of kernels SHARING the GPU -- and (b) with the side stream
+    # off, i.e. each kernel alone (kernel quality).  rocprofv3 of this command shows the same kernels in both regions.
+    timed = iso = None
     if not args.no_prof:
-        timed = (ops.prof_collect(0), ops.prof_collect(1))
-        # The timed region overlaps every weight-gradient kernel with the data-gradient chain on a second HIP stream
-        # (DESIGN.md 3e), so its per-launch durations are those of kernels SHARING the GPU.  Two extra, untimed steps
-        # with the side stream off give the same kernels' durations in isolation (kernel quality, not step throughput).
-        from packnet_sfm.hip import functional as HF
+        def profiled(nsteps):
+            eager_step()
+            fence()
+            ops.prof_reset()
+            ops.prof_enable(True)
+            for _ in range(nsteps):
+                eager_step()
+            fence()
+            ops.prof_enable(False)
+            return ops.prof_collect(0), ops.prof_collect(1)
+        timed = profiled(3)
+        if rank == 0 and args.layer_table:
+            ops.prof_dump(args.layer_table)
         was = HF._WgradStream.enabled
         HF.set_wgrad_stream(False)
-        step()
-        fence()
-        ops.prof_reset()
-        ops.prof_enable(True)
-        for _ in range(2):
-            step()
-        fence()
-        ops.prof_enable(False)
+        iso = profiled(2)
         HF.set_wgrad_stream(was)
     if rank == 0:
         images = B * world * args.steps
@@ -211,45 +269,57 @@ def main():
         scale = (H * W) / (192.0 * 640.0)
         roofline = None
         traffic = measured_traffic()
-        if not args.no_prof:
+        if timed is not None:
             (ms0, fl0, n0), (ms1, fl1, n1) = timed     # conv2d_mfma_kernel (forward + backward-data), conv2d_wgrad_kernel
-            ims0, ifl0, in0 = ops.prof_collect(0)
-            ims1, ifl1, in1 = ops.prof_collect(1)
+            (ims0, ifl0, in0), (ims1, ifl1, in1) = iso
             if n0 > 0 and ms0 > 0:
                 ach = fl0 / (ms0 * 1e-3) / 1e12
+                # flops the conv kernels actually EXECUTE per step (the Conv3d*Conv2d collapse removes ~35 % of the
+                # reference's 1 232 GFLOP/image) -> utilisation of the matrix pipe over the whole step
+                exec_gflop_step = (fl0 + fl1) / 3.0 / 1e9
                 roofline = {
                     'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)',
                     'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'measured_in': '3 eager steps right after the timed region (same kernels and shapes; events cannot '
+                                   'bracket nodes of a replayed hipGraph)' if use_graph else '3 eager steps after the timed region',
                     # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
                     'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
                     'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4),
                     'flop_per_launch_avg': round(fl0 / n0, 1),
                     'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,
                                      'launches': int(n1), 'avg_launch_ms': round(ms1 / max(n1, 1), 4)},
-                    'conv_kernel_time_over_step_time': round((ms0 + ms1) * 1e-3 / elapsed, 4),   # > 1: the two streams overlap
-                    'isolated': {       # same kernels, 2 extra steps with the weight-gradient side stream off
+                    'isolated': {       # same kernels, 2 steps with the weight-gradient side stream off
                         'achieved': round(ifl0 / (ims0 * 1e-3) / 1e12, 2) if ims0 > 0 else None,
                         'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
                         'avg_launch_ms': round(ims0 / max(in0, 1), 4),
                         'wgrad_achieved': round(ifl1 / (ims1 * 1e-3) / 1e12, 2) if ims1 > 0 else None},
-                    'whole_step_vs_mfma_peak': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'whole_step_vs_mfma_peak': {
+                        'reference_flops': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                        'executed_flops': round(exec_gflop_step / 1e3 / (elapsed / args.steps) / FP32_MFMA_PEAK_TFLOPS, 4),
+                        'executed_gflop_per_step': round(exec_gflop_step, 1)},
                 }
+        backend = dist.get_backend() if dist.is_initialized() else None
+        shape_tag = ('BASELINE.json configs[1]' if (H, W, B) == (192, 640, 4) else
+                     ('BASELINE.json configs[2] shape' if (H, W, B) == (384, 1280, 2) else 'custom shape'))
         result = {
             'metric': 'images/sec %s self-sup train %dx%d' % (args.depth_net, H, W), 'value': round(value, 3), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.depth_net + '(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
-                                   'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (
-                                       H, W, B, 'BASELINE.json configs[1]' if (H, W, B) == (192, 640, 4) else
-                                       ('BASELINE.json configs[2] shape' if (H, W, B) == (384, 1280, 2) else 'custom shape')),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 6)},
+                                   'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (H, W, B, shape_tag),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 6),
+                       'step_launch': 'hipGraph replay (one graph per flip state)' if use_graph else 'eager',
+                       'collective_backend': backend, 'devices_visible': ndev},
             'roofline': roofline,
         }
+        if world > ndev:
+            result['config']['note'] = ('%d ranks share %d device(s): functional rehearsal of the N>1 path over gloo, not a '
+                                        'scaling measurement' % (world, ndev))
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
         print(json.dumps(result), flush=True)
-    if world > 1 or force_ddp:
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -45,8 +45,16 @@ static hipEvent_t get_event() {
   return e;
 }
 
+// true while `stream` is being captured into a hipGraph: nothing that synchronises (autotune timing, profiling events that
+// are read back with hipEventElapsedTime) may be enqueued then
+bool stream_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || stream_capturing(stream)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.a = get_event();
@@ -58,7 +66,7 @@ void prof_begin(int kind, double flops, hipStream_t stream, const int* meta) {
 }
 
 void prof_end(int kind, hipStream_t stream) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || stream_capturing(stream)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_recs[kind].empty()) return;
   hipEventRecord(g_recs[kind].back().b, stream);
@@ -66,6 +74,7 @@ void prof_end(int kind, hipStream_t stream) {
 #else
 void prof_begin(int, double, hipStream_t, const int*) {}
 void prof_end(int, hipStream_t) {}
+bool stream_capturing(hipStream_t) { return false; }
 #endif
 
 }  // namespace pnsfm

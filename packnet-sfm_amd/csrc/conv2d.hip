@@ -431,6 +431,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     const std::array<int, 7> key = {kind_tag + 10 * S, B, Cin, Cout, H, W, ks};
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
+    if (it == g_tuned.end() && stream_capturing(stream)) {
+      // a shape first seen inside a hipGraph capture cannot be timed (timing synchronises): un-tuned default, not cached
+    } else {
     if (it == g_tuned.end()) {
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
@@ -454,6 +457,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       tune_db_append(key, best);
     }
     conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 1, S, (it->second[0] >> 8) & 1);
+    }
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
@@ -870,6 +874,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     const std::array<int, 7> key = {2 + 10 * S, B, Cin, Cout, a.cstride, W, ks};
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
+    if (it == g_tuned.end() && stream_capturing(s)) {
+      // first seen inside a hipGraph capture: keep the analytic split (timing would synchronise)
+    } else {
     if (it == g_tuned.end()) {
       float best_ms = 1e30f;
       int best_split = a.splitP, prev_tps = -1;
@@ -888,6 +895,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
       tune_db_append(key, it->second);
     }
     a.splitP = it->second[0];
+    }
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;

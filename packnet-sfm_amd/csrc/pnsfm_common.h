@@ -103,5 +103,6 @@ int conv_pick_MT(int Mc);
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);
 void prof_end(int kind, hipStream_t stream);
+bool stream_capturing(hipStream_t stream);   // hipGraph capture in progress on `stream`
 
 }  // namespace pnsfm

@@ -91,7 +91,7 @@ class _WgradStream:
     _streams = {}
     _pending = set()
     _uses = {}          # id(parameter) -> [forward uses whose backward has not run yet, shared-in-this-step flag]
-    _cb_queued = False
+    _cb_task = None     # autograd graph-task id whose end-of-backward callback is queued (None: no backward in flight)
 
     @classmethod
     def note_use(cls, recording, *params):
@@ -114,8 +114,12 @@ class _WgradStream:
         """Called once in backward: may this node's parameter gradients be left in flight on the side stream until the
         end-of-backward join (True), or must the node wait for them itself (False)?"""
         ok = True
-        if not cls._cb_queued:          # first parameter gradient of this backward pass: arrange the end-of-pass clean-up
-            cls._cb_queued = True
+        task = torch._C._current_graph_task_id()
+        if cls._cb_task != task:        # first parameter gradient of this backward pass: arrange the end-of-pass clean-up
+            if cls._cb_task is not None:
+                # the previous backward pass never reached its callback (it raised): join what it left in flight now
+                cls._join_pending()
+            cls._cb_task = task
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(cls._end_of_backward)
         for p in params:
@@ -123,6 +127,11 @@ class _WgradStream:
                 continue
             u = cls._uses.get(id(p))
             if not p.is_leaf or u is None or u[1]:
+                ok = False
+            # AccumulateGrad only hands the pointer over when .grad is None and nothing hooks the gradient; otherwise it
+            # runs `p.grad += dw` (or the hook) on the COMPUTE stream, which knows nothing about the side stream: gradient
+            # accumulation over several backward() calls, zero_grad(set_to_none=False), Tensor.register_hook
+            if p.is_leaf and (p.grad is not None or p._backward_hooks):
                 ok = False
             if u is not None:
                 u[0] -= 1
@@ -162,11 +171,15 @@ class _WgradStream:
     def _end_of_backward(cls):
         """Autograd-engine callback at the end of a backward pass: the compute streams wait for the weight gradients
         still in flight, and the per-pass use counts are dropped."""
-        cls._cb_queued = False
+        cls._cb_task = None
+        cls._join_pending()
+        cls._uses.clear()
+
+    @classmethod
+    def _join_pending(cls):
         for dev in list(cls._pending):
             torch.cuda.current_stream(dev).wait_stream(cls.get(dev))
         cls._pending.clear()
-        cls._uses.clear()
 
 
 def set_wgrad_stream(on):

@@ -1,0 +1,103 @@
+"""Whole training steps as hipGraphs.
+
+One PackNet01 self-supervised step is ~1 200 kernel launches, about half of them shorter than the ~20-40 us the host
+needs to issue one (Python autograd node + ctypes call + allocator).  Measured on MI355X the eager step leaves the GPU idle
+for 3.7 ms of 50 (rocprofv3 kernel trace, low-resolution encoder/decoder layers and the loss), and the gap grows as the
+kernels get faster.  `GraphedTrainStep` therefore captures zero_grad -> forward -> loss -> backward -> optimizer step
+ONCE into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm: every launch of libpnsfm_hip.so goes to torch's current
+stream, which is the capturing stream; the weight-gradient side stream forks/joins through captured events) and replays
+it with a single host call per step.
+
+What stays outside the graph because it is Python control flow in the reference:
+  * the random left-right flip of the depth-network input (SfmModel.py:84 of the reference draws `random.random()` per
+    step): one graph per flip state is captured and the draw picks the graph, so the RNG sequence is the reference's;
+  * the learning-rate schedule: capturable torch optimizers keep `lr` / `step` in device tensors, FlatAdam does the same.
+
+Requirements: static shapes (the batch is copied into static input tensors before each replay), an optimizer that is
+capture-safe (`torch.optim.Adam(..., fused=True, capturable=True)` or `packnet_sfm.rccl.flat_adam.FlatAdam`), at least
+one eager step before capture (autotuning of the conv kernels synchronises and cannot run inside a capture), and no host
+read-back inside the model's forward.
+"""
+import random
+
+import torch
+
+from packnet_sfm.hip import functional as HF
+
+
+def _clone_static(obj):
+    if torch.is_tensor(obj):
+        return obj.clone()
+    if isinstance(obj, dict):
+        return {k: _clone_static(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_clone_static(v) for v in obj]
+    return obj
+
+
+def _copy_into(dst, src):
+    if torch.is_tensor(dst):
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_into(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _copy_into(d, s)
+
+
+class GraphedTrainStep:
+    """
+    Parameters
+    ----------
+    model : SfmModel-like module; `model(batch, progress=...)` returns {'loss': Tensor[1], ...}
+    optimizer : capture-safe optimizer (see module docstring); may be a rccl.hvd.DistributedOptimizer ONLY for world size 1
+    example_batch : dict of device tensors (shapes/dtypes are frozen)
+    progress : float, handed to the model (ProgressiveScaling input; constant inside a graph)
+    flip_prob : probability of the mirrored depth-network pass (None: read model.flip_lr_prob)
+    """
+
+    def __init__(self, model, optimizer, example_batch, progress=0.0, flip_prob=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('GraphedTrainStep needs an MI355X (hipGraph capture)')
+        self.model, self.optimizer, self.progress = model, optimizer, progress
+        self.flip_prob = float(getattr(model, 'flip_lr_prob', 0.0) if flip_prob is None else flip_prob)
+        self.batch = _clone_static(example_batch)
+        self.graphs, self.loss = {}, {}
+        self._pool = None
+        flips = [False] if self.flip_prob <= 0.0 else ([True] if self.flip_prob >= 1.0 else [False, True])
+        for flip in flips:
+            self._capture(flip)
+
+    def _capture(self, flip):
+        model, opt = self.model, self.optimizer
+        # every graph must contain its own weight re-pack launches: invalidate the packed copies first
+        HF.bump_weight_epoch()
+        g = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        kw = {} if self._pool is None else {'pool': self._pool}
+        model._flip_override = flip
+        try:
+            with torch.cuda.graph(g, **kw):
+                out = model(self.batch, progress=self.progress)
+                out['loss'].backward()
+                opt.step()
+        finally:
+            model._flip_override = None
+        if self._pool is None:
+            self._pool = g.pool()
+        self.graphs[flip] = g
+        self.loss[flip] = out['loss'].detach()
+        HF.bump_weight_epoch()          # eager code after a replay must re-pack too
+
+    def __call__(self, batch=None):
+        """One training step; returns the (device, static) loss tensor of the replayed graph."""
+        if batch is not None:
+            _copy_into(self.batch, batch)
+        draw = random.random() < self.flip_prob        # drawn every step, like the reference, so the RNG sequence matches
+        flip = draw if len(self.graphs) > 1 else next(iter(self.graphs))
+        self.graphs[flip].replay()
+        HF.bump_weight_epoch()
+        return self.loss[flip]

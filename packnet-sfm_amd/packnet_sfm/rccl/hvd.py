@@ -37,13 +37,15 @@ def allreduce(tensor, average=True, name=None):
     if _state['size'] == 1:
         return tensor.clone()
     out = tensor.clone()
-    on_cpu = not out.is_cuda and dist.get_backend() == 'nccl'
-    if on_cpu:
+    backend = dist.get_backend()
+    if backend == 'nccl' and not out.is_cuda:          # RCCL reduces device memory only
         out = out.cuda()
+    elif backend != 'nccl' and out.is_cuda:            # gloo (CPU tests / shared-device rehearsal): stage through the host
+        out = out.cpu()
     dist.all_reduce(out, op=dist.ReduceOp.SUM)
     if average:
         out = out / _state['size']
-    return out.cpu() if on_cpu else out
+    return out.to(tensor.device)
 
 
 def broadcast_parameters(params, root_rank=0):
@@ -53,6 +55,10 @@ def broadcast_parameters(params, root_rank=0):
     items = params.items() if isinstance(params, dict) else params
     for _, p in items:
         dist.broadcast(p.data if hasattr(p, 'data') else p, src=root_rank)
+    # `.data` writes do not bump tensor._version: invalidate the packed conv-weight copies explicitly.  (Any other raw
+    # `.data` update of a conv weight -- an EMA, p.data.copy_() -- must be followed by HF.bump_weight_epoch() as well.)
+    from packnet_sfm.hip import functional as HF
+    HF.bump_weight_epoch()
 
 
 class Compression:
@@ -74,10 +80,27 @@ class DistributedOptimizer:
         self._reducer.zero_grad()
 
     def synchronize(self):
+        """Wait for the averaged gradients (idempotent within a step, so the horovod idiom
+        `optimizer.synchronize(); clip_grad_norm_(...); optimizer.step()` reduces once)."""
         self._reducer.synchronize()
 
+    class _SkipSync:
+        def __init__(self, outer):
+            self.outer = outer
+
+        def __enter__(self):
+            self.outer._skip_sync = True
+
+        def __exit__(self, *exc):
+            self.outer._skip_sync = False
+
+    def skip_synchronize(self):
+        """Context manager: `with optimizer.skip_synchronize(): optimizer.step()` after a manual synchronize() (horovod API)."""
+        return DistributedOptimizer._SkipSync(self)
+
     def step(self, closure=None):
-        self._reducer.synchronize()
+        if not self.__dict__.get('_skip_sync', False):
+            self._reducer.synchronize()
         return self._opt.step(closure) if closure is not None else self._opt.step()
 
     def __getattr__(self, name):

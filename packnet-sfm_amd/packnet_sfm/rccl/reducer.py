@@ -31,7 +31,10 @@ def init_process_group(backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
     if (world > 1 or os.environ.get('PNSFM_FORCE_DDP') == '1') and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # RCCL needs one device per rank ("duplicate GPU" otherwise).  More ranks than devices (a 1-GPU box rehearsing
+            # the N>1 path) fall back to gloo with host-staged buckets: functional, not a performance path.
+            ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            backend = 'nccl' if ndev >= int(os.environ.get('LOCAL_WORLD_SIZE', world)) and ndev > 0 else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
@@ -48,6 +51,7 @@ class _Bucket:
         n = sum(p.numel() for p in params)
         self.flat = torch.zeros(n, device=device, dtype=dtype)
         self.pending = len(params)
+        self.launched = False
         self.work = None
         self.event = None
         off = 0
@@ -77,6 +81,7 @@ class GradBucketReducer:
         # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG, so the CPU tests scale afterwards
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._fused_avg = bool(average) and backend == 'nccl'
+        self._host_staged = False       # set below: gloo + device tensors -> stage each bucket through host memory
         self._reduce_op = dist.ReduceOp.AVG if self._fused_avg else dist.ReduceOp.SUM
         params = [p for p in params if p.requires_grad]
         if not params:
@@ -94,13 +99,16 @@ class GradBucketReducer:
             cur_bytes += nbytes
         if cur:
             self._close(cur)
-        self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self._host_staged = backend == 'gloo' and self.device.type == 'cuda'
+        self.side_stream = torch.cuda.Stream(device=self.device) if (self.device.type == 'cuda' and not self._host_staged) else None
         self._hooks = []
         for b in self.buckets:
             for p in b.params:
                 p.grad = None
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
         self._launched = 0
+        self._next = 0          # index of the next bucket to launch
+        self._synced = False
 
     def _close(self, params):
         b = _Bucket(params, params[0].device, params[0].dtype)
@@ -112,9 +120,17 @@ class GradBucketReducer:
         def hook(param):
             bucket.pending -= 1
             if bucket.pending == 0:
-                self._gather(bucket)
-                self._launch(bucket)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Launch complete buckets strictly in bucket-index order (a complete bucket waits for its predecessors): every
+        rank issues the same sequence of collectives even when ranks see different sets of unused parameters."""
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            b = self.buckets[self._next]
+            self._gather(b)
+            self._launch(b)
+            self._next += 1
 
     @staticmethod
     def _gather(bucket):
@@ -137,10 +153,16 @@ class GradBucketReducer:
 
     def _launch(self, bucket):
         self._launched += 1
+        bucket.launched = True
         if self.world == 1 and not self.force:
             return
         op = self._reduce_op
-        if self.side_stream is not None:
+        if self._host_staged:
+            host = bucket.flat.cpu()                    # synchronises: rehearsal path only
+            dist.all_reduce(host, op=op, group=self.group)
+            bucket.flat.copy_(host)
+            bucket.work = None
+        elif self.side_stream is not None:
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
                 bucket.work = dist.all_reduce(bucket.flat, op=op, group=self.group, async_op=True)
@@ -152,17 +174,24 @@ class GradBucketReducer:
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+            b.launched = False
             for p in b.params:
                 p.grad = None
         self._launched = 0
+        self._next = 0
+        self._synced = False
 
     def synchronize(self):
         """Block the compute stream until every bucket is reduced; buckets whose hooks never all fired (unused
-        parameters) are reduced now.  Applies the averaging."""
-        for b in self.buckets:
-            if b.pending != 0 and b.work is None:      # some parameters got no gradient: gather what exists, reduce now
-                self._gather(b)
-                self._launch(b)
+        parameters) are reduced now, in bucket-index order on every rank (ranks may see different sets of unused
+        parameters; the collectives must still pair up).  Applies the averaging.  Idempotent until zero_grad()."""
+        if self._synced:
+            return
+        self._synced = True
+        for b in self.buckets[self._next:]:            # some parameters got no gradient: gather what exists, reduce now
+            self._gather(b)
+            self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()

@@ -224,17 +224,47 @@ def test_side_stream_bookkeeping(emulated_kernels):
         m(x).sum().backward()                              # weight used once: may stay in flight
         assert decisions == [True] and not WS._uses
         decisions.clear()
+        m(x).sum().backward()                              # .grad already defined (gradient accumulation): AccumulateGrad
+        assert decisions == [False] and not WS._uses       # adds on the compute stream -> the node must wait itself
+        decisions.clear()
+        m.zero_grad(set_to_none=True)
         (m(x).sum() + m(2 * x).sum()).backward()           # the same weight used twice in one graph: wait in the node
         assert decisions == [False, False] and not WS._uses
         decisions.clear()
+        m.zero_grad(set_to_none=True)
         m(x)                                               # graph that is never back-propagated leaves a stale count ...
         assert WS._uses
         m(x).sum().backward()                              # ... which only makes the next pass conservative, then clears
         assert decisions == [False] and not WS._uses
         decisions.clear()
+        m.zero_grad(set_to_none=True)
         m(x).sum().backward()
         assert decisions == [True]
         decisions.clear()
+        m.zero_grad(set_to_none=True)
+        h = m.conv_base.weight.register_hook(lambda g: g * 1.0)   # a tensor hook runs on the compute stream
+        m(x).sum().backward()
+        assert decisions == [False]
+        h.remove()
+        decisions.clear()
+        m.zero_grad(set_to_none=True)
+
+        class Boom(torch.autograd.Function):               # a backward pass that raises never reaches its callback ...
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError('boom')
+        with pytest.raises(RuntimeError):
+            Boom.apply(m(x)).sum().backward()
+        m.zero_grad(set_to_none=True)
+        decisions.clear()
+        m(x).sum().backward()                              # ... the next pass still queues its own (graph-task id differs)
+        assert WS._cb_task is None and not WS._uses
+        decisions.clear()
+        m.zero_grad(set_to_none=True)
         w_eff = m.conv_base.weight * 2.0                   # a non-leaf weight is consumed by compute-stream kernels
         HF.conv2d(x, w_eff, m.conv_base.bias, HF.PackedConvWeight(volatile=True)).sum().backward()
         assert decisions == [False] and not WS._uses

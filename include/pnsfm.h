@@ -60,9 +60,10 @@ int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float*
  * The first call for a new shape times the candidate configurations on the caller's stream (it synchronises), like
  * `torch.backends.cudnn.benchmark = True` in the reference (trainers/horovod_trainer.py:19). */
 int pnsfm_set_autotune(int on);
-/* Un-tuned default of the forward/backward-data kernel's patch staging: 0 = through registers, 1 = double-buffered
- * LDS-DMA (global_load_lds) issued in slices between the taps.  The autotuner times both; this switch exists for tests.
- * Clears the tuning cache. */
+/* Un-tuned default of the forward/backward-data kernel: 0 = halo patch staged through registers, 1 = patch double-buffered
+ * by LDS-DMA (global_load_lds) issued in slices between the taps, 2 = the fully pipelined kernel (patch AND per-kernel-row
+ * weight slabs double-buffered by LDS-DMA, one barrier per kernel row, up to 160 KB of LDS).  The autotuner times all
+ * three; this switch exists for tests.  Clears the tuning cache. */
 int pnsfm_set_conv_variant(int lds_dma);
 /* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and
  * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen

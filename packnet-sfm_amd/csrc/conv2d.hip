@@ -32,7 +32,9 @@ int conv_pick_MT(int Mc) { return (round_up(Mc, 64) == round_up(Mc, 32)) ? 2 : 1
 int conv_pack_MP(int Mc) { return round_up(Mc, 32 * conv_pick_MT(Mc)); }
 int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
 
-static const size_t kMaxSmem = 64 * 1024;
+static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
+static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
+static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
 static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0,
@@ -62,6 +64,24 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     if (rows > H) rows = H;
     g.PH = (rows - 1) * S + ks;
     g.PW = (W - 1) * S + ks;
+  }
+  g.G = 0;
+  if (DMA == 2) {
+    // pipelined variant: LDS = 2 patch buffers + 2 weight-slab buffers of one kernel row (G = ks taps) each.  The K-chunk
+    // is the largest of {32 (1x1 only), 16, 8} channels that still lets two workgroups share a CU's 160 KB.
+    g.G = (ks == 1) ? 1 : ks;
+    auto smem_pipe = [&](int CI) -> size_t {
+      return (2 * (size_t)round_up(CI * g.PH * g.PW, 64) + 2 * (size_t)g.G * CI * BM) * sizeof(float);
+    };
+    g.CI = (ks == 1 && g.KP > 16) ? 32 : (g.KP <= 8 ? 8 : 16);
+    while (smem_pipe(g.CI) > kPipeTwoBlocks && g.CI > 8) g.CI /= 2;
+    g.smem_bytes = smem_pipe(g.CI);
+    g.nchunks = ceil_div(g.KP, g.CI);
+    if (want_split < 1) want_split = 1;
+    if (want_split > g.nchunks) want_split = g.nchunks;
+    const int cps2 = ceil_div(g.nchunks, want_split);
+    g.splitK = ceil_div(g.nchunks, cps2);
+    return g.smem_bytes <= kMaxSmemPipe;
   }
   // shrink the channel chunk if the halo patch of a very wide image does not fit
   auto smem_for = [&](int CI) -> size_t {
@@ -94,7 +114,15 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S) {
   conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA, S);
   const long blocks = (long)B * g.tiles_per_img * (g.MP / (32 * g.MT));
   int split = 1;
-  if (blocks < 4 * 256 && g.nchunks >= 4) {
+  if (DA == 2) {
+    // pipelined variant: one wave per SIMD already runs at the matrix rate, so K is split only when the tiles cannot
+    // give (nearly) every CU one workgroup
+    if (blocks < 200 && g.nchunks >= 4) {
+      split = (int)((256 + blocks - 1) / blocks);
+      if (split > g.nchunks / 2) split = g.nchunks / 2;
+      if (split < 1) split = 1;
+    }
+  } else if (blocks < 4 * 256 && g.nchunks >= 4) {
     split = (int)((6 * 256 + blocks - 1) / blocks);
     if (split > g.nchunks / 2) split = g.nchunks / 2;
     if (split < 1) split = 1;
@@ -161,13 +189,67 @@ struct ConvArgs {
   int B, Cin, Cout, H, W, KS;   // H, W: OUTPUT size
   int S, Hi, Wi;                // stride (1 | 2) and INPUT size (Hi = H, Wi = W when S == 1)
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
-  int pstride;        // DMA variant: floats between the two patch buffers
+  int pstride;        // DMA variants: floats between the two patch buffers
+  int G;              // pipelined variant: taps per weight stage
   float invPW, invPS;
 };
 
 // out-of-image / padded elements are read from here: selecting the POINTER (address | zero page) keeps every staging
 // load unconditional; hipcc turns `ok ? x[off] : 0` into a branch around the load plus s_waitcnt vmcnt(0) per element
 __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
+
+
+// ---- epilogue shared by the forward / backward-data kernels: D row = (r&3) + 8*(r>>2) + 4*half, col = l32.
+// The 16*MT bias values a lane needs are fetched up front in ONE batch (the store loop used to fetch each one right
+// before its store and wait for it: 32 dependent L2 round trips per workgroup), and the plain-store / atomic (split-K)
+// paths are separate loops so the compiler can stream the stores.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int co0, int half,
+                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT]) {
+  const int HW = a.H * a.W;
+  float* yb = a.y + (size_t)b * a.Cout * HW;
+  const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
+  if (add_bias) {
+    float bval[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bval[mt][r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+      }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bval[mt][r];
+  }
+  int poff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) poff[nt] = oy[nt] * a.W + ox[nt];
+  if (a.splitK == 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (co < a.Cout && pvalid[nt]) yb[(size_t)co * HW + poff[nt]] = acc[mt][nt][r];
+      }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (co < a.Cout && pvalid[nt]) atomicAdd(yb + (size_t)co * HW + poff[nt], acc[mt][nt][r]);
+      }
+  }
+}
 
 // DMA = 0: the halo patch of a channel chunk is staged through registers (8 loads in flight per thread) between two
 //          barriers;
@@ -347,27 +429,197 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if constexpr (DMA) dma_cur ^= 1;
   }
 
-  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l32
-  float* yb = a.y + (size_t)b * a.Cout * HW;
-  const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+}
+
+
+// ---- pipelined variant (DMA == 2) ------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles, so ONE wave per SIMD saturates it as long as that
+// wave never waits: the kernel is organised so that nothing it waits for is on the critical path.
+//   * LDS holds two halo patches (K-chunk c and c+1) and two weight slabs (stage s and s+1); a stage is one kernel ROW
+//     of taps (G = ks taps x CI channels x BM output channels), so there is ONE barrier per kernel row instead of one per
+//     tap, and no ds_write at all: both operands arrive by LDS-DMA (global_load_lds, 16 bytes per lane for the weights);
+//   * at the top of stage s (after its barrier) the wave issues the DMA for stage s+1's slab and a slice of chunk c+1's
+//     patch, then runs stage s's MFMAs; the next barrier's vmcnt(0) finds those copies long finished;
+//   * operand fragments for the next batch of 4 k-steps are read from LDS before the current batch's MFMAs are issued.
+// With the data movement off the critical path the low-resolution layers no longer need a K-split across workgroups
+// (fills + fp32 atomics) to hide staging latency: 240 tiles on 256 CUs run at the matrix rate from one wave per SIMD.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
+  PNSFM_DYN_SMEM(float, smem);
+  constexpr int BM = 32 * MT;
+  const int PS = a.PH * a.PW;
+  const int ptotal = a.CI * PS;
+  const int G = a.G;
+  const int wslab = G * a.CI * BM;              // floats per weight slab (a multiple of 256)
+  float* const wbuf0 = smem + 2 * a.pstride;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int P = a.KS >> 1, KK = a.KS * a.KS;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = Hi * Wi;
+
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int t = blockIdx.x - b * a.tiles_per_img;
+  const int co0 = blockIdx.y * BM;
+  const int c_begin = blockIdx.z * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  if (c_end > a.nchunks) c_end = a.nchunks;
+
+  int py0, px0;
+  int boff[NT], oy[NT], ox[NT];
+  bool pvalid[NT];
+  if (a.mode == 0) {
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int y0 = ty * 4 * NT, x0 = tx * 32;
+    py0 = y0 * S - P;
+    px0 = x0 * S - P;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wave * NT + nt;
+      oy[nt] = y0 + row;
+      ox[nt] = x0 + l32;
+      pvalid[nt] = oy[nt] < H;
+      boff[nt] = (row * a.PW + l32) * S;
+    }
+  } else {
+    const int n0 = t * 128 * NT;
+    const int r0 = n0 / W;
+    py0 = r0 * S - P;
+    px0 = -P;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.Cout) {
-        const float bval = add_bias ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if (pvalid[nt]) {
-            float* dst = yb + (size_t)co * HW + oy[nt] * W + ox[nt];
-            const float v = acc[mt][nt][r] + bval;
-            if (a.splitK == 1) *dst = v; else atomicAdd(dst, v);
-          }
-        }
-      }
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wave * NT + nt) * 32 + l32;
+      pvalid[nt] = n < HW;
+      const int yy = pvalid[nt] ? n / W : r0;
+      oy[nt] = yy;
+      ox[nt] = pvalid[nt] ? n - yy * W : 0;
+      boff[nt] = ((yy - r0) * a.PW + ox[nt]) * S;
     }
   }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const float* xb = a.x + (size_t)b * a.Cin * HWi;
+  auto patch_src = [&](int ci0, int idx) -> const float* {
+    const int cil = (int)(((float)idx + 0.5f) * a.invPS);
+    const int e = idx - cil * PS;
+    const int r = (int)(((float)e + 0.5f) * a.invPW);
+    const int cc = e - r * a.PW;
+    const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
+    const bool ok = idx < ptotal && ci < a.Cin && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+    return ok ? xb + ((size_t)ci * HWi + yy * Wi + xx) : pnsfm_zero_page;
+  };
+  const int nld = (ptotal + 255) >> 8;            // patch DMA groups of 256 elements (64 per wave)
+  const int SG = KK / G;                          // stages (kernel rows) per K-chunk
+  const int per_stage = (nld + SG - 1) / SG;
+  const int nstage = (c_end - c_begin) * SG;
+  const size_t tap_stride = (size_t)a.KP * a.MP;
+  const int wpieces = wslab >> 8;                 // 1 KiB wave-instructions per weight slab
+  const int cilog = a.CI == 32 ? 5 : (a.CI == 16 ? 4 : 3);
+
+  // weight slab of stage (chunk c, kernel row g) -> LDS layout [tap in row][ci][BM]
+  auto issue_w = [&](int c, int g, float* dst) {
+    const int ci0 = c * a.CI, tap0 = g * G;
+    for (int p = wave; p < wpieces; p += 4) {
+      const int e = (p << 8) + (lane << 2);
+      const int m = e & (BM - 1);
+      const int r = e / BM;
+      const int ci = ci0 + (r & (a.CI - 1)), tp = tap0 + (r >> cilog);
+      const float* src = (ci < a.KP) ? a.wp + ((size_t)tp * tap_stride + (size_t)ci * a.MP + co0 + m) : pnsfm_zero_page;
+      pnsfm_glds16(src, dst + (p << 8));
+    }
+  };
+  auto issue_patch = [&](int c, int ld0, int ld1, float* dst) {
+    for (int ld = ld0; ld < ld1; ++ld) {
+      const int idx = ld * 256 + tid;
+      const float* src = patch_src(c * a.CI, idx);
+      if (idx < ptotal) pnsfm_glds4(src, dst + ld * 256 + wave * 64);
+    }
+  };
+
+  // prologue: chunk 0's patch and stage 0's slab
+  if (nstage > 0) {
+    issue_patch(c_begin, 0, nld, smem);
+    issue_w(c_begin, 0, wbuf0);
+  }
+  int c = c_begin, g = 0, pcur = 0;
+  for (int s = 0; s < nstage; ++s) {
+    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and meets the others: stage s's operands are in LDS, and
+                       // everyone is done with stage s-1 (its slab buffer, and at a chunk boundary its patch buffer, are free)
+    float* const patch = smem + pcur * a.pstride;
+    const float* const wcur = wbuf0 + (s & 1) * wslab;
+    if (s + 1 < nstage) {
+      const int gn = (g + 1 == SG) ? 0 : g + 1;
+      issue_w(gn == 0 ? c + 1 : c, gn, wbuf0 + ((s + 1) & 1) * wslab);
+      if (c + 1 < c_end) {
+        const int l0 = g * per_stage, l1 = (l0 + per_stage < nld) ? l0 + per_stage : nld;
+        issue_patch(c + 1, l0, l1, smem + (pcur ^ 1) * a.pstride);
+      }
+    }
+    // ---- stage s: G taps x CI/8 batches of 4 k-steps; fragments of batch q+1 are read before batch q's MFMAs
+    const int nb = a.CI >> 3, nq = G * nb;
+    int ky = (g * G) / a.KS, kx = (g * G) - ky * a.KS;
+    const float* wb = wcur + half * BM + l32;
+    const float* pb = patch + half * PS + ky * a.PW + kx;
+    float av[2][4][MT], bv[2][4][NT];
+    auto load = [&](int buf, const float* wq, const float* pq) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[buf][j][mt] = wq[j * 2 * BM + mt * 32];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[buf][j][nt] = pq[j * 2 * PS + boff[nt]];
+      }
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[buf][j][mt], bv[buf][j][nt], acc[mt][nt]);
+    };
+    // pointers of batch q: wq = wb + (tap_in_row * CI + 8*jb) * BM, pq = pb(tap) + 8*jb*PS
+    int jb = 0;
+    const float* wq = wb;
+    const float* pq = pb;
+    auto advance = [&]() {
+      if (++jb == nb) {                            // next tap of the row
+        jb = 0;
+        wq += 8 * BM;
+        if (++kx == a.KS) { kx = 0; ++ky; }
+        pb = patch + half * PS + ky * a.PW + kx;
+        pq = pb;
+      } else {
+        wq += 8 * BM;
+        pq += 8 * PS;
+      }
+    };
+    load(0, wq, pq);
+    int q = 0;
+    for (; q + 2 <= nq; q += 2) {
+      advance();
+      load(1, wq, pq);
+      mma(0);
+      if (q + 2 < nq) {
+        advance();
+        load(0, wq, pq);
+      }
+      mma(1);
+    }
+    if (q < nq) mma(0);                            // odd number of batches: the last one sits in buffer 0
+    if (++g == SG) { g = 0; ++c; pcur ^= 1; }
+  }
+
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
 }
 
 static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
@@ -382,6 +634,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.invPW = 1.0f / (float)g.PW;
   a.invPS = 1.0f / (float)(g.PH * g.PW);
   a.pstride = round_up(g.CI * g.PH * g.PW, 64);
+  a.G = g.G;
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }
@@ -394,7 +647,30 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
     else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);                 \
   } while (0)
-  if (g.DMA) PNSFM_CONV_DISPATCH(true);
+  if (g.DMA == 2) {
+#ifndef PNSFM_EMU
+    // more than 64 KB of dynamic LDS needs an explicit opt-in per kernel (once)
+#define PNSFM_PIPE_ATTR(MTv, NTv)                                                                                  \
+    do {                                                                                                           \
+      static bool done = false;                                                                                    \
+      if (!done && g.smem_bytes > 64 * 1024) {                                                                     \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_pipe_kernel<MTv, NTv>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSmemPipe) != hipSuccess) {    \
+          set_error("%s: cannot raise the dynamic LDS limit", what);                                               \
+          return -1;                                                                                               \
+        }                                                                                                          \
+        done = true;                                                                                               \
+      }                                                                                                            \
+    } while (0)
+#else
+#define PNSFM_PIPE_ATTR(MTv, NTv) do {} while (0)
+#endif
+    if (g.MT == 2 && g.NT == 2) { PNSFM_PIPE_ATTR(2, 2); PNSFM_LAUNCH((conv2d_pipe_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 2 && g.NT == 1) { PNSFM_PIPE_ATTR(2, 1); PNSFM_LAUNCH((conv2d_pipe_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 1 && g.NT == 2) { PNSFM_PIPE_ATTR(1, 2); PNSFM_LAUNCH((conv2d_pipe_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else { PNSFM_PIPE_ATTR(1, 1); PNSFM_LAUNCH((conv2d_pipe_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
+#undef PNSFM_PIPE_ATTR
+  } else if (g.DMA) PNSFM_CONV_DISPATCH(true);
   else PNSFM_CONV_DISPATCH(false);
 #undef PNSFM_CONV_DISPATCH
   return check_launch(what);
@@ -425,7 +701,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
   if (S != 1 && S != 2) { set_error("%s: unsupported stride %d", what, S); return -1; }
   ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks, S);
-  if (g.smem_bytes > kMaxSmem) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
+  if (g.smem_bytes > (g.DMA == 2 ? kMaxSmemPipe : kMaxSmem)) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
 #ifndef PNSFM_EMU
   if (autotune_enabled()) {
     const std::array<int, 7> key = {kind_tag + 10 * S, B, Cin, Cout, H, W, ks};
@@ -438,9 +714,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
-      const int ncfg = (conv_pick_MT(Cout) == 2) ? 8 : 4;
-      for (int cfg = 0; cfg < ncfg; ++cfg) {
-        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) & 1, fMT = (cfg >> 2) & 1;
+      const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
+      for (int cfg = 0; cfg < 6 * nMT; ++cfg) {
+        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % 3, fMT = cfg / 6;
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -456,7 +732,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       it = g_tuned.emplace(key, best).first;
       tune_db_append(key, best);
     }
-    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 1, S, (it->second[0] >> 8) & 1);
+    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 3, S, (it->second[0] >> 8) & 1);
     }
   }
 #endif
@@ -932,7 +1208,7 @@ int pnsfm_set_autotune(int on) {
 }
 
 int pnsfm_set_conv_variant(int lds_dma) {
-  g_default_dma = lds_dma ? 1 : 0;
+  g_default_dma = lds_dma < 0 ? 0 : (lds_dma > 2 ? 2 : lds_dma);
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned.clear();
   return 0;

@@ -15,6 +15,11 @@ typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
 // LDS-DMA: lane l of the wave copies 4 bytes from its own global address to lds_wave_base[l] (emulated synchronously)
 static inline void pnsfm_glds4(const float* src, float* lds_wave_base) { lds_wave_base[hipemu::my_lane()] = *src; }
+// 16-byte LDS-DMA: lane l copies 4 consecutive floats from its own global address to lds_wave_base[4*l .. 4*l+3]
+static inline void pnsfm_glds16(const float* src, float* lds_wave_base) {
+  float* d = lds_wave_base + 4 * hipemu::my_lane();
+  d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[3];
+}
 #define PNSFM_UNIFORM(i) (i)
 // buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
 struct pnsfm_buf { const char* base; unsigned bytes; };
@@ -40,6 +45,11 @@ __device__ __forceinline__ f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c)
 __device__ __forceinline__ void pnsfm_glds4(const float* src, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// global_load_lds_dwordx4: the 16-byte form (1 KiB per wave instruction); both addresses must be 16-byte aligned.
+__device__ __forceinline__ void pnsfm_glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 // tell the compiler a value is wave-uniform (moves it to an SGPR)
 #define PNSFM_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
@@ -91,7 +101,9 @@ struct ConvGeom {
   int PH, PW;         // staged input patch (rows, cols) incl. halo
   int KP, MP;         // padded K-channels / M-channels of the packed weight
   int nchunks, splitK;
-  int DMA;            // 1: input patch double-buffered in LDS and fetched by LDS-DMA (global_load_lds)
+  int DMA;            // 0: patch staged through registers; 1: patch double-buffered in LDS, fetched by LDS-DMA;
+                      // 2: fully pipelined kernel -- patch AND per-kernel-row weight slabs double-buffered by LDS-DMA
+  int G;              // DMA == 2: taps per weight stage (one kernel row; 1 for 1x1)
   size_t smem_bytes;
 };
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S = 1);   // H, W: output size; S: stride

@@ -81,12 +81,12 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
-@pytest.mark.parametrize('direct_a', [1, 0])
+@pytest.mark.parametrize('direct_a', [2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
-                                   (1, 96, 64, 6, 20, 3)])
+                                   (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
     """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; both
-    patch-staging variants of the forward/backward-data kernel (registers vs LDS-DMA)."""
+    variants of the forward/backward-data kernel (patch through registers, patch by LDS-DMA, fully pipelined)."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     _lib.get().pnsfm_set_conv_variant(direct_a)
@@ -325,12 +325,14 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     assert set(net_b.state_dict().keys()) == set(net_a.state_dict().keys())
 
 
+@pytest.mark.parametrize('variant', [0, 2])
 @pytest.mark.parametrize('shape', [(1, 9, 16, 8, 64, 7), (2, 6, 32, 12, 40, 5), (1, 16, 8, 3, 10, 3), (1, 4, 8, 6, 20, 3)])
-def test_conv2d_stride2(emulated_kernels, shape):
+def test_conv2d_stride2(emulated_kernels, shape, variant):
     """PoseNet's stride-2 convs (even and odd input sizes): strided forward / weight-gradient kernels and the
     zero-upsample + stride-1 backward-data path vs torch."""
     import torch.nn.functional as F
-    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.hip import _lib, functional as HF
+    _lib.get().pnsfm_set_conv_variant(variant)
     B, Cin, Cout, H, W, ks = shape
     g = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -348,3 +350,4 @@ def test_conv2d_stride2(emulated_kernels, shape):
     P.check(xh.grad, xr.grad, 1e-5, 'dgrad')
     P.check(wh.grad, wr.grad, 1e-5, 'wgrad')
     P.check(bh.grad, br.grad, 1e-5, 'dbias')
+    _lib.get().pnsfm_set_conv_variant(0)

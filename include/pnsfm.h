@@ -65,6 +65,10 @@ int pnsfm_set_autotune(int on);
  * weight slabs double-buffered by LDS-DMA, one barrier per kernel row, up to 160 KB of LDS).  The autotuner times all
  * three; this switch exists for tests.  Clears the tuning cache. */
 int pnsfm_set_conv_variant(int lds_dma);
+/* Un-tuned default of the weight-gradient kernel: 0 = generic ((ci, tap) columns, offset table; conv2d.hip), 1 = tap-major
+ * (dY fragments kept in registers across the taps, immediate LDS offsets, LDS-DMA double buffering; conv2d_wgrad2.hip) for
+ * the shapes it supports (stride 1, k in {1,3,5}, W % 8 == 0, >= 16 channels); the autotuner times both.  For tests. */
+int pnsfm_set_wgrad_variant(int tap_major);
 /* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and
  * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen
  * convolutions.  A process started with a complete database launches no candidate kernels. */

@@ -163,6 +163,21 @@ static void tune_db_append(const std::array<int, 7>& k, const std::array<int, 2>
   fclose(f);
 }
 
+// PNSFM_TUNE_LOG=<file>: every candidate the autotuner times is appended as
+//   kind B Cin Cout H W ks | variant/config split ms       (kind 0/1 forward/backward-data (+10*stride), 2 weight gradient)
+// -- the whole configuration landscape of a training step from one ordinary run.
+static std::string g_tune_log;
+static void tune_log(int kind, const std::array<int, 7>& k, int cfg, int split, float ms) {
+  if (g_tune_log.empty()) return;
+  FILE* f = fopen(g_tune_log.c_str(), "a");
+  if (!f) return;
+  fprintf(f, "%d %d %d %d %d %d %d | %d %d %.4f\n", k[0], k[1], k[2], k[3], k[4], k[5], k[6], cfg, split, ms);
+  fclose(f);
+  (void)kind;
+}
+
+static int g_wgrad_variant = 0;   // un-tuned default weight-gradient kernel: 0 generic, 1 tap-major (pnsfm_set_wgrad_variant)
+
 static bool autotune_enabled() {
 #ifdef PNSFM_EMU
   return false;
@@ -170,6 +185,8 @@ static bool autotune_enabled() {
   if (g_autotune < 0) {
     const char* e = getenv("PNSFM_AUTOTUNE");
     g_autotune = (e && e[0] == '0') ? 0 : 1;
+    const char* tl = getenv("PNSFM_TUNE_LOG");
+    if (tl && tl[0]) g_tune_log = tl;
     const char* db = getenv("PNSFM_TUNE_DB");
     if (db && db[0] && g_autotune == 1) {
       g_tune_db = db;
@@ -726,6 +743,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
           const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi); });
+          tune_log(0, key, NT | (DA << 4) | (fMT << 8), c.splitK, ms);
           if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8), c.splitK}; }
         }
       }
@@ -1065,6 +1083,16 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   if (S != 1 && S != 2) { set_error("backward_weight: unsupported stride %d", S); return -1; }
   hipStream_t s = (hipStream_t)stream;
   const int KK = ks * ks, N = Cin * KK, HW = H * W;
+  const int H0 = H, W0 = W;                                  // true image size (the 1x1 path below re-tiles H, W)
+  const bool v2_ok = S == 1 && wgrad2_supported(Cin, Cout, H0, W0, ks);
+  // tap-major kernel: split the 64-pixel tiles so that ~every CU gets one workgroup
+  auto v2_default_split = [&]() -> int {
+    const int base = wgrad2_base_blocks(Cin, Cout, ks), tiles = wgrad2_total_tiles(B, H0, W0);
+    int sp = (256 + base / 2) / base;
+    if (sp < 1) sp = 1;
+    if (sp > tiles) sp = tiles;
+    return sp;
+  };
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
@@ -1145,6 +1173,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, c);
     return check_launch("conv2d_backward_weight");
   };
+  int variant = (g_wgrad_variant == 1 && v2_ok) ? 1 : 0;
+  int split2 = v2_ok ? v2_default_split() : 1;
 #ifndef PNSFM_EMU
   if (autotune_enabled()) {
     const std::array<int, 7> key = {2 + 10 * S, B, Cin, Cout, a.cstride, W, ks};
@@ -1165,16 +1195,41 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         if (base * split < 192 && split < a.total_tiles) continue;   // cannot fill the chip: not worth timing
         if (base * split > 40L * 256 && split > 1) break;
         const float ms = time_on_stream(s, 2, [&]() { return enqueue(split); });
+        tune_log(2, key, 0, split, ms);
         if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; }
       }
-      it = g_tuned.emplace(key, std::array<int, 2>{best_split, 0}).first;
+      int best_variant = 0;
+      if (v2_ok) {     // tap-major kernel: pixel splits around one workgroup per CU
+        const int base2 = wgrad2_base_blocks(Cin, Cout, ks), tiles2 = wgrad2_total_tiles(B, H0, W0);
+        int prev = -1;
+        for (int want = 1; want <= tiles2; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
+          const int tps = ceil_div(tiles2, want);
+          const int split = ceil_div(tiles2, tps);
+          if (split == prev) continue;
+          prev = split;
+          if ((long)base2 * split < 160 && split < tiles2) continue;      // cannot fill the chip
+          if ((long)base2 * split > 6L * 256 && split > 1) break;
+          const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad2(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split, s); });
+          tune_log(2, key, 1, split, ms);
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 1; }
+        }
+      }
+      it = g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first;
       tune_db_append(key, it->second);
     }
-    a.splitP = it->second[0];
+    variant = (it->second[1] == 1 && v2_ok) ? 1 : 0;
+    if (variant == 1) split2 = it->second[0]; else a.splitP = it->second[0];
     }
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
+  if (variant == 1) {
+    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split2, wgrad2_base_blocks(Cin, Cout, ks) * split2};
+    prof_begin(1, flops, s, meta);
+    const int rc = enqueue_wgrad2(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split2, s);
+    prof_end(1, s);
+    return rc;
+  }
   const int meta[8] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(n_tiles * m_tiles * a.splitP)};
   prof_begin(1, flops, s, meta);
   const int rc = enqueue(a.splitP);
@@ -1204,6 +1259,13 @@ int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float*
 
 int pnsfm_set_autotune(int on) {
   g_autotune = on ? 1 : 0;
+  return 0;
+}
+
+int pnsfm_set_wgrad_variant(int tap_major) {
+  g_wgrad_variant = tap_major ? 1 : 0;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tuned.clear();
   return 0;
 }
 

@@ -1,0 +1,292 @@
+// conv2d_wgrad2.hip -- weight gradient of a stride-1 KxK convolution, tap-major formulation (K in {1, 3, 5}).
+//
+// Replaces the autograd weight gradient of nn.Conv2d in the reference's Conv2D / ResidualConv / Pack / Unpack blocks
+//   (/root/reference/packnet_sfm/networks/layers/packnet/layers01.py:28-36, 57-60, 235-246, 274-281) for the layers whose
+//   image width is a multiple of 8 -- every PackNet01 layer from 192x640 down to 12x40; the generic kernel in conv2d.hip
+//   keeps the rest (7x7, stride 2, 6x20) and the runtime autotuner times both where both apply.
+//
+//   dW[co][ci][ky][kx] = sum_{b, y, x} dY[b][co][y][x] * X[b][ci][y + ky - P][x + kx - P]
+//
+// GEMM view PER TAP: M = co, N = ci, K = pixels.  conv2d.hip's kernel makes (ci, tap) the N dimension, so a lane's B
+// operand is a gather through an offset table and the dY fragment is re-read for every 32 (ci, tap) columns.  Here a
+// wave owns a 32(co) x 32(ci) tile for ALL taps of a 3x3 (or one kernel row of a 5x5): TG accumulator tiles in AGPRs.
+//   * per 32-pixel K-segment the 16 dY fragments are read from LDS ONCE and reused by every tap (dY stays in registers);
+//   * the X fragment of (tap, k-step) is patch[ci = lane][pixel + tap offset]: the pixel and tap offsets are compile-time
+//     immediates of ds_read_b32 (tile geometry is a template parameter), lanes differ only by the channel stride PS, which
+//     is odd -> conflict-free; no offset table, no address arithmetic in the loop;
+//   * a workgroup = 2 x 2 waves = 64 co x 64 ci sharing one dY tile and one X halo patch of 64 pixels; both are
+//     DOUBLE-BUFFERED in LDS and filled by LDS-DMA (global_load_lds), issued in slices between the taps of the previous
+//     tile, so staging never stalls the matrix pipe (one wave per SIMD saturates v_mfma_f32_32x32x2_f32: 64 cycles each);
+//   * pixel tiles are split over blockIdx.z when (Cout/64)*(Cin/64) workgroups cannot fill 256 CUs; partial dW meet with
+//     fp32 atomics in a zero-filled buffer (un-split: plain stores).
+// Tile shapes: the 32 pixels of a K-segment are SR rows x FC columns with FC = 32, 16 or 8 (the largest that divides W), so
+// 24x80 and 12x40 feature maps tile exactly in x instead of falling back to linear pixel runs with full-width patches.
+// Roofline: MFMA-bound, 2*Cout*Cin*K*K*B*H*W flop against 157.3 TFLOP/s; LDS traffic 0.6 ds_read_b32 per MFMA.
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+namespace pnsfm {
+
+// out-of-image / padded elements are fetched from here (device variables are per translation unit without -fgpu-rdc)
+static __device__ __attribute__((aligned(16))) float w2_zero_page[64];
+
+struct Wgrad2Args {
+  const float* x;    // [B][Cin][H][W]
+  const float* dy;   // [B][Cout][H][W]
+  float* dw;         // [Cout][Cin][KS][KS]
+  float* dbias;      // [Cout] or null
+  int B, Cin, Cout, H, W;
+  int tiles_x, tiles_per_img, total_tiles, tiles_per_split, splitP;
+  int ci_tiles;      // gridDim.x = ci_tiles * (tap groups: KS for a 5x5, 1 otherwise)
+};
+
+template <int KS, int FC>
+struct Wgrad2Geom {
+  static constexpr int P = KS / 2, KK = KS * KS;
+  static constexpr int TG = (KS == 3) ? 9 : KS;       // taps a workgroup accumulates: the whole 3x3, else one kernel row
+  static constexpr int SR = 32 / FC;                    // rows of a 32-pixel K-segment
+  static constexpr int TR = 2 * SR;                     // rows of a 64-pixel tile (two segments stacked)
+  static constexpr int PH = TR + KS - 1, PW = FC + KS - 1, PSR = PH * PW;
+  static constexpr int PS = PSR | 1;                    // odd channel stride: lanes (= channels) hit distinct banks
+  static constexpr int DS = 65;                         // dY row stride (64 pixels + 1)
+  static constexpr int BUF = 64 * DS + 64 * PS;         // floats per LDS buffer
+  static constexpr int NPI = (PSR + 63) / 64;           // DMA instructions per patch channel
+};
+
+template <int KS, int FC>
+__global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
+  using Gm = Wgrad2Geom<KS, FC>;
+  constexpr int P = Gm::P, KK = Gm::KK, TG = Gm::TG, SR = Gm::SR, TR = Gm::TR, PH = Gm::PH, PW = Gm::PW, PSR = Gm::PSR;
+  constexpr int PS = Gm::PS, DS = Gm::DS, BUF = Gm::BUF, NPI = Gm::NPI;
+  PNSFM_DYN_SMEM(float, smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int ci_t = blockIdx.x % a.ci_tiles, tgi = blockIdx.x / a.ci_tiles;
+  const int ci0 = ci_t * 64, co0 = blockIdx.y * 64;
+  const int ky0 = (KS == 5) ? tgi : 0;                 // kernel row of this workgroup (5x5 only)
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int t_begin = blockIdx.z * a.tiles_per_split;
+  int t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.total_tiles) t_end = a.total_tiles;
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;
+  float bsum = 0.f;
+
+  // per-lane constants of the patch DMA: element e = lane + 64*k of a channel's PH x PW patch
+  int pr[NPI], pc[NPI];
+#pragma unroll
+  for (int k = 0; k < NPI; ++k) {
+    const int e = lane + 64 * k;
+    pr[k] = e / PW;
+    pc[k] = e - pr[k] * PW;
+  }
+  // dY DMA: lane = pixel of the tile (segment-major: p = s*32 + r*FC + c)
+  const int dyr = (lane >> 5) * SR + (lane & 31) / FC, dyc = (lane & 31) % FC;
+
+  // The DMA work of one tile: per wave 16 dY rows (one instruction each) + 16 channels x NPI patch instructions.  `i` is a
+  // compile-time constant at every call site (fully unrolled loops), so the per-lane patch coordinates stay in registers.
+  constexpr int DMA_PER_WAVE = 16 + 16 * NPI;
+  struct TileOrg { int b, y0, x0; };
+  auto tile_org = [&](int tt) -> TileOrg {
+    const int b = tt / a.tiles_per_img;
+    const int t = tt - b * a.tiles_per_img;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    return TileOrg{b, ty * TR, tx * FC};
+  };
+  auto issue_one = [&](const TileOrg& o, float* buf, int i) {
+    float* dys = buf;
+    float* patch = buf + 64 * DS;
+    if (i < 16) {
+      const int m = wave + 4 * i;                      // dY row (output channel) of this instruction
+      const int yy = o.y0 + dyr;
+      const bool ok = (co0 + m) < a.Cout && yy < H;
+      const float* src = ok ? a.dy + ((size_t)(o.b * a.Cout + co0 + m) * HW + yy * W + o.x0 + dyc) : w2_zero_page;
+      pnsfm_glds4(src, dys + m * DS);
+    } else {
+      const int q = i - 16;
+      const int cil = wave + 4 * (q / NPI), k = q % NPI;
+      const int yy = o.y0 - P + pr[k], xx = o.x0 - P + pc[k];
+      const bool in_patch = lane + 64 * k < PSR;
+      const bool ok = in_patch && (ci0 + cil) < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float* src = ok ? a.x + ((size_t)(o.b * a.Cin + ci0 + cil) * HW + yy * W + xx) : w2_zero_page;
+      if (in_patch) pnsfm_glds4(src, patch + cil * PS + 64 * k);
+    }
+  };
+
+  if (t_begin < t_end) {
+    const TileOrg o = tile_org(t_begin);
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) issue_one(o, smem, i);
+  }
+  int cur = 0;
+  for (int tt = t_begin; tt < t_end; ++tt) {
+    __syncthreads();    // this wave's DMA has landed (vmcnt(0)), everyone's has, and the other buffer is free again
+    float* buf = smem + cur * BUF;
+    float* nbuf = smem + (cur ^ 1) * BUF;
+    const TileOrg onext = tile_org(tt + 1 < t_end ? tt + 1 : tt);
+    const float* dys = buf;
+    const float* patch = buf + 64 * DS;
+    if (do_bias) {      // bias gradient rides along: 4 threads per dY row, 16 pixels each (tile already in LDS)
+      const int m = tid >> 2, q = tid & 3;
+      const float* row = dys + m * DS + q * 16;
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sacc += row[j];
+      bsum += sacc;
+    }
+    const float* Ab = dys + (32 * wm + l32) * DS + half;
+    const float* Bb = patch + (32 * wn + l32) * PS + half + ky0 * PW;
+    // 2 segments x TG taps = NGROUP groups of 16 MFMAs.  Software pipeline (everything below is fully unrolled, so the
+    // buffer parities are compile-time): the 16 X fragments of group g+1 are read from LDS BEFORE group g's MFMAs are
+    // issued, both segments' dY fragments are read at the top of the tile, and a slice of the NEXT tile's DMA is issued in
+    // front of each group (unconditionally -- past the last tile it re-fetches that tile into the idle buffer -- so that no
+    // branch splits the schedule).
+    constexpr int NGROUP = 2 * TG;
+    constexpr int PER_GROUP = (DMA_PER_WAVE + NGROUP - 1) / NGROUP;
+    float av[2][16], bv[2][16];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) av[sg][j] = Ab[sg * 32 + 2 * j];
+    auto load_b = [&](int gi, float (&dst)[16]) {
+      const int sg = gi / TG, tp = gi % TG;
+      const int ky = (KS == 3) ? tp / 3 : 0, kx = (KS == 3) ? tp % 3 : tp;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = (2 * j) / FC, c = (2 * j) % FC;
+        dst[j] = Bb[(sg * SR + r + ky) * PW + c + kx];
+      }
+    };
+    load_b(0, bv[0]);
+#pragma unroll
+    for (int gi = 0; gi < NGROUP; ++gi) {
+      // The group's share of the next tile's DMA is spread BETWEEN its MFMAs (one instruction + its ~10 address
+      // instructions every 16/PER_GROUP MFMAs hides in the 64-cycle shadow of the matrix instruction; issued as one clump
+      // it would leave the pipe idle), and the X fragments of group gi+1 are read half-way through.
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if ((j * PER_GROUP) / 16 != ((j + 1) * PER_GROUP) / 16 || PER_GROUP >= 16) {
+#pragma unroll
+          for (int u = (j * PER_GROUP) / 16; u < ((j + 1) * PER_GROUP) / 16; ++u) {
+            const int i = gi * PER_GROUP + u;
+            if (i < DMA_PER_WAVE) issue_one(onext, nbuf, i);
+          }
+        }
+        if (j == 8 && gi + 1 < NGROUP) load_b(gi + 1, bv[(gi + 1) & 1]);
+        acc[gi % TG] = pnsfm_mfma_32x32x2(av[gi / TG][j], bv[gi & 1][j], acc[gi % TG]);
+      }
+    }
+    cur ^= 1;
+  }
+  __syncthreads();      // the redundant prefetch behind the last tile must land before this workgroup's LDS is released
+
+  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half (co), col = l32 (ci); a lane owns the TG taps of 16 (co, ci) pairs
+  const int ci = ci0 + 32 * wn + l32;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout) {
+        float* dst = a.dw + ((size_t)co * a.Cin + ci) * KK + ky0 * KS;
+        if (a.splitP == 1) {
+#pragma unroll
+          for (int tp = 0; tp < TG; ++tp) dst[tp] = acc[tp][r];
+        } else {
+#pragma unroll
+          for (int tp = 0; tp < TG; ++tp) atomicAdd(dst + tp, acc[tp][r]);
+        }
+      }
+    }
+  }
+  if (do_bias) {
+    bsum += __shfl_down(bsum, 2);
+    bsum += __shfl_down(bsum, 1);
+    const int m = tid >> 2;
+    if ((tid & 3) == 0 && co0 + m < a.Cout) {
+      if (a.splitP == 1) a.dbias[co0 + m] = bsum; else atomicAdd(&a.dbias[co0 + m], bsum);
+    }
+  }
+}
+
+static int wgrad2_fc(int W) { return W % 32 == 0 ? 32 : (W % 16 == 0 ? 16 : (W % 8 == 0 ? 8 : 0)); }
+
+bool wgrad2_supported(int Cin, int Cout, int H, int W, int ks) {
+  if (ks != 1 && ks != 3 && ks != 5) return false;
+  if (wgrad2_fc(W) == 0) return false;
+  return Cin >= 16 && Cout >= 16 && H >= 1;
+}
+
+// total 64-pixel tiles of the launch (the unit the pixel split divides)
+int wgrad2_total_tiles(int B, int H, int W) {
+  const int fc = wgrad2_fc(W);
+  if (!fc) return 0;
+  const int TR = 64 / fc;
+  return B * (W / fc) * ceil_div(H, TR);
+}
+
+// workgroups of one pixel split
+int wgrad2_base_blocks(int Cin, int Cout, int ks) { return ceil_div(Cin, 64) * (ks == 5 ? 5 : 1) * ceil_div(Cout, 64); }
+
+template <int KS, int FC>
+static int launch_wgrad2(Wgrad2Args a, dim3 grid, hipStream_t s) {
+  using Gm = Wgrad2Geom<KS, FC>;
+  const size_t smem = 2 * (size_t)Gm::BUF * sizeof(float);
+#ifndef PNSFM_EMU
+  static bool raised = false;
+  if (!raised && smem > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad2_kernel<KS, FC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
+      return -1;
+    }
+    raised = true;
+  }
+#endif
+  PNSFM_LAUNCH((conv2d_wgrad2_kernel<KS, FC>), grid, dim3(256), smem, s, a);
+  return check_launch("conv2d_backward_weight (tap-major)");
+}
+
+int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
+                   int split, hipStream_t s) {
+  if (!wgrad2_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (tap-major): unsupported shape"); return -1; }
+  const int fc = wgrad2_fc(W);
+  Wgrad2Args a;
+  a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.tiles_x = W / fc;
+  a.tiles_per_img = a.tiles_x * ceil_div(H, 64 / fc);
+  a.total_tiles = B * a.tiles_per_img;
+  if (split < 1) split = 1;
+  if (split > a.total_tiles) split = a.total_tiles;
+  a.tiles_per_split = ceil_div(a.total_tiles, split);
+  a.splitP = ceil_div(a.total_tiles, a.tiles_per_split);
+  a.ci_tiles = ceil_div(Cin, 64);
+  const size_t N = (size_t)Cin * ks * ks;
+  if (a.splitP > 1) {
+    const bool joined = dbias == dw + (size_t)Cout * N;
+    int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
+    if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+    if (e) { set_error("conv2d_backward_weight: memset failed"); return e; }
+  }
+  dim3 grid(a.ci_tiles * (ks == 5 ? 5 : 1), ceil_div(Cout, 64), a.splitP);
+#define PNSFM_W2(KSv)                                                     \
+  do {                                                                    \
+    if (fc == 32) return launch_wgrad2<KSv, 32>(a, grid, s);              \
+    if (fc == 16) return launch_wgrad2<KSv, 16>(a, grid, s);              \
+    return launch_wgrad2<KSv, 8>(a, grid, s);                             \
+  } while (0)
+  if (ks == 1) PNSFM_W2(1);
+  if (ks == 3) PNSFM_W2(3);
+  PNSFM_W2(5);
+#undef PNSFM_W2
+}
+
+}  // namespace pnsfm

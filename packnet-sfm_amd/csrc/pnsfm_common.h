@@ -112,6 +112,13 @@ int conv_pack_KP(int Kc);
 int conv_pack_MP(int Mc);
 int conv_pick_MT(int Mc);
 
+// tap-major weight-gradient kernel (conv2d_wgrad2.hip); the generic one lives in conv2d.hip and the autotuner picks
+bool wgrad2_supported(int Cin, int Cout, int H, int W, int ks);
+int wgrad2_total_tiles(int B, int H, int W);
+int wgrad2_base_blocks(int Cin, int Cout, int ks);
+int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
+                   int split, hipStream_t stream);
+
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);
 void prof_end(int kind, hipStream_t stream);

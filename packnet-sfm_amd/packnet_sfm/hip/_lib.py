@@ -63,6 +63,7 @@ SIGNATURES = {
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),
     "pnsfm_set_autotune": (_i, [_i]),
     "pnsfm_set_conv_variant": (_i, [_i]),
+    "pnsfm_set_wgrad_variant": (_i, [_i]),
     "pnsfm_prof_enable": (_i, [_i]),
     "pnsfm_prof_reset": (_i, []),
     "pnsfm_prof_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

@@ -202,6 +202,42 @@ def test_conv2d_vs_cpu_oracle(shape, conv_variant):
     P.check(db, br.grad, 5e-5, 'dbias')
 
 
+WGRAD2_SHAPES = [  # (B, Cin, Cout, H, W, k): shapes the tap-major weight-gradient kernel supports (W % 8 == 0, k in 1/3/5)
+    (2, 64, 64, 48, 160, 3),      # conv2 stage, 32-column fragments
+    (2, 129, 64, 48, 160, 3),     # iconv1 (odd Cin: third ci tile nearly empty)
+    (2, 256, 256, 24, 80, 3),     # conv4 stage, 16-column fragments
+    (4, 512, 512, 12, 40, 3),     # conv5 stage, 8-column fragments, H not a multiple of the tile rows
+    (2, 256, 512, 12, 40, 1),     # residual shortcut 1x1
+    (1, 512, 128, 24, 80, 5),     # pack3.conv collapsed (5x5: one kernel row per workgroup)
+    (1, 64, 32, 24, 80, 3),       # unpack1.conv (Cout 32: half-empty co tile)
+]
+
+
+@pytest.mark.parametrize('shape', WGRAD2_SHAPES)
+def test_conv2d_wgrad_tap_major_vs_cpu_oracle(shape):
+    """csrc/conv2d_wgrad2.hip forced on (autotuner off) vs the oracle's conv weight/bias gradient."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_autotune(0)
+    lib.pnsfm_set_wgrad_variant(1)
+    try:
+        B, Cin, Cout, H, W, ks = shape
+        g = torch.Generator().manual_seed(sum(shape))
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv2d(x, wr, br, padding=ks // 2)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        dw, db = ops.conv2d_backward_weight(x.to(DEV), dy.to(DEV), ks)
+        P.check(dw, wr.grad, 5e-5, 'wgrad (tap-major)')
+        P.check(db, br.grad, 5e-5, 'dbias (tap-major)')
+    finally:
+        lib.pnsfm_set_wgrad_variant(0)
+        lib.pnsfm_set_autotune(1)
+
+
 def test_groupnorm_vs_cpu_oracle():
     from packnet_sfm.hip import functional as HF, ops
     g = torch.Generator().manual_seed(5)

@@ -107,6 +107,33 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     P.check(db, br.grad, 1e-5, 'dbias')
 
 
+@pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
+                                   (1, 40, 64, 6, 24, 5), (3, 17, 31, 7, 40, 1), (2, 64, 64, 8, 32, 3)])
+def test_conv2d_wgrad_tap_major(emulated_kernels, shape):
+    """The tap-major weight-gradient kernel (csrc/conv2d_wgrad2.hip) vs torch: every fragment width (32 / 16 / 8 columns),
+    k in {1, 3, 5}, channel counts that do not fill the 64 x 64 tile, heights that do not fill the tile rows, and a pixel
+    split (atomics into a zero-filled buffer) -- forced through pnsfm_set_wgrad_variant(1)."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_wgrad_variant(1)
+    try:
+        B, Cin, Cout, H, W, ks = shape
+        g = torch.Generator().manual_seed(sum(shape))
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+        b = torch.randn(Cout, generator=g)
+        xr, wr, br = x.clone(), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, padding=ks // 2)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy)
+        dw, db = ops.conv2d_backward_weight(x, dy, ks)
+        P.check(dw, wr.grad, 1e-5, 'wgrad (tap-major)')
+        P.check(db, br.grad, 1e-5, 'dbias (tap-major)')
+    finally:
+        lib.pnsfm_set_wgrad_variant(0)
+
+
 @pytest.mark.parametrize('nf', [8, 4])
 @pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3)])
 def test_conv3d_raw(emulated_kernels, shape, nf):

@@ -69,6 +69,12 @@ int pnsfm_set_conv_variant(int lds_dma);
  * (dY fragments kept in registers across the taps, immediate LDS offsets, LDS-DMA double buffering; conv2d_wgrad2.hip) for
  * the shapes it supports (stride 1, k in {1,3,5}, W % 8 == 0, >= 16 channels); the autotuner times both.  For tests. */
 int pnsfm_set_wgrad_variant(int tap_major);
+/* Programmatic entry of the tuning database (what a PNSFM_TUNE_DB line does): key7 = {kind, B, Cin, Cout, H, W, ks} with
+ * kind = 0 forward / 1 backward-data / 2 backward-weight, + 10 * stride; for kind 2 the key holds H*W in place of H and the
+ * tiling width in place of W (32 for a 1x1 convolution).  forward / backward-data: v0 = NT | variant << 4 | narrow-M << 8,
+ * v1 = K-split; backward-weight: v0 = pixel split, v1 = kernel (0 generic, 1 tap-major).  Used by the determinism sweep
+ * (tools/conv_config_sweep.py), which checks EVERY configuration the autotuner may pick against the oracle's convolution. */
+int pnsfm_tune_set(const int* key7, int v0, int v1);
 /* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and
  * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen
  * convolutions.  A process started with a complete database launches no candidate kernels. */

@@ -30,7 +30,9 @@ namespace pnsfm {
 
 int conv_pick_MT(int Mc) { return (round_up(Mc, 64) == round_up(Mc, 32)) ? 2 : 1; }
 int conv_pack_MP(int Mc) { return round_up(Mc, 32 * conv_pick_MT(Mc)); }
-int conv_pack_KP(int Kc) { return round_up(Kc, 2); }
+// K rows of a packed weight are padded (with zeros) to whole 16-channel K-chunks: the LDS-DMA of a weight slab then needs
+// no validity test for the ragged last chunk
+int conv_pack_KP(int Kc) { return round_up(Kc, 16); }
 
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
 static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
@@ -48,7 +50,7 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   const int BM = 32 * g.MT;
   g.MP = conv_pack_MP(Cout);
   g.KP = conv_pack_KP(Cin);
-  g.CI = g.KP <= 8 ? 8 : 16;   // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
+  g.CI = Cin <= 8 ? 8 : 16;    // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
   g.mode = (W % 32 == 0) ? 0 : 1;
   g.NT = NT;
   if (g.mode == 0) {
@@ -73,10 +75,11 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     auto smem_pipe = [&](int CI) -> size_t {
       return (2 * (size_t)round_up(CI * g.PH * g.PW, 64) + 2 * (size_t)g.G * CI * BM) * sizeof(float);
     };
-    g.CI = (ks == 1 && g.KP > 16) ? 32 : (g.KP <= 8 ? 8 : 16);
+    g.CI = Cin <= 8 ? 8 : 16;
     while (smem_pipe(g.CI) > kPipeTwoBlocks && g.CI > 8) g.CI /= 2;
     g.smem_bytes = smem_pipe(g.CI);
-    g.nchunks = ceil_div(g.KP, g.CI);
+    g.nchunks = ceil_div(Cin, g.CI);
+    if (g.PH * g.PW > 1024) return false;          // a channel's patch is fetched as <= 4 DMA groups of 256 elements
     if (want_split < 1) want_split = 1;
     if (want_split > g.nchunks) want_split = g.nchunks;
     const int cps2 = ceil_div(g.nchunks, want_split);
@@ -92,7 +95,7 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   };
   while (smem_for(g.CI) > kMaxSmem && g.CI > 8) g.CI /= 2;
   g.smem_bytes = smem_for(g.CI);
-  g.nchunks = ceil_div(g.KP, g.CI);
+  g.nchunks = ceil_div(Cin, g.CI);
   if (want_split < 1) want_split = 1;
   if (want_split > g.nchunks) want_split = g.nchunks;
   const int cps = ceil_div(g.nchunks, want_split);
@@ -472,7 +475,9 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
   float* const wbuf0 = smem + 2 * a.pstride;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  // `wave` in an SGPR: LDS-DMA destinations (M0) and buffer descriptors derived from it must be provably wave-uniform,
+  // otherwise hipcc wraps every DMA in a waterfall loop
+  const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int P = a.KS >> 1, KK = a.KS * a.KS;
   const int H = a.H, W = a.W, HW = H * W;
   const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = Hi * Wi;
@@ -525,64 +530,74 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
   const float* xb = a.x + (size_t)b * a.Cin * HWi;
-  auto patch_src = [&](int ci0, int idx) -> const float* {
-    const int cil = (int)(((float)idx + 0.5f) * a.invPS);
-    const int e = idx - cil * PS;
-    const int r = (int)(((float)e + 0.5f) * a.invPW);
-    const int cc = e - r * a.PW;
-    const int yy = py0 + r, xx = px0 + cc, ci = ci0 + cil;
-    const bool ok = idx < ptotal && ci < a.Cin && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
-    return ok ? xb + ((size_t)ci * HWi + yy * Wi + xx) : pnsfm_zero_page;
-  };
-  const int nld = (ptotal + 255) >> 8;            // patch DMA groups of 256 elements (64 per wave)
   const int SG = KK / G;                          // stages (kernel rows) per K-chunk
-  const int per_stage = (nld + SG - 1) / SG;
   const int nstage = (c_end - c_begin) * SG;
   const size_t tap_stride = (size_t)a.KP * a.MP;
-  const int wpieces = wslab >> 8;                 // 1 KiB wave-instructions per weight slab
-  const int cilog = a.CI == 32 ? 5 : (a.CI == 16 ? 4 : 3);
+  const int cilog = a.CI == 16 ? 4 : 3;
 
-  // weight slab of stage (chunk c, kernel row g) -> LDS layout [tap in row][ci][BM]
-  auto issue_w = [&](int c, int g, float* dst) {
-    const int ci0 = c * a.CI, tap0 = g * G;
-    for (int p = wave; p < wpieces; p += 4) {
-      const int e = (p << 8) + (lane << 2);
-      const int m = e & (BM - 1);
-      const int r = e / BM;
-      const int ci = ci0 + (r & (a.CI - 1)), tp = tap0 + (r >> cilog);
-      const float* src = (ci < a.KP) ? a.wp + ((size_t)tp * tap_stride + (size_t)ci * a.MP + co0 + m) : pnsfm_zero_page;
-      pnsfm_glds16(src, dst + (p << 8));
-    }
+  // ---- LDS-DMA with buffer addressing: per DMA instruction the wave spends a handful of SCALAR instructions (re-based
+  // descriptor, M0) and one buffer_load ... lds; nothing per element.
+  // Patch of one channel = PS floats = NG groups of 256 (64 per wave).  A thread's elements sit at the same (row, col) of
+  // the patch for every channel, so their byte offsets inside a channel image are computed ONCE; out-of-image elements
+  // carry an out-of-range offset and the hardware writes zeros for them (also for a channel >= Cin: empty descriptor).
+  constexpr int MAXG = 4;
+  const int NG = (PS + 255) >> 8;
+  unsigned pv[MAXG];
+#pragma unroll
+  for (int gg = 0; gg < MAXG; ++gg) {
+    const int e = gg * 256 + tid;
+    const int r = e / a.PW, cc = e - r * a.PW;
+    const int yy = py0 + r, xx = px0 + cc;
+    const bool ok = e < PS && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+    pv[gg] = ok ? (unsigned)(yy * Wi + xx) * 4u : PNSFM_DMA_INVALID;
+  }
+  auto issue_channel = [&](int ci, int cil, float* dst) {        // channel `ci` of the image -> row `cil` of the patch buffer
+    const pnsfm_dma_buf buf = pnsfm_make_dma_buf(xb + (unsigned)(ci * HWi), ci < a.Cin ? (long)HWi * 4 : 0);
+#pragma unroll
+    for (int gg = 0; gg < MAXG; ++gg)
+      if (gg < NG && gg * 256 + tid < PS) pnsfm_dma4(buf, pv[gg], dst + cil * PS + gg * 256 + wave * 64);
   };
-  auto issue_patch = [&](int c, int ld0, int ld1, float* dst) {
-    for (int ld = ld0; ld < ld1; ++ld) {
-      const int idx = ld * 256 + tid;
-      const float* src = patch_src(c * a.CI, idx);
-      if (idx < ptotal) pnsfm_glds4(src, dst + ld * 256 + wave * 64);
-    }
+  // Weight slab of a stage = G taps x CI rows x BM floats, LDS layout [tap][ci][BM]; one 16-byte DMA piece = 256 floats =
+  // 256/BM consecutive rows of one tap.  Lane part of the offset is constant; (tap, first row) go into the descriptor.
+  constexpr int RPP = 256 / BM;                    // rows per piece
+  const unsigned wv = (unsigned)((lane / (BM / 4)) * a.MP + (lane % (BM / 4)) * 4) * 4u;
+  const int wpieces = wslab >> 8;
+  const long wbytes = (long)KK * (long)tap_stride * 4;
+  auto issue_wpiece = [&](int c, int g, int p, float* dst) {
+    const int R = p * RPP;                          // first slab row of the piece
+    const unsigned off = (unsigned)(g * G + (R >> cilog)) * (unsigned)tap_stride + (unsigned)((c * a.CI + (R & (a.CI - 1))) * a.MP + co0);
+    const pnsfm_dma_buf buf = pnsfm_make_dma_buf(a.wp + off, wbytes - (long)off * 4);
+    pnsfm_dma16(buf, wv, dst + (p << 8));
   };
 
   // prologue: chunk 0's patch and stage 0's slab
   if (nstage > 0) {
-    issue_patch(c_begin, 0, nld, smem);
-    issue_w(c_begin, 0, wbuf0);
+    for (int cil = 0; cil < a.CI; ++cil) issue_channel(c_begin * a.CI + cil, cil, smem);
+    for (int p = wave; p < wpieces; p += 4) issue_wpiece(c_begin, 0, p, wbuf0);
   }
+  const int cps = (a.CI + SG - 1) / SG;            // patch channels prefetched per stage
   int c = c_begin, g = 0, pcur = 0;
   for (int s = 0; s < nstage; ++s) {
     __syncthreads();   // drains this wave's DMA (vmcnt(0)) and meets the others: stage s's operands are in LDS, and
                        // everyone is done with stage s-1 (its slab buffer, and at a chunk boundary its patch buffer, are free)
     float* const patch = smem + pcur * a.pstride;
     const float* const wcur = wbuf0 + (s & 1) * wslab;
-    if (s + 1 < nstage) {
-      const int gn = (g + 1 == SG) ? 0 : g + 1;
-      issue_w(gn == 0 ? c + 1 : c, gn, wbuf0 + ((s + 1) & 1) * wslab);
-      if (c + 1 < c_end) {
-        const int l0 = g * per_stage, l1 = (l0 + per_stage < nld) ? l0 + per_stage : nld;
-        issue_patch(c + 1, l0, l1, smem + (pcur ^ 1) * a.pstride);
-      }
-    }
+    // DMA work of this stage, handed out in slices between the MFMA batches below: the slab of stage s+1 and this
+    // stage's share of chunk c+1's patch channels
+    const bool more = s + 1 < nstage;
+    const int gn = (g + 1 == SG) ? 0 : g + 1, cn = (gn == 0) ? c + 1 : c;
+    float* const wnext = wbuf0 + ((s + 1) & 1) * wslab;
+    float* const pnext = smem + (pcur ^ 1) * a.pstride;
+    int wp_next = more ? wave : wpieces;            // next weight piece of this wave
+    int ch_next = g * cps;                          // next patch channel (local) ...
+    const int ch_end = (more && c + 1 < c_end) ? ((ch_next + cps < a.CI) ? ch_next + cps : a.CI) : ch_next;
     // ---- stage s: G taps x CI/8 batches of 4 k-steps; fragments of batch q+1 are read before batch q's MFMAs
     const int nb = a.CI >> 3, nq = G * nb;
+    const int wpb = ((wpieces + 3) / 4 + nq - 1) / nq, cpb = (cps + nq - 1) / nq;
+    auto issue_slice = [&]() {
+      for (int i = 0; i < wpb && wp_next < wpieces; ++i, wp_next += 4) issue_wpiece(cn, gn, wp_next, wnext);
+      for (int i = 0; i < cpb && ch_next < ch_end; ++i, ++ch_next) issue_channel((c + 1) * a.CI + ch_next, ch_next, pnext);
+    };
     int ky = (g * G) / a.KS, kx = (g * G) - ky * a.KS;
     const float* wb = wcur + half * BM + l32;
     const float* pb = patch + half * PS + ky * a.PW + kx;
@@ -624,15 +639,20 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
     int q = 0;
     for (; q + 2 <= nq; q += 2) {
       advance();
+      issue_slice();
       load(1, wq, pq);
       mma(0);
+      issue_slice();
       if (q + 2 < nq) {
         advance();
         load(0, wq, pq);
       }
       mma(1);
     }
-    if (q < nq) mma(0);                            // odd number of batches: the last one sits in buffer 0
+    if (q < nq) { issue_slice(); mma(0); }         // odd number of batches: the last one sits in buffer 0
+    // whatever the slices did not cover (short stages)
+    for (; wp_next < wpieces; wp_next += 4) issue_wpiece(cn, gn, wp_next, wnext);
+    for (; ch_next < ch_end; ++ch_next) issue_channel((c + 1) * a.CI + ch_next, ch_next, pnext);
     if (++g == SG) { g = 0; ++c; pcur ^= 1; }
   }
 
@@ -1259,6 +1279,13 @@ int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float*
 
 int pnsfm_set_autotune(int on) {
   g_autotune = on ? 1 : 0;
+  return 0;
+}
+
+int pnsfm_tune_set(const int* key7, int v0, int v1) {
+  if (!key7) { set_error("tune_set: null key"); return -1; }
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tuned[{key7[0], key7[1], key7[2], key7[3], key7[4], key7[5], key7[6]}] = {v0, v1};
   return 0;
 }
 

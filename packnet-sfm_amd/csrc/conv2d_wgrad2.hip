@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
   PNSFM_DYN_SMEM(float, smem);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  // `wave` lives in an SGPR so that LDS-DMA destinations and buffer descriptors derived from it are provably uniform
+  const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int H = a.H, W = a.W, HW = H * W;
   const int ci_t = blockIdx.x % a.ci_tiles, tgi = blockIdx.x / a.ci_tiles;
@@ -91,38 +92,46 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
   // dY DMA: lane = pixel of the tile (segment-major: p = s*32 + r*FC + c)
   const int dyr = (lane >> 5) * SR + (lane & 31) / FC, dyc = (lane & 31) % FC;
 
-  // The DMA work of one tile: per wave 16 dY rows (one instruction each) + 16 channels x NPI patch instructions.  `i` is a
-  // compile-time constant at every call site (fully unrolled loops), so the per-lane patch coordinates stay in registers.
+  // The DMA work of one tile: per wave 16 dY rows (one instruction each) + 16 channels x NPI patch instructions, all
+  // buffer_load ... lds: the byte offsets of a lane's elements inside a channel image depend on the TILE only (computed once
+  // per tile: TileOff), the channel goes into the scalar descriptor, and out-of-image elements / channels >= C carry an
+  // out-of-range offset / an empty descriptor so that the hardware writes the zeros.  `i` is a compile-time constant at
+  // every call site (fully unrolled loops).
   constexpr int DMA_PER_WAVE = 16 + 16 * NPI;
-  struct TileOrg { int b, y0, x0; };
-  auto tile_org = [&](int tt) -> TileOrg {
-    const int b = tt / a.tiles_per_img;
-    const int t = tt - b * a.tiles_per_img;
+  struct TileOff { int b; unsigned dyv; unsigned pv[NPI]; };
+  auto tile_off = [&](int tt) -> TileOff {
+    TileOff o;
+    o.b = tt / a.tiles_per_img;
+    const int t = tt - o.b * a.tiles_per_img;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    return TileOrg{b, ty * TR, tx * FC};
+    const int y0 = ty * TR, x0 = tx * FC;
+    const int yd = y0 + dyr;
+    o.dyv = yd < H ? (unsigned)(yd * W + x0 + dyc) * 4u : PNSFM_DMA_INVALID;
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+      const int yy = y0 - P + pr[k], xx = x0 - P + pc[k];
+      const bool ok = lane + 64 * k < PSR && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      o.pv[k] = ok ? (unsigned)(yy * W + xx) * 4u : PNSFM_DMA_INVALID;
+    }
+    return o;
   };
-  auto issue_one = [&](const TileOrg& o, float* buf, int i) {
+  auto issue_one = [&](const TileOff& o, float* buf, int i) {
     float* dys = buf;
     float* patch = buf + 64 * DS;
     if (i < 16) {
       const int m = wave + 4 * i;                      // dY row (output channel) of this instruction
-      const int yy = o.y0 + dyr;
-      const bool ok = (co0 + m) < a.Cout && yy < H;
-      const float* src = ok ? a.dy + ((size_t)(o.b * a.Cout + co0 + m) * HW + yy * W + o.x0 + dyc) : w2_zero_page;
-      pnsfm_glds4(src, dys + m * DS);
+      const pnsfm_dma_buf src = pnsfm_make_dma_buf(a.dy + (unsigned)((o.b * a.Cout + co0 + m) * HW), (co0 + m) < a.Cout ? (long)HW * 4 : 0);
+      pnsfm_dma4(src, o.dyv, dys + m * DS);
     } else {
       const int q = i - 16;
       const int cil = wave + 4 * (q / NPI), k = q % NPI;
-      const int yy = o.y0 - P + pr[k], xx = o.x0 - P + pc[k];
-      const bool in_patch = lane + 64 * k < PSR;
-      const bool ok = in_patch && (ci0 + cil) < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float* src = ok ? a.x + ((size_t)(o.b * a.Cin + ci0 + cil) * HW + yy * W + xx) : w2_zero_page;
-      if (in_patch) pnsfm_glds4(src, patch + cil * PS + 64 * k);
+      const pnsfm_dma_buf src = pnsfm_make_dma_buf(a.x + (unsigned)((o.b * a.Cin + ci0 + cil) * HW), (ci0 + cil) < a.Cin ? (long)HW * 4 : 0);
+      if (lane + 64 * k < PSR) pnsfm_dma4(src, o.pv[k], patch + cil * PS + 64 * k);
     }
   };
 
   if (t_begin < t_end) {
-    const TileOrg o = tile_org(t_begin);
+    const TileOff o = tile_off(t_begin);
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) issue_one(o, smem, i);
   }
@@ -131,7 +140,7 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
     __syncthreads();    // this wave's DMA has landed (vmcnt(0)), everyone's has, and the other buffer is free again
     float* buf = smem + cur * BUF;
     float* nbuf = smem + (cur ^ 1) * BUF;
-    const TileOrg onext = tile_org(tt + 1 < t_end ? tt + 1 : tt);
+    const TileOff onext = tile_off(tt + 1 < t_end ? tt + 1 : tt);
     const float* dys = buf;
     const float* patch = buf + 64 * DS;
     if (do_bias) {      // bias gradient rides along: 4 threads per dY row, 16 pixels each (tile already in LDS)
@@ -188,20 +197,38 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
   }
   __syncthreads();      // the redundant prefetch behind the last tile must land before this workgroup's LDS is released
 
-  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half (co), col = l32 (ci); a lane owns the TG taps of 16 (co, ci) pairs
-  const int ci = ci0 + 32 * wn + l32;
-  if (ci < a.Cin) {
+  // ---- epilogue.  MFMA D layout: row (co) = (r&3) + 8*(r>>2) + 4*half, col (ci) = l32; a lane owns the TG taps of 16
+  // (co, ci) pairs, i.e. 16 runs of TG consecutive floats of dW[co][ci][tap] that are 32*TG floats apart between lanes.
+  // Storing (or atomically adding) them directly costs 16 partial cache lines per wave instruction -- measured 3-4x the
+  // whole kernel's time when the pixel split makes them atomics.  Each wave therefore transposes its tile through LDS (free
+  // by now), 16 co rows at a time: row-major [co][ci*TG + tap] in LDS, then every wave instruction covers 64 CONSECUTIVE
+  // floats of one dW row.
+  {
+    constexpr int RW = 32 * TG;                       // floats of one co row of this wave's tile
+    float* tb = smem + wave * (16 * RW);
+    const int ci_w = ci0 + 32 * wn;                   // first input channel of this wave's tile
+    const int ncol = (a.Cin - ci_w < 32 ? a.Cin - ci_w : 32) * TG;      // valid floats per row (<= 0: nothing)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.Cout) {
-        float* dst = a.dw + ((size_t)co * a.Cin + ci) * KK + ky0 * KS;
-        if (a.splitP == 1) {
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
 #pragma unroll
-          for (int tp = 0; tp < TG; ++tp) dst[tp] = acc[tp][r];
-        } else {
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * h + rr;
+        const int lr = (r & 3) + 4 * half + 8 * ((r >> 2) & 1);         // co row inside the 16-row pass
 #pragma unroll
-          for (int tp = 0; tp < TG; ++tp) atomicAdd(dst + tp, acc[tp][r]);
+        for (int tp = 0; tp < TG; ++tp) tb[lr * RW + l32 * TG + tp] = acc[tp][r];
+      }
+      __syncthreads();
+      const int co_b = co0 + 32 * wm + 16 * h;
+      for (int row = 0; row < 16; ++row) {
+        const int co = co_b + row;
+        if (co >= a.Cout) break;
+        float* drow = a.dw + ((size_t)co * a.Cin + ci_w) * KK + ky0 * KS;
+        for (int col = lane; col < ncol; col += 64) {
+          // KS == 5: a row group covers TG = 5 of the 25 taps of each channel -> runs of 5 floats, 25 apart
+          const int dcol = (KS == 5) ? (col / TG) * KK + (col % TG) : col;
+          const float v = tb[row * RW + col];
+          if (a.splitP == 1) drow[dcol] = v; else atomicAdd(drow + dcol, v);
         }
       }
     }

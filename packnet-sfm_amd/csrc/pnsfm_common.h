@@ -20,6 +20,26 @@ static inline void pnsfm_glds16(const float* src, float* lds_wave_base) {
   float* d = lds_wave_base + 4 * hipemu::my_lane();
   d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[3];
 }
+// LDS-DMA with buffer addressing (buffer_load_dword{,x4} ... lds): lane l copies 4 / 16 bytes from base + voff_bytes to
+// lds_wave_base[l] / [4l..4l+3]; an out-of-range lane (voff + size > bytes) writes ZEROS (checked on gfx950:
+// tools/micro/blds_check.hip), which is how zero padding and the ragged last K-chunk are produced without a single compare.
+#define PNSFM_DMA_INVALID 0x7ffffff0u
+struct pnsfm_dma_buf { const char* base; unsigned bytes; };
+static inline pnsfm_dma_buf pnsfm_make_dma_buf(const void* base, long bytes) {
+  return pnsfm_dma_buf{(const char*)base, bytes <= 0 ? 0u : (unsigned)bytes};
+}
+static inline void pnsfm_dma4(const pnsfm_dma_buf& b, unsigned voff, float* lds_wave_base) {
+  const bool ok = voff <= 0x7fffffffu && (unsigned long long)voff + 4u <= b.bytes;
+  lds_wave_base[hipemu::my_lane()] = ok ? *reinterpret_cast<const float*>(b.base + voff) : 0.f;
+}
+static inline void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned voff, float* lds_wave_base) {
+  float* d = lds_wave_base + 4 * hipemu::my_lane();
+  for (int i = 0; i < 4; ++i) {
+    const unsigned o = voff + 4u * i;
+    const bool ok = voff <= 0x7fffffffu && (unsigned long long)o + 4u <= b.bytes;
+    d[i] = ok ? *reinterpret_cast<const float*>(b.base + o) : 0.f;
+  }
+}
 #define PNSFM_UNIFORM(i) (i)
 // buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
 struct pnsfm_buf { const char* base; unsigned bytes; };
@@ -51,6 +71,22 @@ __device__ __forceinline__ void pnsfm_glds16(const float* src, float* lds_wave_b
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// LDS-DMA with buffer addressing: buffer_load_dword{,x4} v_off, s[rsrc], 0 offen lds.  The descriptor (base, num_records)
+// lives in SGPRs and is re-based by scalar code; a lane needs ONE 32-bit offset register and no per-element compare: an
+// out-of-range lane (voff + size > bytes) writes ZEROS to its LDS slot (checked on gfx950: tools/micro/blds_check.hip).
+struct pnsfm_dma_buf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ pnsfm_dma_buf pnsfm_make_dma_buf(const void* base, long bytes) {
+  pnsfm_dma_buf b;
+  b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, bytes <= 0 ? 0 : (int)bytes, 0x00020000);
+  return b;
+}
+__device__ __forceinline__ void pnsfm_dma4(const pnsfm_dma_buf& b, unsigned voff, float* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned voff, float* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+#define PNSFM_DMA_INVALID 0x7ffffff0u     // a voffset that is out of range for every descriptor
 // tell the compiler a value is wave-uniform (moves it to an SGPR)
 #define PNSFM_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
 // Raw buffer loads (buffer_load_dword v, v_off, s[rsrc], s_off offen): the address is base + s_off + v_off with a

@@ -28,3 +28,8 @@ def view_synthesis(ref_image, depth, ref_cam, cam, mode='bilinear', padding_mode
     warped = HF.view_synthesis(1.0 / depth, ref_image.unsqueeze(0), cam.K.float(), ref_cam.K.float(), T.unsqueeze(0),
                                padding_mode)
     return warped[0]
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -76,3 +76,8 @@ class Pose:
         if other.dim() in (3, 4) and other.shape[1] == 3:
             return self.transform_points(other)
         raise ValueError('Unknown tensor dimensions {}'.format(other.shape))
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

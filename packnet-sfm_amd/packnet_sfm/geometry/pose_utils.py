@@ -44,3 +44,8 @@ def invert_pose_numpy(T):
     R, t = T[:3, :3], T[:3, 3]
     out[:3, :3], out[:3, 3] = R.T, -np.matmul(R.T, t)
     return out
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

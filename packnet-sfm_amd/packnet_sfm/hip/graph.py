@@ -15,9 +15,16 @@ What stays outside the graph because it is Python control flow in the reference:
 
 Requirements: static shapes (the batch is copied into static input tensors before each replay), an optimizer that is
 capture-safe (`torch.optim.Adam(..., fused=True, capturable=True)` or `packnet_sfm.rccl.flat_adam.FlatAdam`), at least
-one eager step before capture (autotuning of the conv kernels synchronises and cannot run inside a capture), and no host
-read-back inside the model's forward.
+one eager step before capture (autotuning of the conv kernels synchronises and cannot run inside a capture), no host
+read-back inside the model's forward -- and NO live reference to the outputs of earlier eager steps (drop the loss
+tensor): an autograd graph that is still alive keeps its AccumulateGrad nodes, which are bound to the stream they were
+created on (the default stream), and the captured backward would hand its gradients over to work on that stream outside
+the capture.  As in PyTorch's whole-network-capture recipe the constructor therefore runs one full warm-up step on a
+side stream first, so that every AccumulateGrad node the capture meets was created off the default stream.
+The optimizer's state tensors are captured by address: restore a checkpoint with in-place copies (load_state_dict of
+torch optimizers REPLACES the state tensors; re-create the GraphedTrainStep after it).
 """
+import gc
 import random
 
 import torch
@@ -65,10 +72,32 @@ class GraphedTrainStep:
         self.flip_prob = float(getattr(model, 'flip_lr_prob', 0.0) if flip_prob is None else flip_prob)
         self.batch = _clone_static(example_batch)
         self.graphs, self.loss = {}, {}
-        self._pool = None
         flips = [False] if self.flip_prob <= 0.0 else ([True] if self.flip_prob >= 1.0 else [False, True])
+        self._warm_up(flips[0])
         for flip in flips:
             self._capture(flip)
+
+    def _warm_up(self, flip):
+        """One eager step on a side stream (PyTorch's capture recipe): AccumulateGrad nodes of dead graphs are gone after
+        the collection, the new ones are created on a non-default stream."""
+        gc.collect()
+        model, opt = self.model, self.optimizer
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        model._flip_override = flip
+        try:
+            with torch.cuda.stream(s):
+                opt.zero_grad(set_to_none=True)
+                out = model(self.batch, progress=self.progress)
+                out['loss'].backward()
+                # NOT opt.step(): the warm-up must not change the training state
+                del out
+                opt.zero_grad(set_to_none=True)
+        finally:
+            model._flip_override = None
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        gc.collect()
 
     def _capture(self, flip):
         model, opt = self.model, self.optimizer
@@ -77,26 +106,28 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
-        kw = {} if self._pool is None else {'pool': self._pool}
+        # Each graph gets its OWN memory pool: sharing one (torch's `pool=` idiom) is only safe when the graphs are replayed in
+        # capture order, and here the flip draw picks the graph; 288 GB of HBM makes the second copy of the activations free.
         model._flip_override = flip
         try:
-            with torch.cuda.graph(g, **kw):
+            with torch.cuda.graph(g):
                 out = model(self.batch, progress=self.progress)
                 out['loss'].backward()
                 opt.step()
         finally:
             model._flip_override = None
-        if self._pool is None:
-            self._pool = g.pool()
         self.graphs[flip] = g
         self.loss[flip] = out['loss'].detach()
         HF.bump_weight_epoch()          # eager code after a replay must re-pack too
 
-    def __call__(self, batch=None):
-        """One training step; returns the (device, static) loss tensor of the replayed graph."""
+    def __call__(self, batch=None, flip=None):
+        """One training step; returns the (device, static) loss tensor of the replayed graph.  `flip`: force the flip state
+        (tests); default: drawn from Python's global RNG exactly like the reference's SfmModel."""
         if batch is not None:
             _copy_into(self.batch, batch)
         draw = random.random() < self.flip_prob        # drawn every step, like the reference, so the RNG sequence matches
+        if flip is not None:
+            draw = bool(flip)
         flip = draw if len(self.graphs) > 1 else next(iter(self.graphs))
         self.graphs[flip].replay()
         HF.bump_weight_epoch()

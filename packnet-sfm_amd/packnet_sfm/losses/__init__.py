@@ -1,0 +1,3 @@
+# one package with a reference checkout further down sys.path (see packnet_sfm/_merge.py)
+from packnet_sfm._merge import extend as _extend
+__path__ = _extend(__path__, __name__)

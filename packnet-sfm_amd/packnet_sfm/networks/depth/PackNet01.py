@@ -98,3 +98,8 @@ class PackNet01(nn.Module):
         if self.training:
             return {'inv_depths': [disp1, disp2, disp3, disp4]}
         return {'inv_depths': disp1}
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

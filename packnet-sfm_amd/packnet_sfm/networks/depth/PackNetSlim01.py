@@ -11,3 +11,8 @@ class PackNetSlim01(PackNet01):
     STEM_WIDTH = 32
     WIDTHS = (32, 64, 128, 256, 512)
     NUM_3D_FEAT = 4
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -214,3 +214,8 @@ class UnpackLayerConv3d(nn.Module):
     def forward(self, x):
         feats = HF.conv3d_1to8(self.conv(x), self.conv3d.weight, self.conv3d.bias)
         return HF.depth_to_space(feats)
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -63,3 +63,8 @@ class PoseNet(nn.Module):
         pose = HF.conv2d(x, self.pose_pred.weight, self.pose_pred.bias, self._head_packed)
         pose = pose.mean(3).mean(2)
         return 0.01 * pose.view(pose.size(0), self.nb_ref_imgs, 6)
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -59,3 +59,8 @@ class BaseTrainer:
 
     def test_progress_bar(self, dataloader, config, n=0, ncols=120):
         return self._bar(dataloader, config, desc='test[%d]' % n, ncols=ncols)
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

@@ -77,3 +77,8 @@ def compute_depth_metrics(config, gt, pred, use_gt_scale=True):
         p = p.clamp(config.min_depth, config.max_depth)
         totals += torch.stack([fn(g, p) for _, fn in _DEPTH_METRICS]).double().cpu()
     return (totals / B).type_as(gt)
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

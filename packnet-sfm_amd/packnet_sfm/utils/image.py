@@ -66,3 +66,8 @@ def image_grid(B, H, W, dtype, device, normalized=False):
     """Homogeneous pixel grid [B,3,H,W] = (x, y, 1)."""
     xs, ys = meshgrid(B, H, W, dtype, device, normalized=normalized)
     return torch.stack((xs, ys, torch.ones_like(xs)), dim=1)
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

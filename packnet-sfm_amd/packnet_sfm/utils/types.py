@@ -35,3 +35,8 @@ def is_tensor(data):
 def is_seq(data):
     """list or tuple"""
     return isinstance(data, (list, tuple))
+
+
+# names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)
+from packnet_sfm._merge import reference_fallback as _reference_fallback  # noqa: E402
+__getattr__ = _reference_fallback(__name__, __file__)

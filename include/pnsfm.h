@@ -83,13 +83,14 @@ int pnsfm_tune_set(const int* key7, int v0, int v1);
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the
  * residual form `activ(normalize(x_out + shortcut))`: layers01.py:61-62,72.
  * act: 0 = identity, 1 = ELU(alpha=1), 2 = ReLU (PoseNet, networks/pose/PoseNet.py:28-34).
- * stats_ws: double[2*B*G*PNSFM_GN_MAX_SPLIT] scratch (per-block partials: no zero-fill needed, deterministic);
- * mean/rstd: float[B*G] saved for backward. */
+ * stats_ws / red_ws: double[pnsfm_groupnorm_ws_doubles(B, C, G)] scratch (per-workgroup partial sums: no zero-fill needed,
+ * deterministic); mean/rstd: float[B*G] saved for backward. */
 #define PNSFM_GN_MAX_SPLIT 64
+size_t pnsfm_groupnorm_ws_doubles(int B, int C, int G);
 int pnsfm_groupnorm_act_forward(const float* x, const float* res /*nullable*/, const float* gamma,
                                 const float* beta, float* y, float* mean, float* rstd, double* stats_ws,
                                 int B, int C, int HW, int G, float eps, int act, void* stream);
-/* red_ws: double[2*B*C*PNSFM_GN_MAX_SPLIT] scratch. dx is the gradient w.r.t. x (and, identically, w.r.t. res). */
+/* red_ws: double[pnsfm_groupnorm_ws_doubles(B, C, G)] scratch. dx is the gradient w.r.t. x (and, identically, w.r.t. res). */
 int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* res /*nullable*/,
                                  const float* gamma, const float* beta, const float* mean, const float* rstd,
                                  float* dx, float* dgamma, float* dbeta, double* red_ws,

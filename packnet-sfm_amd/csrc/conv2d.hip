@@ -212,6 +212,10 @@ struct ConvArgs {
   int pstride;        // DMA variants: floats between the two patch buffers
   int G;              // pipelined variant: taps per weight stage
   float invPW, invPS;
+#ifdef PNSFM_PIPE_TRACE
+  long long* trace;   // debug build only (tools/pipe_trace.py): per wave {barrier wait, stage compute, prologue, epilogue} cycles
+  int trace_flags;    // 1: skip the in-loop DMA (timing experiment: results are wrong)
+#endif
 };
 
 // out-of-image / padded elements are read from here: selecting the POINTER (address | zero page) keeps every staging
@@ -570,16 +574,30 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
     pnsfm_dma16(buf, wv, dst + (p << 8));
   };
 
+#ifdef PNSFM_PIPE_TRACE
+  long long tr_bar = 0, tr_comp = 0;
+  const long long tr_start = __builtin_readcyclecounter();
+#endif
   // prologue: chunk 0's patch and stage 0's slab
   if (nstage > 0) {
     for (int cil = 0; cil < a.CI; ++cil) issue_channel(c_begin * a.CI + cil, cil, smem);
     for (int p = wave; p < wpieces; p += 4) issue_wpiece(c_begin, 0, p, wbuf0);
   }
+#ifdef PNSFM_PIPE_TRACE
+  const long long tr_loop = __builtin_readcyclecounter();
+#endif
   const int cps = (a.CI + SG - 1) / SG;            // patch channels prefetched per stage
   int c = c_begin, g = 0, pcur = 0;
   for (int s = 0; s < nstage; ++s) {
+#ifdef PNSFM_PIPE_TRACE
+    const long long tr0 = __builtin_readcyclecounter();
+#endif
     __syncthreads();   // drains this wave's DMA (vmcnt(0)) and meets the others: stage s's operands are in LDS, and
                        // everyone is done with stage s-1 (its slab buffer, and at a chunk boundary its patch buffer, are free)
+#ifdef PNSFM_PIPE_TRACE
+    const long long tr1 = __builtin_readcyclecounter();
+    tr_bar += tr1 - tr0;
+#endif
     float* const patch = smem + pcur * a.pstride;
     const float* const wcur = wbuf0 + (s & 1) * wslab;
     // DMA work of this stage, handed out in slices between the MFMA batches below: the slab of stage s+1 and this
@@ -593,8 +611,14 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
     const int ch_end = (more && c + 1 < c_end) ? ((ch_next + cps < a.CI) ? ch_next + cps : a.CI) : ch_next;
     // ---- stage s: G taps x CI/8 batches of 4 k-steps; fragments of batch q+1 are read before batch q's MFMAs
     const int nb = a.CI >> 3, nq = G * nb;
-    const int wpb = ((wpieces + 3) / 4 + nq - 1) / nq, cpb = (cps + nq - 1) / nq;
+    // front-loaded: everything is issued during the FIRST HALF of the stage's batches, because the barrier that ends the
+    // stage drains vmcnt(0) -- a copy issued in the last batch would expose its whole latency (~1-2 us) there
+    const int nq_issue = nq > 1 ? nq / 2 : 1;
+    const int wpb = ((wpieces + 3) / 4 + nq_issue - 1) / nq_issue, cpb = (cps + nq_issue - 1) / nq_issue;
     auto issue_slice = [&]() {
+#ifdef PNSFM_PIPE_TRACE
+      if (a.trace_flags & 1) { wp_next = wpieces; ch_next = ch_end; return; }
+#endif
       for (int i = 0; i < wpb && wp_next < wpieces; ++i, wp_next += 4) issue_wpiece(cn, gn, wp_next, wnext);
       for (int i = 0; i < cpb && ch_next < ch_end; ++i, ++ch_next) issue_channel((c + 1) * a.CI + ch_next, ch_next, pnext);
     };
@@ -653,11 +677,31 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
     // whatever the slices did not cover (short stages)
     for (; wp_next < wpieces; wp_next += 4) issue_wpiece(cn, gn, wp_next, wnext);
     for (; ch_next < ch_end; ++ch_next) issue_channel((c + 1) * a.CI + ch_next, ch_next, pnext);
+#ifdef PNSFM_PIPE_TRACE
+    tr_comp += __builtin_readcyclecounter() - tr1;
+#endif
     if (++g == SG) { g = 0; ++c; pcur ^= 1; }
   }
+#ifdef PNSFM_PIPE_TRACE
+  const long long tr_epi = __builtin_readcyclecounter();
+#endif
 
   conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+#ifdef PNSFM_PIPE_TRACE
+  if (a.trace && lane == 0) {
+    const long long tr_end = __builtin_readcyclecounter();
+    long long* t = a.trace + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave) * 6;
+    t[0] = tr_bar; t[1] = tr_comp; t[2] = tr_loop - tr_start; t[3] = tr_end - tr_epi; t[4] = tr_end - tr_start; t[5] = nstage;
+  }
+#endif
 }
+
+#ifdef PNSFM_PIPE_TRACE
+static long long* g_trace_buf = nullptr;
+static int g_trace_flags = 0;
+extern "C" int pnsfm_debug_set_trace(void* p) { g_trace_buf = (long long*)p; return 0; }
+extern "C" int pnsfm_debug_set_trace_flags(int f) { g_trace_flags = f; return 0; }
+#endif
 
 static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
                         int Cout, int H, int W, int ks, hipStream_t stream, const char* what, int S, int Hi, int Wi) {
@@ -672,6 +716,10 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.invPS = 1.0f / (float)(g.PH * g.PW);
   a.pstride = round_up(g.CI * g.PH * g.PW, 64);
   a.G = g.G;
+#ifdef PNSFM_PIPE_TRACE
+  a.trace = g_trace_buf;
+  a.trace_flags = g_trace_flags;
+#endif
   if (g.splitK > 1) {
     int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
     if (e) { set_error("%s: memset failed", what); return e; }

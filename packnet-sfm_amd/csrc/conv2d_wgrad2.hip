@@ -159,7 +159,10 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
     // front of each group (unconditionally -- past the last tile it re-fetches that tile into the idle buffer -- so that no
     // branch splits the schedule).
     constexpr int NGROUP = 2 * TG;
-    constexpr int PER_GROUP = (DMA_PER_WAVE + NGROUP - 1) / NGROUP;
+    // the next tile's DMA is issued during the first two thirds of this tile's groups: the barrier that ends the tile drains
+    // vmcnt(0), and a copy issued in the last groups would expose its latency there
+    constexpr int NISSUE = (2 * NGROUP + 2) / 3;
+    constexpr int PER_GROUP = (DMA_PER_WAVE + NISSUE - 1) / NISSUE;
     float av[2][16], bv[2][16];
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg)

@@ -4,48 +4,20 @@
 //   (/root/reference/packnet_sfm/networks/layers/packnet/layers01.py:31-32,36-37), the residual form
 //   `activ(normalize(x_out + shortcut))` of ResidualConv (:61-62,72) and GroupNorm+ReLU of PoseNet's conv_gn
 //   (/root/reference/packnet_sfm/networks/pose/PoseNet.py:28-34).
-// HBM-bound: forward reads x (+res) twice and writes y once (12 or 20 B/element); statistics are
-// accumulated in fp64 (sum, sum of squares) so that var = E[x^2]-E[x]^2 is safe.
+// HBM-bound: forward reads x (+res) twice and writes y once (12 or 20 B/element), backward reads dy, x (+res) twice and
+// writes dx once (24 B/element).  Statistics are accumulated in fp64 (sum, sum of squares) so that var = E[x^2]-E[x]^2 is safe.
+//
+// Layout of the work (round 2: the round-1 kernels moved 4 bytes per lane per load and gave a workgroup 1024 elements; they
+// ran at 8-26 % of HBM bandwidth and were launch-bound on the 24x80 and smaller maps):
+//   * every load/store is a float4 when HW % 4 == 0 (all PackNet01 shapes), scalar otherwise;
+//   * a workgroup owns ROWS x one pixel chunk, ROWS = channels (b, c) handled by 256/T threads groups of T lanes each, so
+//     that small maps (6x20: 30 float4 per channel) still give every lane work -- T = threads per channel row (power of 2);
+//   * per-(sample, group) statistics and per-(sample, channel) gradient sums are one slot per workgroup row/chunk: no zero
+//     fill, no atomics, deterministic; the consumer adds the <= PNSFM_GN_MAX_SPLIT partials.
 #include "pnsfm_common.h"
 #include "../../include/pnsfm.h"
 
 namespace pnsfm {
-
-__device__ __forceinline__ double block_sum_256(double v, double* red) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
-
-// stats[((b*G+g)*nsplit + s)*2 + {0,1}] = {sum, sumsq} over slice s of the group's contiguous (C/G)*HW elements
-// (one slot per block: no zero-fill, no atomics, deterministic; the consumer adds the <= 64 partials)
-__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                        double* __restrict__ stats, long n_per_group, int nsplit) {
-  __shared__ double red[4];
-  const int bg = blockIdx.x, s = blockIdx.y;
-  const long per = ((n_per_group + nsplit - 1) / nsplit + 3) & ~3L;
-  const long beg = s * per;
-  long end = beg + per;
-  if (end > n_per_group) end = n_per_group;
-  const float* xp = x + (size_t)bg * n_per_group;
-  const float* rp = res ? res + (size_t)bg * n_per_group : nullptr;
-  double s1 = 0.0, s2 = 0.0;
-  for (long i = beg + threadIdx.x; i < end; i += 256) {
-    float v = xp[i];
-    if (rp) v += rp[i];
-    s1 += (double)v;
-    s2 += (double)v * (double)v;
-  }
-  s1 = block_sum_256(s1, red);
-  s2 = block_sum_256(s2, red);
-  if (threadIdx.x == 0) {
-    stats[((size_t)bg * nsplit + s) * 2 + 0] = s1;
-    stats[((size_t)bg * nsplit + s) * 2 + 1] = s2;
-  }
-}
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == 1) return z > 0.f ? z : expm1f(z);
@@ -58,138 +30,289 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return 1.f;
 }
 
-// grid: (B*C, chunks over HW)
-__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const double* __restrict__ stats, float* __restrict__ y,
-                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                        int C, int HW, int G, float eps, int act, int chunk, int nsplit) {
-  const int bc = blockIdx.x;
-  const int b = bc / C, c = bc - b * C;
-  const int cpg = C / G, g = c / cpg;
-  const double n = (double)cpg * (double)HW;
+struct GnGeom {
+  int T;        // lanes per channel row (power of two, <= 256)
+  int rows;     // channel rows per workgroup = 256 / T
+  int chunk;    // elements of a row handled by one workgroup (multiple of 4*T, or HW)
+  int nchunk;   // chunks per row
+};
+
+// sum over the T lanes of a row (T a power of two <= 64: shuffles inside the wave; T > 64: through LDS)
+__device__ __forceinline__ double row_sum(double v, int T, double* red) {
+  const int tid = threadIdx.x;
+  if (T <= 64) {
+    for (int d = T >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+  }
+  // T = 128 or 256: lanes of a row span T/64 waves
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  const int wave = tid >> 6, wpr = T >> 6;          // waves per row
+  __syncthreads();
+  if ((tid & 63) == 0) red[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int w0 = (wave / wpr) * wpr;
+  for (int k = 0; k < wpr; ++k) s += red[w0 + k];
+  return s;
+}
+
+// ---- forward statistics: stats[((bg)*nslot + slot)*2 + {0,1}] = {sum, sumsq} of one (channel row, chunk) piece of group bg;
+//      nslot = cpg * nchunk (channels per group x chunks)
+template <bool VEC>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        double* __restrict__ stats, int BC, int C, int HW, int G, GnGeom g) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int r = tid / g.T, l = tid - r * g.T;
+  const int bc = blockIdx.x * g.rows + r;
+  const int beg = blockIdx.y * g.chunk;
+  int end = beg + g.chunk;
+  if (end > HW) end = HW;
+  double s1 = 0.0, s2 = 0.0;
+  if (bc < BC) {
+    const float* xp = x + (size_t)bc * HW;
+    const float* rp = res ? res + (size_t)bc * HW : nullptr;
+    if (VEC) {
+      for (int i = beg + 4 * l; i < end; i += 4 * g.T) {
+        float4 v = *reinterpret_cast<const float4*>(xp + i);
+        if (rp) { const float4 q = *reinterpret_cast<const float4*>(rp + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+      }
+    } else {
+      for (int i = beg + l; i < end; i += g.T) {
+        float v = xp[i];
+        if (rp) v += rp[i];
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
+    }
+  }
+  s1 = row_sum(s1, g.T, red);
+  s2 = row_sum(s2, g.T, red);
+  if (l == 0 && bc < BC) {
+    const int cpg = C / G;
+    const int b = bc / C, c = bc - b * C;
+    const int gi = c / cpg, cl = c - gi * cpg;
+    const size_t slot = ((size_t)(b * G + gi) * (cpg * g.nchunk) + (size_t)cl * g.nchunk + blockIdx.y) * 2;
+    stats[slot] = s1;
+    stats[slot + 1] = s2;
+  }
+}
+
+// mean / rstd of every (sample, group) from the partial slots (one thread per (b, g); nslot <= a few hundred)
+__global__ void __launch_bounds__(64) gn_finish_kernel(const double* __restrict__ stats, float* __restrict__ mean_out,
+                                                       float* __restrict__ rstd_out, int BG, int nslot, double n, float eps) {
+  const int bg = blockIdx.x * 64 + threadIdx.x;
+  if (bg >= BG) return;
   double t1 = 0.0, t2 = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    t1 += stats[((size_t)(b * G + g) * nsplit + k) * 2 + 0];
-    t2 += stats[((size_t)(b * G + g) * nsplit + k) * 2 + 1];
+  for (int k = 0; k < nslot; ++k) {
+    t1 += stats[((size_t)bg * nslot + k) * 2];
+    t2 += stats[((size_t)bg * nslot + k) * 2 + 1];
   }
   const double m = t1 / n;
   double var = t2 / n - m * m;
   if (var < 0.0) var = 0.0;
-  const float mean = (float)m;
-  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (blockIdx.y == 0 && threadIdx.x == 0 && c == g * cpg) {
-    mean_out[b * G + g] = mean;
-    rstd_out[b * G + g] = rstd;
-  }
-  const float ga = gamma[c], be = beta[c];
+  mean_out[bg] = (float)m;
+  rstd_out[bg] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        float* __restrict__ y, int BC, int C, int HW, int G, int act, GnGeom g) {
+  const int tid = threadIdx.x;
+  const int r = tid / g.T, l = tid - r * g.T;
+  const int bc = blockIdx.x * g.rows + r;
+  if (bc >= BC) return;
+  const int b = bc / C, c = bc - b * C;
+  const int gi = c / (C / G);
+  const float mu = mean[b * G + gi], rs = rstd[b * G + gi];
+  const float sc = rs * gamma[c], sh = beta[c] - mu * sc;         // z = v * sc + sh
   const size_t base = (size_t)bc * HW;
-  const int beg = blockIdx.y * chunk;
-  int end = beg + chunk;
+  const int beg = blockIdx.y * g.chunk;
+  int end = beg + g.chunk;
   if (end > HW) end = HW;
-  for (int i = beg + threadIdx.x; i < end; i += 256) {
-    float v = x[base + i];
-    if (res) v += res[base + i];
-    const float z = (v - mean) * rstd * ga + be;
-    y[base + i] = act_fwd(z, act);
+  if (VEC) {
+    for (int i = beg + 4 * l; i < end; i += 4 * g.T) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + base + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      float4 o;
+      o.x = act_fwd(fmaf(v.x, sc, sh), act); o.y = act_fwd(fmaf(v.y, sc, sh), act);
+      o.z = act_fwd(fmaf(v.z, sc, sh), act); o.w = act_fwd(fmaf(v.w, sc, sh), act);
+      *reinterpret_cast<float4*>(y + base + i) = o;
+    }
+  } else {
+    for (int i = beg + l; i < end; i += g.T) {
+      float v = x[base + i];
+      if (res) v += res[base + i];
+      y[base + i] = act_fwd(fmaf(v, sc, sh), act);
+    }
   }
 }
 
-// red[((b*C+c)*nchunk + chunk)*2 + {0,1}] = { sum dz, sum dz * xhat } over one chunk of HW;  dz = dy * act'(z)
+// ---- backward, pass 1: red[((b*C+c)*nchunk + chunk)*2 + {0,1}] = { sum dz, sum dz * xhat };  dz = dy * act'(z)
+template <bool VEC>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ res, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, double* __restrict__ red_ws,
-                                                             int C, int HW, int G, int act, int chunk) {
+                                                             int BC, int C, int HW, int G, int act, GnGeom g) {
   __shared__ double red[4];
-  const int bc = blockIdx.x;
-  const int b = bc / C, c = bc - b * C;
-  const int g = c / (C / G);
-  const float mu = mean[b * G + g], rs = rstd[b * G + g];
-  const float ga = gamma[c], be = beta[c];
-  const size_t base = (size_t)bc * HW;
-  const int beg = blockIdx.y * chunk;
-  int end = beg + chunk;
-  if (end > HW) end = HW;
+  const int tid = threadIdx.x;
+  const int r = tid / g.T, l = tid - r * g.T;
+  const int bc = blockIdx.x * g.rows + r;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = beg + threadIdx.x; i < end; i += 256) {
-    float v = x[base + i];
-    if (res) v += res[base + i];
-    const float xh = (v - mu) * rs;
-    const float dz = dy[base + i] * act_grad(xh * ga + be, act);
-    s1 += (double)dz;
-    s2 += (double)dz * (double)xh;
+  if (bc < BC) {
+    const int b = bc / C, c = bc - b * C;
+    const int gi = c / (C / G);
+    const float mu = mean[b * G + gi], rs = rstd[b * G + gi];
+    const float ga = gamma[c], be = beta[c];
+    const size_t base = (size_t)bc * HW;
+    const int beg = blockIdx.y * g.chunk;
+    int end = beg + g.chunk;
+    if (end > HW) end = HW;
+    if (VEC) {
+      for (int i = beg + 4 * l; i < end; i += 4 * g.T) {
+        float4 v = *reinterpret_cast<const float4*>(x + base + i);
+        if (res) { const float4 q = *reinterpret_cast<const float4*>(res + base + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+        const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (vv[k] - mu) * rs;
+          const float dz = dd[k] * act_grad(fmaf(xh, ga, be), act);
+          s1 += (double)dz;
+          s2 += (double)dz * (double)xh;
+        }
+      }
+    } else {
+      for (int i = beg + l; i < end; i += g.T) {
+        float v = x[base + i];
+        if (res) v += res[base + i];
+        const float xh = (v - mu) * rs;
+        const float dz = dy[base + i] * act_grad(fmaf(xh, ga, be), act);
+        s1 += (double)dz;
+        s2 += (double)dz * (double)xh;
+      }
+    }
   }
-  s1 = block_sum_256(s1, red);
-  s2 = block_sum_256(s2, red);
-  if (threadIdx.x == 0) {
-    red_ws[((size_t)bc * gridDim.y + blockIdx.y) * 2 + 0] = s1;
-    red_ws[((size_t)bc * gridDim.y + blockIdx.y) * 2 + 1] = s2;
+  s1 = row_sum(s1, g.T, red);
+  s2 = row_sum(s2, g.T, red);
+  if (l == 0 && bc < BC) {
+    red_ws[((size_t)bc * g.nchunk + blockIdx.y) * 2 + 0] = s1;
+    red_ws[((size_t)bc * g.nchunk + blockIdx.y) * 2 + 1] = s2;
   }
 }
 
-// dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat))
+// ---- backward, pass 1b (one thread per (b, c) for the channel sums, then per (b, g)):
+//   csum[(b*C+c)*2 + {0,1}] = channel totals (for dgamma / dbeta);  gsum[(b*G+g)*2 + {0,1}] = { mean_g(dz*gamma), mean_g(dz*gamma*xhat) }
+__global__ void __launch_bounds__(256) gn_bwd_group_kernel(const double* __restrict__ red_ws, const float* __restrict__ gamma,
+                                                            double* __restrict__ csum, float* __restrict__ gsum, int B, int C,
+                                                            int G, int nchunk, double n) {
+  const int bg = blockIdx.x * 256 + threadIdx.x;
+  if (bg >= B * G) return;
+  const int cpg = C / G;
+  const int b = bg / G, gi = bg - b * G;
+  double A = 0.0, Bq = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const int c = gi * cpg + k;
+    double r1 = 0.0, r2 = 0.0;
+    for (int j = 0; j < nchunk; ++j) {
+      r1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
+      r2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
+    }
+    csum[((size_t)b * C + c) * 2 + 0] = r1;
+    csum[((size_t)b * C + c) * 2 + 1] = r2;
+    A += (double)gamma[c] * r1;
+    Bq += (double)gamma[c] * r2;
+  }
+  gsum[bg * 2 + 0] = (float)(A / n);
+  gsum[bg * 2 + 1] = (float)(Bq / n);
+}
+
+// ---- backward, pass 2: dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat))
+template <bool VEC>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ res, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, const double* __restrict__ red_ws,
-                                                            float* __restrict__ dx, int C, int HW, int G, int act, int chunk) {
-  const int bc = blockIdx.x;
+                                                            const float* __restrict__ rstd, const float* __restrict__ gsum,
+                                                            float* __restrict__ dx, int BC, int C, int HW, int G, int act, GnGeom g) {
+  const int tid = threadIdx.x;
+  const int r = tid / g.T, l = tid - r * g.T;
+  const int bc = blockIdx.x * g.rows + r;
+  if (bc >= BC) return;
   const int b = bc / C, c = bc - b * C;
-  const int cpg = C / G, g = c / cpg;
-  double A = 0.0, Bq = 0.0;
-  const int nchunk = gridDim.y;
-  for (int k = 0; k < cpg; ++k) {
-    const int cc = g * cpg + k;
-    const double gk = (double)gamma[cc];
-    double r1 = 0.0, r2 = 0.0;
-    for (int j = 0; j < nchunk; ++j) {
-      r1 += red_ws[(((size_t)b * C + cc) * nchunk + j) * 2 + 0];
-      r2 += red_ws[(((size_t)b * C + cc) * nchunk + j) * 2 + 1];
-    }
-    A += gk * r1;
-    Bq += gk * r2;
-  }
-  const double n = (double)cpg * (double)HW;
-  const float mA = (float)(A / n), mB = (float)(Bq / n);
-  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  const int gi = c / (C / G);
+  const float mA = gsum[(b * G + gi) * 2 + 0], mB = gsum[(b * G + gi) * 2 + 1];
+  const float mu = mean[b * G + gi], rs = rstd[b * G + gi];
   const float ga = gamma[c], be = beta[c];
   const size_t base = (size_t)bc * HW;
-  const int beg = blockIdx.y * chunk;
-  int end = beg + chunk;
+  const int beg = blockIdx.y * g.chunk;
+  int end = beg + g.chunk;
   if (end > HW) end = HW;
-  for (int i = beg + threadIdx.x; i < end; i += 256) {
-    float v = x[base + i];
-    if (res) v += res[base + i];
-    const float xh = (v - mu) * rs;
-    const float dz = dy[base + i] * act_grad(xh * ga + be, act);
-    dx[base + i] = rs * (dz * ga - mA - xh * mB);
+  if (VEC) {
+    for (int i = beg + 4 * l; i < end; i += 4 * g.T) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + base + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      const float4 d = *reinterpret_cast<const float4*>(dy + base + i);
+      const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+      float oo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (vv[k] - mu) * rs;
+        const float dz = dd[k] * act_grad(fmaf(xh, ga, be), act);
+        oo[k] = rs * (dz * ga - mA - xh * mB);
+      }
+      *reinterpret_cast<float4*>(dx + base + i) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+    }
+  } else {
+    for (int i = beg + l; i < end; i += g.T) {
+      float v = x[base + i];
+      if (res) v += res[base + i];
+      const float xh = (v - mu) * rs;
+      const float dz = dy[base + i] * act_grad(fmaf(xh, ga, be), act);
+      dx[base + i] = rs * (dz * ga - mA - xh * mB);
+    }
   }
 }
 
-__global__ void __launch_bounds__(256) gn_bwd_params_kernel(const double* __restrict__ red_ws, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int B, int C, int nchunk) {
+__global__ void __launch_bounds__(256) gn_bwd_params_kernel(const double* __restrict__ csum, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int B, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b)
-    for (int j = 0; j < nchunk; ++j) {
-      s1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
-      s2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
-    }
+  for (int b = 0; b < B; ++b) {
+    s1 += csum[((size_t)b * C + c) * 2 + 0];
+    s2 += csum[((size_t)b * C + c) * 2 + 1];
+  }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
 }
 
-static int pick_chunk(int HW, int rows) {
-  // aim for >= ~1024 blocks overall, chunks a multiple of 256 elements, at least 1024 elements each
-  int want = ceil_div(1024, rows);
+// Work split: T lanes per channel row so that a lane moves >= 4 float4 per pass when the map allows it; rows of one
+// workgroup are consecutive (b, c) channels; a row is cut into chunks only when B*C rows alone cannot give ~4 workgroups per CU.
+static GnGeom gn_geom(int BC, int HW, bool vec, int max_chunks) {
+  GnGeom g;
+  const int units = vec ? HW / 4 : HW;                 // loads per row
+  int T = 256;
+  while (T > 1 && units < 4 * T) T >>= 1;             // >= 4 loads per lane, down to 1 lane per row for tiny maps
+  if (T > 256) T = 256;
+  g.T = T;
+  g.rows = 256 / T;
+  const int row_blocks = ceil_div(BC, g.rows);
+  int want = ceil_div(1024, row_blocks);               // ~1024 workgroups overall
   if (want < 1) want = 1;
-  if (want > PNSFM_GN_MAX_SPLIT) want = PNSFM_GN_MAX_SPLIT;
-  int chunk = ceil_div(HW, want);
-  if (chunk < 1024) chunk = 1024;
-  chunk = round_up(chunk, 256);
-  return chunk;
+  if (want > max_chunks) want = max_chunks;
+  const int per_pass = (vec ? 4 : 1) * T;              // elements one pass of the row's lanes covers
+  int chunk = round_up(ceil_div(HW, want), per_pass);
+  const int min_chunk = 8 * per_pass;                  // >= 8 passes per lane before a row is cut
+  if (chunk < min_chunk) chunk = min_chunk;
+  if (chunk >= HW) chunk = HW;
+  g.chunk = chunk;
+  g.nchunk = ceil_div(HW, chunk);
+  return g;
 }
 
 }  // namespace pnsfm
@@ -198,23 +321,31 @@ using namespace pnsfm;
 
 extern "C" {
 
+// workspace (doubles) the forward / backward entry points need for a [B, C, HW] tensor with G groups
+size_t pnsfm_groupnorm_ws_doubles(int B, int C, int G) {
+  // forward: 2 per (b, c, chunk); backward: 2 per (b, c, chunk) + 2 per (b, c) + 2 floats per (b, g) (rounded up)
+  return (size_t)2 * B * C * PNSFM_GN_MAX_SPLIT + (size_t)2 * B * C + (size_t)B * G + 16;
+}
+
 int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                 float* mean, float* rstd, double* stats_ws, int B, int C, int HW, int G, float eps,
                                 int act, void* stream) {
   if (C % G != 0 || B <= 0 || HW <= 0) { set_error("groupnorm_forward: bad shape C=%d G=%d", C, G); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  const long npg = (long)(C / G) * HW;
-  int nsplit = ceil_div(1024, B * G);
-  const int max_split = (int)((npg + 2047) / 2048);
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit > PNSFM_GN_MAX_SPLIT) nsplit = PNSFM_GN_MAX_SPLIT;
-  if (nsplit < 1) nsplit = 1;
-  PNSFM_LAUNCH(gn_stats_kernel, dim3(B * G, nsplit), dim3(256), 0, s, x, res, stats_ws, npg, nsplit);
+  const bool vec = (HW % 4 == 0);
+  const int BC = B * C, cpg = C / G;
+  const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
+  dim3 grid(ceil_div(BC, g.rows), g.nchunk);
+  if (vec) PNSFM_LAUNCH((gn_stats_kernel<true>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
+  else PNSFM_LAUNCH((gn_stats_kernel<false>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
   int e = check_launch("gn_stats");
   if (e) return e;
-  const int chunk = pick_chunk(HW, B * C);
-  PNSFM_LAUNCH(gn_apply_kernel, dim3(B * C, ceil_div(HW, chunk)), dim3(256), 0, s, x, res, gamma, beta,
-               (const double*)stats_ws, y, mean, rstd, C, HW, G, eps, act, chunk, nsplit);
+  PNSFM_LAUNCH(gn_finish_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, s, (const double*)stats_ws, mean, rstd, B * G,
+               cpg * g.nchunk, (double)cpg * (double)HW, eps);
+  e = check_launch("gn_finish");
+  if (e) return e;
+  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const float*)mean, (const float*)rstd, y, BC, C, HW, G, act, g);
+  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const float*)mean, (const float*)rstd, y, BC, C, HW, G, act, g);
   return check_launch("gn_apply");
 }
 
@@ -223,18 +354,26 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
                                  float* dbeta, double* red_ws, int B, int C, int HW, int G, int act, void* stream) {
   if (C % G != 0 || B <= 0 || HW <= 0) { set_error("groupnorm_backward: bad shape C=%d G=%d", C, G); return -1; }
   hipStream_t s = (hipStream_t)stream;
+  const bool vec = (HW % 4 == 0);
+  const int BC = B * C;
+  const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
+  dim3 grid(ceil_div(BC, g.rows), g.nchunk);
+  double* csum = red_ws + (size_t)2 * BC * g.nchunk;
+  float* gsum = reinterpret_cast<float*>(csum + (size_t)2 * BC);
   int e = 0;
-  const int chunk = pick_chunk(HW, B * C);
-  dim3 grid(B * C, ceil_div(HW, chunk));
-  if ((int)grid.y > PNSFM_GN_MAX_SPLIT) { set_error("groupnorm_backward: too many chunks"); return -1; }
-  PNSFM_LAUNCH(gn_bwd_reduce_kernel, grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, C, HW, G, act, chunk);
+  if (vec) PNSFM_LAUNCH((gn_bwd_reduce_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
+  else PNSFM_LAUNCH((gn_bwd_reduce_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_reduce");
   if (e) return e;
-  PNSFM_LAUNCH(gn_bwd_apply_kernel, grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const double*)red_ws, dx,
-               C, HW, G, act, chunk);
+  PNSFM_LAUNCH(gn_bwd_group_kernel, dim3(ceil_div(B * G, 256)), dim3(256), 0, s, (const double*)red_ws, gamma, csum, gsum, B, C, G,
+               g.nchunk, (double)(C / G) * (double)HW);
+  e = check_launch("gn_bwd_group");
+  if (e) return e;
+  if (vec) PNSFM_LAUNCH((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
+  else PNSFM_LAUNCH((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_apply");
   if (e) return e;
-  PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)red_ws, dgamma, dbeta, B, C, (int)grid.y);
+  PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)csum, dgamma, dbeta, B, C);
   return check_launch("gn_bwd_params");
 }
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_forward_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_groupnorm_ws_doubles": (_sz, [_i, _i, _i]),
     "pnsfm_groupnorm_act_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_space_to_depth": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -132,7 +132,7 @@ def groupnorm_act_forward(x, res, gamma, beta, G, eps, act):
     y = torch.empty_like(x)
     mean = torch.empty((B * G,), dtype=torch.float32, device=x.device)
     rstd = torch.empty((B * G,), dtype=torch.float32, device=x.device)
-    ws = torch.empty((2 * B * G * GN_MAX_SPLIT,), dtype=torch.float64, device=x.device)
+    ws = torch.empty((int(_lib.get().pnsfm_groupnorm_ws_doubles(B, C, G)),), dtype=torch.float64, device=x.device)
     rc = _lib.get().pnsfm_groupnorm_act_forward(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
                                                 _ptr(ws), B, C, HW, G, float(eps), act, _stream(x))
     _lib.check(rc, "groupnorm_act_forward")
@@ -146,7 +146,7 @@ def groupnorm_act_backward(dy, x, res, gamma, beta, mean, rstd, G, act):
     dx = torch.empty_like(x)
     dgamma = torch.empty_like(gamma)
     dbeta = torch.empty_like(beta)
-    ws = torch.empty((2 * B * C * GN_MAX_SPLIT,), dtype=torch.float64, device=x.device)
+    ws = torch.empty((int(_lib.get().pnsfm_groupnorm_ws_doubles(B, C, G)),), dtype=torch.float64, device=x.device)
     rc = _lib.get().pnsfm_groupnorm_act_backward(_ptr(dy), _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                                                  _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, C, HW, G, act, _stream(x))
     _lib.check(rc, "groupnorm_act_backward")

@@ -36,8 +36,8 @@ def test_packed_weight_sizes(lib_path):
     from packnet_sfm.hip import _lib
     lib = _lib.bind(ctypes.CDLL(lib_path))
     assert lib.pnsfm_conv2d_packed_elems_fwd(64, 64, 3) == 9 * 64 * 64
-    assert lib.pnsfm_conv2d_packed_elems_fwd(3, 64, 5) == 25 * 4 * 64          # K padded to even
-    assert lib.pnsfm_conv2d_packed_elems_fwd(129, 64, 3) == 9 * 130 * 64
+    assert lib.pnsfm_conv2d_packed_elems_fwd(3, 64, 5) == 25 * 16 * 64         # K rows padded to whole 16-channel chunks
+    assert lib.pnsfm_conv2d_packed_elems_fwd(129, 64, 3) == 9 * 144 * 64
     assert lib.pnsfm_conv2d_packed_elems_bwd(129, 64, 3) == 9 * 64 * 160       # M = 129 -> 5 tiles of 32
     assert lib.pnsfm_conv2d_packed_elems_fwd(256, 1, 3) == 9 * 256 * 32
 

@@ -227,6 +227,10 @@ int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* 
 int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                     int step, void* stream);
+/* The same update with the optimizer state on the DEVICE (replayable inside a hipGraph, one launch per parameter group of any
+ * size, float4 accesses): hp = float[12] {step, lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2, ...}; the call increments
+ * hp[0] and then applies step hp[0].  All four buffers must be 16-byte aligned. */
+int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, void* stream);
 
 /* ---- live timing of the dominant kernels (used by bench.py's roofline block) ---------------
  * When enabled, every launch of kind k is bracketed by hipEvents on its own stream.

@@ -102,6 +102,50 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Device-resident optimizer state (hipGraph-replayable: nothing the kernel needs is a launch argument that changes):
+//   hp[0] = step (as float, exact up to 2^24), hp[1] = lr, hp[2] = beta1, hp[3] = beta2, hp[4] = eps, hp[5] = weight decay,
+//   hp[6] = gradient scale (e.g. 1/world when gradients were sum-reduced), hp[7] = 1 - beta1, hp[8] = 1 - beta2 (rounded from
+//   the host's double arithmetic like torch.optim.Adam does: 1.f - 0.999f is 4.7e-5 off)
+__global__ void adam_tick_kernel(float* __restrict__ hp) { hp[0] += 1.f; }
+
+// float4 streaming Adam: 28 B/parameter of HBM traffic, bias corrections computed per thread from the device-side step
+__global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, size_t n, const float* __restrict__ hp) {
+  const float step = hp[0], lr = hp[1], beta1 = hp[2], beta2 = hp[3], eps = hp[4], wd = hp[5], gscale = hp[6];
+  const float omb1 = hp[7], omb2 = hp[8];
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));          // once per thread, in double like the host formula
+  const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+  const float step_size = lr / bc1;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float ga[4] = {gg.x, gg.y, gg.z, gg.w}, pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gi = ga[k] * gscale;
+      if (wd != 0.f) gi = fmaf(wd, pa[k], gi);
+      ma[k] = beta1 * ma[k] + omb1 * gi;
+      va[k] = beta2 * va[k] + omb2 * gi * gi;
+      pa[k] -= step_size * (ma[k] / (sqrtf(va[k]) * rsqrt_bc2 + eps));
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+  }
+  // tail (n % 4 elements)
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float gi = g[i] * gscale;
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    const float mi = beta1 * m[i] + omb1 * gi;
+    const float vi = beta2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
+  }
+}
+
 static int grid_for(size_t total) {
   size_t g = (total + 255) / 256;
   if (g > 16384) g = 16384;
@@ -146,6 +190,18 @@ int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   PNSFM_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
                beta1, beta2, eps, weight_decay, grad_scale, (float)bc1, (float)(1.0 / sqrt(bc2)));
   return check_launch("adam_step");
+}
+
+
+int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, void* stream) {
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) {
+    set_error("adam_flat_step: buffers must be 16-byte aligned");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  PNSFM_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, hp);
+  PNSFM_LAUNCH(adam_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, (const float*)hp);
+  return check_launch("adam_flat_step");
 }
 
 }  // extern "C"

@@ -186,6 +186,36 @@ def set_wgrad_stream(on):
     _WgradStream.enabled = bool(on)
 
 
+# Gradient slots: id(parameter) -> tensor the parameter's gradient should be WRITTEN into (a view of the flat gradient arena
+# of rccl/flat_adam.py, which is also the all-reduce bucket).  Only used when the node's gradient is the parameter's only
+# one this step (leaf, used once, .grad undefined, no hooks -- exactly `side_ok`): then AccumulateGrad just adopts the view.
+_GRAD_SLOTS = {}
+
+
+def register_grad_slots(pairs):
+    """pairs: iterable of (parameter, view).  Returns a handle whose .remove() unregisters them."""
+    keys = []
+    for p, v in pairs:
+        _GRAD_SLOTS[id(p)] = v
+        keys.append(id(p))
+
+    class _Handle:
+        def remove(self):
+            for k in keys:
+                _GRAD_SLOTS.pop(k, None)
+    return _Handle()
+
+
+def _slots_for(weight, bias, usable):
+    if not usable or not _GRAD_SLOTS:
+        return None, None
+    sw = _GRAD_SLOTS.get(id(weight))
+    sb = _GRAD_SLOTS.get(id(bias)) if bias is not None else None
+    if sw is None or (bias is not None and sb is None):
+        return None, None
+    return sw, sb
+
+
 def join_wgrad_stream(device):
     """Make the current stream of `device` wait for every weight gradient launched so far (no-op when unused).
     The gradient all-reduce calls this before it gathers a bucket in the middle of the backward pass."""
@@ -220,15 +250,17 @@ class Conv2dFn(Function):
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
         detached = _WgradStream.side_ok(*ctx.params)
+        sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[1])
         wait = None
         if want_w and _WgradStream.enabled and dy.is_cuda:
-            r = _WgradStream.run(lambda: ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias), x, dy, detached=detached)
+            r = _WgradStream.run(lambda: ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb), x, dy,
+                                 detached=detached)
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
         if want_w:
-            dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias)
+            dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
         if wait is not None:
             wait()
         return dx, dw, db, None, None

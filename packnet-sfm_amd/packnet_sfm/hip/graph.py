@@ -125,6 +125,9 @@ class GraphedTrainStep:
         (tests); default: drawn from Python's global RNG exactly like the reference's SfmModel."""
         if batch is not None:
             _copy_into(self.batch, batch)
+        sync = getattr(self.optimizer, 'sync_hyperparams', None)
+        if sync is not None:
+            sync()                 # FlatAdam keeps lr & co. on the device: push what an LR scheduler changed since the last step
         draw = random.random() < self.flip_prob        # drawn every step, like the reference, so the RNG sequence matches
         if flip is not None:
             draw = bool(flip)

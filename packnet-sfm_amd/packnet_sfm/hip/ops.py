@@ -87,11 +87,21 @@ def _alloc_dw_db(Cout, Cin, ks, want_bias, device):
     return buf[:n].view(Cout, Cin, ks, ks), (buf[n:] if want_bias else None)
 
 
-def conv2d_backward_weight(x, dy, ks, want_bias=True):
+def conv2d_backward_weight(x, dy, ks, want_bias=True, dw_out=None, db_out=None):
+    """dw_out / db_out: write the gradients into these (contiguous, right-shaped) tensors instead of fresh ones -- the flat
+    gradient arena of rccl/flat_adam.py hands out views of its all-reduce buckets here, so the weight gradient lands
+    where the collective and the optimizer read it, with no gather copy."""
     _chk(x, dy); _f32(x, dy)
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    dw, db = _alloc_dw_db(Cout, Cin, ks, want_bias, x.device)
+    if dw_out is not None:
+        _chk(dw_out, db_out); _f32(dw_out, db_out)
+        if tuple(dw_out.shape) != (Cout, Cin, ks, ks) or (want_bias and (db_out is None or db_out.numel() != Cout)):
+            raise RuntimeError("conv2d_backward_weight: gradient slot has the wrong shape")
+        # fresh view objects: AccumulateGrad adopts a gradient only if nobody else holds the tensor object
+        dw, db = dw_out.view(dw_out.shape), (db_out.view(db_out.shape) if want_bias else None)
+    else:
+        dw, db = _alloc_dw_db(Cout, Cin, ks, want_bias, x.device)
     rc = _lib.get().pnsfm_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, ks, _stream(x))
     _lib.check(rc, "conv2d_backward_weight")
     return dw, db
@@ -390,6 +400,13 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     _lib.check(_lib.get().pnsfm_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
                                           float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale),
                                           int(step), _stream(param)), "adam_step")
+
+
+def adam_flat_step(param, grad, exp_avg, exp_avg_sq, hp):
+    """Adam on flat fp32 buffers with device-resident state hp = float[12]: [step, lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2, ...]."""
+    _chk(param, grad, exp_avg, exp_avg_sq, hp); _f32(param, grad, exp_avg, exp_avg_sq, hp)
+    _lib.check(_lib.get().pnsfm_adam_flat_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(hp),
+                                               _stream(param)), "adam_flat_step")
 
 
 # ---------------------------------------------------------------------------------------------- prof

@@ -1,89 +1,179 @@
-"""FlatAdam: torch.optim.Adam semantics on ONE flat fp32 buffer per parameter group, updated by a single launch of the
-gfx950 `adam_kernel` (csrc/elementwise.hip, 28 B/parameter of HBM traffic) instead of ~250 per-tensor updates.
+"""FlatAdam: torch.optim.Adam semantics on flat fp32 arenas -- parameters, gradients, exp_avg, exp_avg_sq of a parameter
+group are each ONE buffer, updated by ONE launch of the gfx950 `adam_flat_kernel` (csrc/elementwise.hip: float4 accesses,
+28 B/parameter of HBM traffic, step counter and hyper-parameters read from device memory so the launch replays inside a
+hipGraph) instead of ~250 per-tensor updates.
 
-The parameters of each group are re-homed as views into a flat buffer (their names/shapes -- the checkpoint contract --
-do not change); gradients are expected as views into a matching flat buffer (GradBucketReducer already keeps them that
-way), otherwise they are gathered first.  Matches `Adam(lr, betas, eps, weight_decay)` of the reference's
-configure_optimizers (packnet_sfm/models/model_wrapper.py:128-149): two groups ('Depth', 'Pose'), StepLR-compatible
-(`param_groups[i]['lr']` is read every step).
+SURVEY.md 8(f) N1: the optimizer CONSUMES THE ALL-REDUCE BUCKETS IN PLACE.  The gradient arena is laid out in reverse
+registration order (the order backward produces gradients) and `grad_buckets()` cuts it into the contiguous <=128 MiB
+slices that `GradBucketReducer` all-reduces, so reduce and update touch the same memory: no second flat gradient buffer,
+no gather pass.  The conv weight-gradient kernels even write straight into their slice of the arena
+(`hip.functional.register_grad_slots`), so for them not even the bucket gather copy exists; gradients produced elsewhere
+(GroupNorm affine, Conv3d, PoseNet head) are gathered with one multi-tensor copy per group.
+
+Matches `Adam(lr, betas, eps, weight_decay)` of the reference's configure_optimizers
+(packnet_sfm/models/model_wrapper.py:128-166): two groups ('Depth', 'Pose') with their own lr / weight decay, StepLR-
+compatible (`param_groups[i]['lr']` is read before every step; `default_config.py:70-74`), and `state_dict()` /
+`load_state_dict()` speak torch.optim.Adam's layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups'}), which
+is what the reference's checkpoints store (`model.optimizer.state_dict()`), so optimizer state moves between the two.
 """
 import torch
 
 from packnet_sfm.hip import functional as HF
 from packnet_sfm.hip import ops
 
+_ALIGN = 4          # floats: every parameter starts on a 16-byte boundary of the arena (float4 kernel, 16-byte DMA)
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
 
 class FlatAdam:
-    def __init__(self, param_groups, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, param_groups, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_slots=True):
         if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
             param_groups = [{'params': list(param_groups)}]
         self.param_groups = []
-        self.state = {}
+        self.state = {}                 # torch-style handle; the tensors live in the arenas
+        self.grad_scale = 1.0           # e.g. 1/world_size when gradients were sum-reduced
+        slots = []
         for g in param_groups:
             params = [p for p in g['params'] if p.requires_grad]
-            group = {'lr': g.get('lr', lr), 'betas': g.get('betas', betas), 'eps': g.get('eps', eps),
-                     'weight_decay': g.get('weight_decay', weight_decay), 'name': g.get('name', ''), 'params': params}
-            n = sum(p.numel() for p in params)
+            if not params:
+                raise ValueError('FlatAdam: a parameter group without trainable parameters')
+            group = {'lr': g.get('lr', lr), 'betas': tuple(g.get('betas', betas)), 'eps': g.get('eps', eps),
+                     'weight_decay': g.get('weight_decay', weight_decay), 'name': g.get('name', ''), 'params': params,
+                     'amsgrad': False, 'maximize': False}
             dev = params[0].device
-            flat = torch.empty(n, dtype=torch.float32, device=dev)
-            off = 0
-            for p in params:
-                k = p.numel()
-                flat[off:off + k].copy_(p.detach().reshape(-1))
-                p.data = flat[off:off + k].view_as(p)          # parameter now lives inside the flat buffer
-                off += k
-            group['_flat'] = flat
-            group['_grad'] = torch.zeros(n, dtype=torch.float32, device=dev)
-            group['_m'] = torch.zeros(n, dtype=torch.float32, device=dev)
-            group['_v'] = torch.zeros(n, dtype=torch.float32, device=dev)
-            group['_step'] = 0
-            self._bind_grads(group)
+            order = list(reversed(params))          # arena order = the order backward produces gradients
+            offs, n = {}, 0
+            for p in order:
+                offs[id(p)] = n
+                n += _round_up(p.numel(), _ALIGN)
+            flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            grad = torch.zeros(n, dtype=torch.float32, device=dev)
+            for p in order:
+                o, k = offs[id(p)], p.numel()
+                flat[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = flat[o:o + k].view_as(p)   # the parameter now lives inside the arena (names / shapes unchanged)
+                p.grad = None
+            group.update(_order=order, _offs=offs, _flat=flat, _grad=grad,
+                         _m=torch.zeros(n, dtype=torch.float32, device=dev), _v=torch.zeros(n, dtype=torch.float32, device=dev),
+                         _hp=torch.zeros(12, dtype=torch.float32, device=dev), _hp_host=None)
+            self._sync_group(group)
             self.param_groups.append(group)
-        self.grad_scale = 1.0      # e.g. 1/world_size when gradients were sum-reduced
+            slots += [(p, self.grad_view(group, p)) for p in order]
+        self._slots = HF.register_grad_slots(slots) if grad_slots else None
+        HF.bump_weight_epoch()
 
+    # ---- arena access -------------------------------------------------------------------------------------------------
     @staticmethod
-    def _bind_grads(group):
-        off = 0
-        for p in group['params']:
-            k = p.numel()
-            p.grad = group['_grad'][off:off + k].view_as(p)
-            off += k
+    def grad_view(group, p):
+        o = group['_offs'][id(p)]
+        return group['_grad'][o:o + p.numel()].view_as(p)
 
-    def zero_grad(self, set_to_none=False):
+    def grad_buckets(self, bucket_bytes=128 << 20):
+        """[(flat slice of the gradient arena, [parameters], [their views])] -- contiguous, cut at parameter boundaries, in
+        the order backward fills them (last group first).  What GradBucketReducer all-reduces in place."""
+        out = []
+        for g in reversed(self.param_groups):
+            cur, start, end = [], None, None
+            for p in g['_order']:
+                o = g['_offs'][id(p)]
+                e = o + _round_up(p.numel(), _ALIGN)
+                if cur and (e - start) * 4 > bucket_bytes:
+                    out.append((g['_grad'][start:end], cur, [self.grad_view(g, q) for q in cur]))
+                    cur, start = [], None
+                if start is None:
+                    start = o
+                cur.append(p)
+                end = e
+            if cur:
+                out.append((g['_grad'][start:end], cur, [self.grad_view(g, q) for q in cur]))
+        return out
+
+    # ---- hyper-parameters live on the device (the update kernel reads them: replayable) --------------------------------
+    def _sync_group(self, g):
+        b1, b2 = float(g['betas'][0]), float(g['betas'][1])
+        host = (float(g['lr']), b1, b2, float(g['eps']), float(g['weight_decay']), float(self.grad_scale), 1.0 - b1, 1.0 - b2)
+        if g['_hp_host'] != host:
+            g['_hp_host'] = host
+            g['_hp'][1:9].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
+
+    def sync_hyperparams(self):
+        """Push lr / betas / eps / weight decay / grad_scale to the device if they changed (call OUTSIDE a hipGraph replay
+        after an LR-scheduler step; eager `step()` does it itself)."""
         for g in self.param_groups:
-            g['_grad'].zero_()
-            self._bind_grads(g)
+            self._sync_group(g)
 
-    def _gather_grads(self, group):
-        """Make sure group['_grad'] holds the gradients (no copy when p.grad is already the flat view)."""
-        off = 0
-        for p in group['params']:
-            k = p.numel()
-            view = group['_grad'][off:off + k]
+    # ---- torch.optim.Optimizer surface --------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none=True):
+        """Gradients are dropped, not zero-filled: the next backward writes every element of the arena slices it uses (the
+        conv kernels directly, the rest through the gather), and a parameter without a gradient is zeroed in the gather."""
+        for g in self.param_groups:
+            for p in g['params']:
+                p.grad = None
+
+    def _gather_grads(self, g):
+        """Make g['_grad'] hold the gradients: no copy for gradients that already live in their arena slice."""
+        src, dst = [], []
+        for p in g['_order']:
+            view = self.grad_view(g, p)
             if p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad.reshape(-1))
-            off += k
+                src.append(p.grad.detach().reshape(view.shape))
+                dst.append(view)
+        if src:
+            torch._foreach_copy_(dst, src)
 
     @torch.no_grad()
     def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         for g in self.param_groups:
             self._gather_grads(g)
-            g['_step'] += 1
-            b1, b2 = g['betas']
-            ops.adam_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['lr'], b1, b2, g['eps'], g['weight_decay'],
-                          self.grad_scale, g['_step'])
+            if not capturing:
+                self._sync_group(g)
+            ops.adam_flat_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['_hp'])
         HF.bump_weight_epoch()      # parameters changed through raw pointers: invalidate packed conv weights
+        return loss
 
+    # ---- checkpoints in torch.optim.Adam's layout ----------------------------------------------------------------------
     def state_dict(self):
-        return {'groups': [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in g.items() if k != 'params'}
-                           for g in self.param_groups]}
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            step = g['_hp'][0:1].detach().clone().reshape(()).cpu()
+            ids = []
+            for p in g['params']:
+                o, k = g['_offs'][id(p)], p.numel()
+                state[idx] = {'step': step.clone(), 'exp_avg': g['_m'][o:o + k].view_as(p).clone(),
+                              'exp_avg_sq': g['_v'][o:o + k].view_as(p).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({'lr': g['lr'], 'betas': g['betas'], 'eps': g['eps'], 'weight_decay': g['weight_decay'],
+                           'amsgrad': False, 'maximize': False, 'name': g['name'], 'params': ids})
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        for g, s in zip(self.param_groups, sd['groups']):
-            for k in ('_m', '_v'):
-                g[k].copy_(s[k])
-            g['_step'] = s['_step']
-            for k in ('lr', 'betas', 'eps', 'weight_decay'):
-                g[k] = s[k]
+        if 'param_groups' not in sd or len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError('FlatAdam.load_state_dict: expected torch.optim.Adam layout with %d groups' % len(self.param_groups))
+        for g, sg in zip(self.param_groups, sd['param_groups']):
+            if len(sg['params']) != len(g['params']):
+                raise ValueError('FlatAdam.load_state_dict: group size mismatch')
+            for k in ('lr', 'eps', 'weight_decay'):
+                if k in sg:
+                    g[k] = sg[k]
+            if 'betas' in sg:
+                g['betas'] = tuple(sg['betas'])
+            step = 0.0
+            for p, i in zip(g['params'], sg['params']):
+                st = sd['state'].get(i)
+                if st is None:
+                    continue
+                o, k = g['_offs'][id(p)], p.numel()
+                g['_m'][o:o + k].copy_(st['exp_avg'].reshape(-1))
+                g['_v'][o:o + k].copy_(st['exp_avg_sq'].reshape(-1))
+                step = max(step, float(st['step']))
+            g['_hp'][0:1].fill_(step)
+            g['_hp_host'] = None
+            self._sync_group(g)

@@ -73,8 +73,10 @@ class DistributedOptimizer:
                  force_collectives=False):
         self._opt = optimizer
         params = [p for g in optimizer.param_groups for p in g['params']]
+        # an optimizer that keeps its gradients in a flat arena (rccl/flat_adam.py) lends its buckets: reduce + update in place
+        buckets = optimizer.grad_buckets(bucket_bytes) if hasattr(optimizer, 'grad_buckets') else None
         self._reducer = GradBucketReducer(params, bucket_bytes=bucket_bytes, average=True,
-                                          force_collectives=force_collectives)
+                                          force_collectives=force_collectives, buckets=buckets)
 
     def zero_grad(self, set_to_none=False):
         self._reducer.zero_grad()

@@ -46,14 +46,17 @@ def init_process_group(backend=None):
 
 
 class _Bucket:
-    def __init__(self, params, device, dtype):
+    def __init__(self, params, device, dtype, flat=None, views=None):
         self.params = params
-        n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, device=device, dtype=dtype)
         self.pending = len(params)
         self.launched = False
         self.work = None
         self.event = None
+        if flat is not None:            # a slice of somebody else's arena (FlatAdam's gradient buffer): reduced in place
+            self.flat, self.views = flat, list(views)
+            return
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, device=device, dtype=dtype)
         off = 0
         self.views = []
         for p in params:
@@ -72,7 +75,7 @@ class GradBucketReducer:
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
-    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, force_collectives=False):
+    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, force_collectives=False, buckets=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
@@ -89,16 +92,30 @@ class GradBucketReducer:
         self.device = params[0].device
         self.buckets = []
         self._bucket_of = {}
-        cur, cur_bytes = [], 0
-        for p in reversed(params):                      # backward produces gradients roughly back-to-front
-            nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
+        if buckets is not None:
+            # `buckets`: [(flat slice, [parameters], [views])] handed over by the optimizer (FlatAdam.grad_buckets): the
+            # collective runs in place on the optimizer's gradient arena -- no second flat buffer, no gather for gradients
+            # the kernels already wrote there
+            covered = set()
+            for flat, bparams, views in buckets:
+                b = _Bucket(list(bparams), self.device, flat.dtype, flat=flat, views=views)
+                for p in bparams:
+                    self._bucket_of[p] = b
+                    covered.add(id(p))
+                self.buckets.append(b)
+            if covered != {id(p) for p in params}:
+                raise ValueError('GradBucketReducer: the optimizer buckets do not cover the trainable parameters')
+        else:
+            cur, cur_bytes = [], 0
+            for p in reversed(params):                      # backward produces gradients roughly back-to-front
+                nbytes = p.numel() * p.element_size()
+                if cur and cur_bytes + nbytes > bucket_bytes:
+                    self._close(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
                 self._close(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._close(cur)
         self._host_staged = backend == 'gloo' and self.device.type == 'cuda'
         self.side_stream = torch.cuda.Stream(device=self.device) if (self.device.type == 'cuda' and not self._host_staged) else None
         self._hooks = []

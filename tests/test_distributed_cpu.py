@@ -16,7 +16,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, opt_kind='torch'):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     import sys
@@ -29,8 +29,24 @@ def _worker(rank, world, port, q):
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
     net.add_module('unused', torch.nn.Linear(3, 3))        # never reached by the loss: its bucket slots must reduce as zeros
     used = lambda t: net[3](net[2](net[1](net[0](t))))     # noqa: E731
-    opt = hvd.DistributedOptimizer(torch.optim.Adam(net.parameters(), lr=1e-2), named_parameters=net.named_parameters(),
+    if opt_kind == 'flat':
+        # FlatAdam's update kernel runs on the host-emulated build here (test infrastructure; the product loads gfx950 only)
+        sys.path.insert(0, os.path.join(root, 'tests', 'emu'))
+        import emu_loader
+        emu_loader.use_emulated_kernels()
+        from packnet_sfm.rccl.flat_adam import FlatAdam
+        inner = FlatAdam([{'params': list(net[:3].parameters()), 'lr': 1e-2},
+                          {'params': list(net[3].parameters()) + list(net.unused.parameters()), 'lr': 1e-2}])
+    else:
+        inner = torch.optim.Adam(net.parameters(), lr=1e-2)
+    opt = hvd.DistributedOptimizer(inner, named_parameters=net.named_parameters(),
                                    compression=hvd.Compression.none, bucket_bytes=300)   # tiny buckets -> several collectives
+    if opt_kind == 'flat':
+        # the collective runs IN PLACE on the optimizer's gradient arena (no second flat buffer)
+        arenas = [(g['_grad'].data_ptr(), g['_grad'].data_ptr() + g['_grad'].numel() * 4) for g in inner.param_groups]
+        assert len(opt._reducer.buckets) >= 3
+        for b in opt._reducer.buckets:
+            assert any(lo <= b.flat.data_ptr() and b.flat.data_ptr() + b.flat.numel() * 4 <= hi for lo, hi in arenas)
     data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
     target = torch.randn(8, 1, generator=torch.Generator().manual_seed(2))
     shard = slice(rank * 4, rank * 4 + 4)
@@ -40,6 +56,7 @@ def _worker(rank, world, port, q):
         loss = ((used(data[shard]) - target[shard]) ** 2).mean()
         loss.backward()
         opt.synchronize()
+        opt.synchronize()           # idempotent within a step (horovod idiom: synchronize(); clip; step())
         if it == 0:
             assert all(p.grad is not None for p in net.parameters()), 'unused parameters must still hold a (zero) gradient'
             assert float(net.unused.weight.grad.abs().sum()) == 0.0
@@ -53,11 +70,20 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gloo_world2_gradient_average():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('opt_kind', ['torch', 'flat'])
+def test_gloo_world2_gradient_average(opt_kind):
+    if opt_kind == 'flat':
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+        from build_emu import build_emu
+        build_emu()                 # once, in the parent: the two ranks only load it
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, opt_kind)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(q.get(timeout=120) for _ in range(world))

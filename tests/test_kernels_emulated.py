@@ -350,6 +350,64 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     for pa, pb in zip(net_a.parameters(), net_b.parameters()):
         P.check(pb, pa, 1e-5, 'flat adam parameter')
     assert set(net_b.state_dict().keys()) == set(net_a.state_dict().keys())
+    # optimizer state in torch.optim.Adam's layout, both directions (the reference's checkpoints store optimizer.state_dict())
+    sd = opt.state_dict()
+    assert set(sd.keys()) == {'state', 'param_groups'} and len(sd['state']) == 4 and [g['params'] for g in sd['param_groups']] == [[0, 1], [2, 3]]
+    rsd = ref.state_dict()
+    for i in range(4):
+        P.check(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'], 1e-5, 'exp_avg %d' % i)
+        P.check(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq'], 1e-5, 'exp_avg_sq %d' % i)
+        assert float(sd['state'][i]['step']) == float(rsd['state'][i]['step']) == 4.0
+    net_c = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 3))
+    net_c.load_state_dict(net_a.state_dict())
+    opt_c = FlatAdam([{'params': list(net_c[0].parameters()), 'lr': 1e-2}, {'params': list(net_c[2].parameters()), 'lr': 3e-3}])
+    opt_c.load_state_dict(rsd)                  # resume from a TORCH Adam checkpoint ...
+    ref2 = torch.optim.Adam([{'params': net_a[0].parameters(), 'lr': 1e-2}, {'params': net_a[2].parameters(), 'lr': 3e-3}])
+    ref2.load_state_dict(sd)                    # ... and torch Adam from a FlatAdam checkpoint
+    for o, net in ((opt_c, net_c), (ref2, net_a), (opt, net_b)):
+        o.zero_grad()
+        net(x).pow(2).sum().backward()
+        o.step()
+    for pa, pb, pc in zip(net_a.parameters(), net_b.parameters(), net_c.parameters()):
+        P.check(pc, pb, 1e-5, 'resumed from torch state')
+        P.check(pa, pb, 1e-5, 'torch resumed from FlatAdam state')
+    opt.param_groups[0]['lr'] = 5e-3            # an LR scheduler writes param_groups[i]['lr']: picked up by the next step
+    w0 = net_b[0].weight.detach().clone()
+    opt.zero_grad(); net_b(x).pow(2).sum().backward(); opt.step()
+    moved = float((net_b[0].weight.detach() - w0).abs().max())
+    assert 3e-3 < moved <= 5e-3 * 1.2, moved     # ~lr * m/sqrt(v): the new lr (was 1e-2) took effect
+
+
+def test_flat_adam_gradient_slots(emulated_kernels):
+    """The conv weight-gradient kernel writes straight into FlatAdam's gradient arena (hip.functional.register_grad_slots):
+    after backward the parameter's .grad IS the arena view (no gather copy), a parameter used twice falls back to the normal
+    path, and three steps equal torch.optim.Adam on an identical replica."""
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    torch.manual_seed(2)
+    a, b = Conv2D(4, 32, 3, 1), Conv2D(4, 32, 3, 1)     # 2 channels per GroupNorm group: the conv bias has a real gradient
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2)
+    opt = FlatAdam([{'params': list(b.parameters()), 'lr': 1e-2}])
+    g = opt.param_groups[0]
+    x = torch.randn(2, 4, 6, 8)
+    for step in range(3):
+        ref.zero_grad(); opt.zero_grad()
+        a(x).pow(2).mean().backward()
+        b(x).pow(2).mean().backward()
+        w = b.conv_base.weight
+        assert w.grad.data_ptr() == opt.grad_view(g, w).data_ptr(), 'conv weight gradient was not written into the arena'
+        assert b.conv_base.bias.grad.data_ptr() == opt.grad_view(g, b.conv_base.bias).data_ptr()
+        P.check(w.grad, a.conv_base.weight.grad, 1e-5, 'slot gradient')
+        ref.step(); opt.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        P.check(pb, pa, 1e-5, 'parameter after 3 steps')
+    opt.zero_grad()
+    (b(x).pow(2).mean() + b(2 * x).pow(2).mean()).backward()          # weight used twice: gradients must ACCUMULATE
+    ref.zero_grad()
+    (a(x).pow(2).mean() + a(2 * x).pow(2).mean()).backward()
+    P.check(b.conv_base.weight.grad, a.conv_base.weight.grad, 1e-5, 'shared-use gradient')
+    opt._slots.remove()
 
 
 @pytest.mark.parametrize('variant', [0, 2])

@@ -160,7 +160,7 @@ def main():
                     help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
-    ap.add_argument('--optimizer', default='torch', choices=['flat', 'torch'],
+    ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
                     help='replay the whole step as a hipGraph (packnet_sfm/hip/graph.py); auto = on for 1 GPU, off for N>1 '

@@ -79,6 +79,20 @@ int pnsfm_tune_set(const int* key7, int v0, int v1);
  * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen
  * convolutions.  A process started with a complete database launches no candidate kernels. */
 
+/* ---- device-side input pipeline (uint8 frames; bit-exact to Pillow's libImaging arithmetic) --------------------------------
+ * replaces, on the training input path, datasets/transforms.py:11-41 (train_transforms) = datasets/augmentations.py:101-180
+ * resize (transforms.Resize, Lanczos), :228-337 duplicate + colour jitter (torchvision adjust_* on PIL images), :185-226 ToTensor.
+ * pnsfm_resample8: ONE axis of PIL's separable 8-bit resample (axis 1: width, axis 0: height) over N images in NHWC layout;
+ *   kk [out][ksize] int32 fixed-point coefficients (22 fractional bits) and bounds [out][2] = {first input index, count}, computed
+ *   by the host exactly as Resample.c precompute_coeffs / normalize_coeffs_8bpc (packnet_sfm/datasets/device_transforms.py).
+ * pnsfm_jitter_totensor: per image the <= 4 colour operations in the drawn order, then ToTensor; img NHWC uint8 [N][H][W][3],
+ *   ops = N records {int op[4] (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none); float factor[4]; int hue_add
+ *   (= uint8(hue_factor*255)); int enabled}, lsum_ws: N x uint64 scratch; out / out_orig (nullable): NCHW float32 [N][3][H][W]. */
+int pnsfm_resample8(const uint8_t* in, uint8_t* out, const int* kk, const int* bounds, int ksize, int N, int inH, int inW,
+                    int outH, int outW, int C, int axis, void* stream);
+int pnsfm_jitter_totensor(const uint8_t* img, const void* ops, unsigned long long* lsum_ws, float* out, float* out_orig /*nullable*/,
+                          int N, int H, int W, void* stream);
+
 /* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the
  * residual form `activ(normalize(x_out + shortcut))`: layers01.py:61-62,72.

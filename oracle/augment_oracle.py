@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE -- CPU oracle of the training input pipeline: the reference's train_transforms
+(/root/reference/packnet_sfm/datasets/transforms.py:11-41) executed with the REAL Pillow of this image.
+
+The reference calls torchvision (pinned torchvision==0.9.1 in docker/Dockerfile:88-89; not installed here) on PIL images.
+For PIL inputs torchvision 0.9.1's functional_pil does nothing but call Pillow, restated here call for call:
+  transforms.Resize(shape, ANTIALIAS)       -> img.resize(shape[::-1], Image.LANCZOS)            (augmentations.py:101-125)
+  adjust_brightness / _contrast / _saturation-> ImageEnhance.Brightness / Contrast / Color(img).enhance(f)   (functional_pil.py)
+  adjust_hue                                 -> HSV split, np.uint8 add of uint8(hue_factor*255) with wrap, merge, back
+  transforms.ToTensor                        -> uint8 HWC -> float32 CHW / 255
+and the random draws are the reference's own (augmentations.py:254-337: random.random, 4 x random.uniform, random.shuffle).
+Pinned: tests/test_input_pipeline.py checks the product kernels against THIS (i.e. against Pillow 12.2 itself), exhaustively
+over all 2^24 colours for the HSV round trip.  Only tests / smoke may import this module."""
+import random
+
+import numpy as np
+import torch
+from PIL import Image, ImageEnhance
+
+
+def resize_image(img, shape):
+    return img.resize((shape[1], shape[0]), Image.LANCZOS)
+
+
+def adjust_hue(img, hue_factor):
+    if not -0.5 <= hue_factor <= 0.5:
+        raise ValueError('hue_factor ({}) is not in [-0.5, 0.5].'.format(hue_factor))
+    h, s, v = img.convert('HSV').split()
+    np_h = np.array(h, dtype=np.uint8)
+    with np.errstate(over='ignore'):
+        np_h += np.array(hue_factor * 255).astype(np.uint8)
+    return Image.merge('HSV', (Image.fromarray(np_h, 'L'), s, v)).convert('RGB')
+
+
+def random_color_jitter_transform(parameters):
+    brightness, contrast, saturation, hue = parameters
+    bf = random.uniform(max(0, 1 - brightness), 1 + brightness)
+    cf = random.uniform(max(0, 1 - contrast), 1 + contrast)
+    sf = random.uniform(max(0, 1 - saturation), 1 + saturation)
+    hf = random.uniform(-hue, hue)
+    all_transforms = [lambda im: ImageEnhance.Brightness(im).enhance(bf), lambda im: ImageEnhance.Contrast(im).enhance(cf),
+                      lambda im: ImageEnhance.Color(im).enhance(sf), lambda im: adjust_hue(im, hf)]
+    random.shuffle(all_transforms)
+
+    def composed(im):
+        for t in all_transforms:
+            im = t(im)
+        return im
+    return composed
+
+
+def to_tensor(img):
+    return torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float().div(255)
+
+
+def train_transforms(sample, image_shape, jittering, crop_train_borders=()):
+    """sample: {'rgb': PIL, 'rgb_context': [PIL], 'intrinsics': np [3,3]} -> as the reference's train_transforms (image keys)."""
+    sample = dict(sample)
+    if len(crop_train_borders) > 0:
+        b = crop_train_borders
+        K = np.copy(sample['intrinsics']); K[0, 2] -= b[0]; K[1, 2] -= b[1]
+        sample['intrinsics'] = K
+        sample['rgb'] = sample['rgb'].crop(b)
+        sample['rgb_context'] = [k.crop(b) for k in sample['rgb_context']]
+    if len(image_shape) > 0:
+        ow, oh = sample['rgb'].size
+        K = np.copy(sample['intrinsics']); K[0] *= image_shape[1] / ow; K[1] *= image_shape[0] / oh
+        sample['intrinsics'] = K
+        sample['rgb'] = resize_image(sample['rgb'], image_shape)
+        sample['rgb_context'] = [resize_image(k, image_shape) for k in sample['rgb_context']]
+    sample['rgb_original'] = sample['rgb'].copy()
+    sample['rgb_context_original'] = [k.copy() for k in sample['rgb_context']]
+    if len(jittering) > 0 and random.random() < 1.0:
+        t = random_color_jitter_transform(jittering[:4])
+        sample['rgb'] = t(sample['rgb'])
+        sample['rgb_context'] = [t(k) for k in sample['rgb_context']]
+    for key in ('rgb', 'rgb_original'):
+        sample[key] = to_tensor(sample[key])
+    for key in ('rgb_context', 'rgb_context_original'):
+        sample[key] = [to_tensor(k) for k in sample[key]]
+    return sample

@@ -394,6 +394,35 @@ def supervised_loss_backward(pred, gt, ws, grad_out, method, sparse):
     return dpred
 
 
+# ------------------------------------------------------------------------------------- input pipeline
+def resample8(img, kk, bounds, out_size, axis):
+    """One axis of PIL's 8-bit separable resample.  img: uint8 [N,H,W,C] (NHWC); kk int32 [out, ksize]; bounds int32 [out, 2]."""
+    _chk(img, kk, bounds)
+    if img.dtype != torch.uint8 or kk.dtype != torch.int32 or bounds.dtype != torch.int32:
+        raise RuntimeError("resample8: uint8 image, int32 coefficient tables expected")
+    N, H, W, C = img.shape
+    oH, oW = (H, out_size) if axis == 1 else (out_size, W)
+    out = torch.empty((N, oH, oW, C), dtype=torch.uint8, device=img.device)
+    _lib.check(_lib.get().pnsfm_resample8(_ptr(img), _ptr(out), _ptr(kk), _ptr(bounds), kk.shape[1], N, H, W, oH, oW, C, axis,
+                                          _stream(img)), "resample8")
+    return out
+
+
+def jitter_totensor(img, ops_records, want_original=True):
+    """img: uint8 [N,H,W,3]; ops_records: uint8 tensor holding N packed 40-byte JitterOps records -> (jittered, original) float32
+    [N,3,H,W] (original is None unless requested)."""
+    _chk(img, ops_records)
+    N, H, W, C = img.shape
+    if img.dtype != torch.uint8 or C != 3 or ops_records.dtype != torch.uint8 or ops_records.numel() != 40 * N:
+        raise RuntimeError("jitter_totensor: uint8 [N,H,W,3] image and N 40-byte operation records expected")
+    out = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device)
+    orig = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device) if want_original else None
+    ws = torch.empty((N,), dtype=torch.int64, device=img.device)
+    _lib.check(_lib.get().pnsfm_jitter_totensor(_ptr(img), _ptr(ops_records), _ptr(ws), _ptr(out), _ptr(orig), N, H, W, _stream(img)),
+               "jitter_totensor")
+    return out, orig
+
+
 # ---------------------------------------------------------------------------------------------- adam
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     _chk(param, grad, exp_avg, exp_avg_sq); _f32(param, grad, exp_avg, exp_avg_sq)

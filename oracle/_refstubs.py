@@ -31,6 +31,21 @@ def install():
         y = _mod('yacs')
         y.config = _mod('yacs.config')
         y.config.CfgNode = type('CfgNode', (dict,), {})
+    if 'MinkowskiEngine' not in sys.modules:
+        # PackNetSAN01 imports MinkowskiEngine (third-party, un-versioned, not installed).  Parameter-free placeholders let the
+        # reference's DENSE path (input_depth=None) be constructed and run; the sparse branch itself cannot be executed here.
+        me = _mod('MinkowskiEngine')
+
+        class _Placeholder(torch.nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def forward(self, *a, **k):
+                raise RuntimeError('MinkowskiEngine is not available: the sparse branch of the reference cannot run here')
+        for name in ('MinkowskiConvolution', 'MinkowskiBatchNorm', 'MinkowskiReLU', 'MinkowskiMaxPooling', 'MinkowskiSigmoid'):
+            setattr(me, name, _Placeholder)
+        me.SparseTensor = _Placeholder
+        me.utils = _mod('MinkowskiEngine.utils')
     if 'termcolor' not in sys.modules:
         _mod('termcolor').colored = lambda s, *a, **k: s
     if not hasattr(cm, 'get_cmap'):

@@ -35,11 +35,20 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 torch.set_num_threads(8)
 
 
-def close(a, b, tol, what):
+def close(a, b, tol, what, floor=0.0):
+    """max |a - b| <= tol * max(max |b|, floor): a RELATIVE tolerance.  `floor` is the scale below which a tensor counts as
+    round-off (gradient comparisons pass 1e-3 x the largest gradient of the same block / network: conv biases in front of a
+    one-channel-per-group GroupNorm have a mathematically zero gradient, pure noise in both implementations).  VERDICT r1:
+    the earlier `tol * max(ref, 1.0)` was an absolute tolerance for every tensor whose maximum is below 1."""
     err = (a - b).abs().max().item()
-    ref = b.abs().max().item() + 1e-30
-    assert err <= tol * max(ref, 1.0) or err / ref <= tol, '%s: max err %.3e (ref max %.3e)' % (what, err, ref)
+    ref = max(b.abs().max().item(), floor, 1e-30)
+    assert err <= tol * ref, '%s: max err %.3e > %.1e x %.3e' % (what, err, tol, ref)
     return err / ref
+
+
+def grad_floor(grads):
+    """1e-3 x the largest gradient magnitude of a block / network (see close)."""
+    return 1e-3 * max(g.abs().max().item() for g in grads if g is not None)
 
 
 def smooth_images(B, H, W, gen, n=3, shift=2.0):
@@ -77,6 +86,7 @@ def case_layers(gen):
     # Conv2D (pad+conv+GN+ELU) -- several kernel sizes / odd channel counts
     for name, cin, cout, k, H, W in (('conv2d_k3', 19, 32, 3, 12, 40), ('conv2d_k5', 3, 16, 5, 10, 32),
                                       ('conv2d_k7', 16, 16, 7, 8, 64)):
+        torch.manual_seed(101)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
         m = R.Conv2D(cin, cout, k, 1)
         randomize(m, gen)
         x = torch.randn(2, cin, H, W, generator=gen, requires_grad=True)
@@ -90,6 +100,7 @@ def case_layers(gen):
         fx[name] = dict(k=k, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
                         dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
     # ResidualConv
+    torch.manual_seed(102)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
     m = R.ResidualConv(16, 32, 1)
     randomize(m, gen)
     x = torch.randn(2, 16, 6, 20, generator=gen, requires_grad=True)
@@ -106,6 +117,7 @@ def case_layers(gen):
     fx['packing'] = dict(x=x, y=R.packing(x))
     # PackLayerConv3d
     for name, c, k, H, W in (('pack_k3', 16, 3, 12, 40), ('pack_k5', 16, 5, 8, 64)):
+        torch.manual_seed(103)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
         m = R.PackLayerConv3d(c, k)
         randomize(m, gen)
         with torch.no_grad():
@@ -119,6 +131,7 @@ def case_layers(gen):
         fx[name] = dict(k=k, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
                         dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
     # UnpackLayerConv3d
+    torch.manual_seed(104)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
     m = R.UnpackLayerConv3d(32, 32, 3)
     randomize(m, gen)
     with torch.no_grad():
@@ -132,6 +145,7 @@ def case_layers(gen):
     fx['unpack'] = dict(k=3, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
                         dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
     # InvDepth
+    torch.manual_seed(105)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
     m = R.InvDepth(16)
     randomize(m, gen)
     x = torch.randn(2, 16, 6, 20, generator=gen, requires_grad=True)
@@ -183,7 +197,7 @@ def case_loss(gen, cases=None, keep_clip=False):
         go = grads_of(lo.sum(), inv_o + [pv_o])
         close(lo, loss.detach(), 1e-5, name + '.loss')
         for i in range(5):
-            close(go[i], g[i], 2e-4, '%s.grad%d' % (name, i))
+            close(go[i], g[i], 2e-4, '%s.grad%d' % (name, i), floor=grad_floor(g))
         fx[name] = dict(kwargs=okw, image=image, context=context, K=K, inv_depths=[t.detach() for t in inv],
                         pose_vec=pose_vec, loss=loss.detach(), photometric_loss=out['metrics']['photometric_loss'],
                         smoothness_loss=out['metrics']['smoothness_loss'], d_inv_depths=g[:4], d_pose_vec=g[4])
@@ -213,7 +227,7 @@ def case_network(gen):
     g = grads_of(sum((d * dy).sum() for d, dy in zip(disps, dys)), list(net.parameters()))
     go = grads_of(sum((d * dy).sum() for d, dy in zip(disps_o, dys)), [sdo[n] for n in names])
     for n, a, b in zip(names, go, g):
-        close(a, b, 5e-4, 'packnet01.grad.' + n)
+        close(a, b, 5e-4, 'packnet01.grad.' + n, floor=grad_floor(g))
     net.eval()
     with torch.no_grad():
         d_eval = net(rgb)['inv_depths']
@@ -279,8 +293,9 @@ def case_step(gen):
         close(oo['loss'], loss.detach(), 2e-5, 'step.loss')
         go = grads_of(oo['loss'].sum(), [sdo[n] for n, _ in dn.named_parameters()] + [psdo[n] for n, _ in pn.named_parameters()])
         worst = 0.0
+        gfloor = grad_floor(g)
         for n, a, b in zip(names, go, g):
-            worst = max(worst, close(a, b, 2e-3, 'step.grad.' + n))
+            worst = max(worst, close(a, b, 2e-3, 'step.grad.' + n, floor=gfloor))
         print('  step flip=%s loss=%.6f  worst rel grad err oracle-vs-reference %.2e' % (flip, float(loss), worst))
         fx['step_flip%d' % int(flip)] = dict(
             depth_seed=42, pose_seed=43, pose_pred_bias=psd['pose_pred.bias'], loss_kwargs=loss_kwargs, flip=flip,
@@ -346,6 +361,7 @@ def case_slim(gen):
     """The d = 4 (`num_3d_feat`) variants of the packing / unpacking blocks and PackNetSlim01('1A') at 32x64."""
     fx = {}
     for name, c, k, H, W in (('pack_d4_k3', 16, 3, 12, 40), ('pack_d4_k5', 16, 5, 8, 64)):
+        torch.manual_seed(106)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
         m = R.PackLayerConv3d(c, k, d=4)
         randomize(m, gen)
         with torch.no_grad():
@@ -358,6 +374,7 @@ def case_slim(gen):
         g = grads_of((y * dy).sum(), [x] + list(m.parameters()))
         fx[name] = dict(k=k, d=4, x=x.detach(), sd=sd, y=y.detach(), dy=dy, dx=g[0],
                         dparams={n: gg for (n, _), gg in zip(m.named_parameters(), g[1:])})
+    torch.manual_seed(107)      # default init of the reference module draws from the GLOBAL RNG: seeded so that the fixture regenerates bit-for-bit
     m = R.UnpackLayerConv3d(32, 32, 3, d=4)
     randomize(m, gen)
     with torch.no_grad():
@@ -391,7 +408,7 @@ def case_slim(gen):
     g = grads_of(sum((d * dy).sum() for d, dy in zip(disps, dys)), list(net.parameters()))
     go = grads_of(sum((d * dy).sum() for d, dy in zip(disps_o, dys)), [sdo[n] for n in names])
     for n, a, b in zip(names, go, g):
-        close(a, b, 5e-4, 'packnetslim01.grad.' + n)
+        close(a, b, 5e-4, 'packnetslim01.grad.' + n, floor=grad_floor(g))
     net64 = RefPackNetSlim01(dropout=0.0, version='1A').double()
     net64.load_state_dict({k: v.double() for k, v in sd.items()})
     net64.train()
@@ -444,7 +461,7 @@ def case_slim(gen):
         close(lo, out['loss'][0].detach(), 1e-6, 'supervised.' + method)
         go = grads_of(lo, po)
         for a, b in zip(go, gr):
-            close(a, b, 1e-5, 'supervised.grad.' + method)
+            close(a, b, 1e-5, 'supervised.grad.' + method, floor=grad_floor([b]))
         sup[method] = dict(pred=[pred0, pred1], gt=gt, loss=out['loss'].detach(), dpred=gr)
     fx['supervised'] = sup
     # clip_loss > 0 (the constructor default of the reference's loss class is 0.5; its YAML default is 0.0)
@@ -469,10 +486,39 @@ def case_slim(gen):
     return fx
 
 
+def pin_san():
+    """PackNetSAN01's dense path (input_depth=None; MinkowskiEngine stubbed, oracle/_refstubs.py) IS PackNetSlim01 under the
+    prefixes encoder. / decoder.: same key set through tests/parity_cases.py:san_key and, with the same weights, the same
+    outputs.  This is what lets tests/golden/slim.pt (reference PackNetSlim01) anchor PackNetSAN01's dense path."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from parity_cases import san_key
+    from packnet_sfm.networks.depth.PackNetSAN01 import PackNetSAN01 as RefSAN
+    shapes = O.packnet01_param_shapes('1A', ni=32, n1=32, d=4)
+    sd = O.init_params(shapes, seed=2468, randomize_affine=True)
+    san = RefSAN(dropout=0.0, version='1A')
+    dense = {k for k in san.state_dict() if k.startswith(('encoder.', 'decoder.'))}
+    assert dense == {san_key(k) for k in sd}, 'PackNetSAN01 dense keys != PackNetSlim01 keys under encoder./decoder.'
+    missing, unexpected = san.load_state_dict({san_key(k): v for k, v in sd.items()}, strict=False)
+    assert not unexpected and set(missing) <= {'weight', 'bias'}, (missing, unexpected)
+    slim = RefPackNetSlim01(dropout=0.0, version='1A')
+    slim.load_state_dict(sd)
+    san.train(); slim.train()
+    rgb = torch.rand(1, 3, 32, 64, generator=torch.Generator().manual_seed(5))
+    a, b = san(rgb)['inv_depths'], slim(rgb)['inv_depths']
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), 'reference PackNetSAN01 (rgb only) differs from reference PackNetSlim01'
+    san.eval()
+    assert isinstance(san(rgb)['inv_depths'], list)
+    print('  PackNetSAN01 dense path == PackNetSlim01 (keys and outputs): OK')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     gen = torch.Generator().manual_seed(20260923)
     only = sys.argv[1:]
+    if only == ['san']:
+        pin_san()
+        return
     if only == ['slim']:      # added later: own generator, leaves the four original fixture files untouched
         fx = case_slim(torch.Generator().manual_seed(20260924))
         path = os.path.join(GOLD, 'slim.pt')
@@ -487,6 +533,7 @@ def main():
         print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
     fx = case_slim(torch.Generator().manual_seed(20260924))
     torch.save(fx, os.path.join(GOLD, 'slim.pt'))
+    pin_san()
     print('oracle pinned against /root/reference: OK')
 
 

@@ -93,6 +93,17 @@ int pnsfm_resample8(const uint8_t* in, uint8_t* out, const int* kk, const int* b
 int pnsfm_jitter_totensor(const uint8_t* img, const void* ops, unsigned long long* lsum_ws, float* out, float* out_orig /*nullable*/,
                           int N, int H, int W, void* stream);
 
+/* ---- Neural-Ray-Surface projection (softmax expectation over a 41x41 candidate patch) --------------------------------------
+ * replaces the core of GenericCamera.project, packnet_sfm/geometry/camera_generic.py:127-192 (patch coordinates with the window
+ * translated into the image, ray-surface gather, logits d.r / T, softmax, expectation of the candidate coordinates).
+ * dir, ray: [3][h][w] (unit directions of the points to project, ray surface, both at the projection resolution, h, w >= 41);
+ * coords: [h][w][2] = (expected row, expected column) in pixels; stat: [h][w][2] = (max logit, sum of exponentials) saved for
+ * backward.  Backward: gcoords [h][w][2] -> gdir [3][h][w] and gray [3][h][w] (either may be null); gather formulation, no atomics. */
+int pnsfm_nrs_project_forward(const float* dir, const float* ray, float* coords, float* stat, int h, int w, float temperature,
+                              void* stream);
+int pnsfm_nrs_project_backward(const float* dir, const float* ray, const float* coords, const float* stat, const float* gcoords,
+                               float* gdir /*nullable*/, float* gray /*nullable*/, int h, int w, float temperature, void* stream);
+
 /* ---- GroupNorm(G) + activation, optional residual add in front -----------------------------
  * replaces torch.nn.GroupNorm(16, C) + nn.ELU(inplace=True): layers01.py:31-32,36-37 and the
  * residual form `activ(normalize(x_out + shortcut))`: layers01.py:61-62,72.

@@ -486,6 +486,42 @@ def case_slim(gen):
     return fx
 
 
+def case_nrs(gen):
+    """GenericCamera.project (Neural Ray Surfaces, camera_generic.py:86-208) run by the reference itself on CPU (its hard-coded
+    `.cuda()` calls are made no-ops for the duration): grid and autograd gradients w.r.t. the points and the ray surface, for
+    two annealing stages of the softmax temperature.  The oracle here IS the reference function."""
+    from packnet_sfm.geometry.camera_generic import GenericCamera as RefGenericCamera
+    H, W = 96, 112
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    # a wide-angle-ish ray surface: pinhole rays bent by a radial term, plus a smooth learned-looking perturbation
+    x, y = (u - 0.5 * W) / (0.7 * W), (v - 0.5 * H) / (0.7 * W)
+    r2 = x * x + y * y
+    rays = torch.stack([x * (1 + 0.3 * r2), y * (1 + 0.3 * r2), torch.ones_like(x)], 0)
+    rays = rays + 0.01 * torch.nn.functional.interpolate(torch.randn(1, 3, 6, 7, generator=gen), size=(H, W), mode='bicubic', align_corners=True)[0]
+    rays = (rays / rays.norm(dim=0, keepdim=True)).unsqueeze(0)
+    depth = 5.0 + 20.0 * torch.nn.functional.interpolate(torch.rand(1, 1, 5, 6, generator=gen), size=(H, W), mode='bicubic', align_corners=True).clamp(0, 1)
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    fx = {}
+    try:
+        for name, progress in (('nrs_start', 0.0), ('nrs_late', 35.0)):
+            R = rays.clone().requires_grad_(True)
+            cam = RefGenericCamera(R)
+            # points seen from a slightly moved camera
+            X0 = (rays * depth).detach()
+            X = (X0 + torch.tensor([0.35, -0.1, 0.2]).view(1, 3, 1, 1)).requires_grad_(True)
+            grid = cam.project(X, progress, downsample=True, frame='c')
+            dy = torch.randn(grid.shape, generator=gen)
+            gX, gR = torch.autograd.grad((grid * dy).sum(), [X, R])
+            fx[name] = dict(progress=progress, rays=rays.clone(), X=X.detach().clone(), grid=grid.detach().clone(), dy=dy,
+                            gX=gX.clone(), gR=gR.clone())
+            print('  %s: grid range [%.3f, %.3f], |gX| max %.3e, |gR| max %.3e' % (name, float(grid.min()), float(grid.max()),
+                                                                                 float(gX.abs().max()), float(gR.abs().max())))
+    finally:
+        torch.Tensor.cuda = cuda
+    return fx
+
+
 def pin_san():
     """PackNetSAN01's dense path (input_depth=None; MinkowskiEngine stubbed, oracle/_refstubs.py) IS PackNetSlim01 under the
     prefixes encoder. / decoder.: same key set through tests/parity_cases.py:san_key and, with the same weights, the same
@@ -519,6 +555,11 @@ def main():
     if only == ['san']:
         pin_san()
         return
+    if only == ['nrs']:
+        fx = case_nrs(torch.Generator().manual_seed(20260925))
+        torch.save(fx, os.path.join(GOLD, 'nrs.pt'))
+        print('  wrote nrs.pt (%.1f KB)' % (os.path.getsize(os.path.join(GOLD, 'nrs.pt')) / 1024))
+        return
     if only == ['slim']:      # added later: own generator, leaves the four original fixture files untouched
         fx = case_slim(torch.Generator().manual_seed(20260924))
         path = os.path.join(GOLD, 'slim.pt')
@@ -534,6 +575,7 @@ def main():
     fx = case_slim(torch.Generator().manual_seed(20260924))
     torch.save(fx, os.path.join(GOLD, 'slim.pt'))
     pin_san()
+    torch.save(case_nrs(torch.Generator().manual_seed(20260925)), os.path.join(GOLD, 'nrs.pt'))
     print('oracle pinned against /root/reference: OK')
 
 

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) nrs_walk_kernel(const float* __restrict__
   const int hw = h * w;
   // window of the tile = union of its pixels' windows
   const int r_lo = nrs_clampc(i0, h) - NRS_SIDE, c_lo = nrs_clampc(j0, w) - NRS_SIDE;
-  const int r_hi = nrs_clampc(min(i0 + TS - 1, h - 1), h) + NRS_SIDE, c_hi = nrs_clampc(min(j0 + TS - 1, w - 1), w) + NRS_SIDE;
+  const int i1 = i0 + TS - 1 < h ? i0 + TS - 1 : h - 1, j1 = j0 + TS - 1 < w ? j0 + TS - 1 : w - 1;
+  const int r_hi = nrs_clampc(i1, h) + NRS_SIDE, c_hi = nrs_clampc(j1, w) + NRS_SIDE;
   const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
   for (int e = tid; e < nr * nc; e += 256) {
     const int r = e / nc, c = e - r * nc;

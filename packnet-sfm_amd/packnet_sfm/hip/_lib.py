@@ -65,6 +65,8 @@ SIGNATURES = {
     "pnsfm_adam_flat_step": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "pnsfm_resample8": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_jitter_totensor": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_nrs_project_forward": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "pnsfm_nrs_project_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "pnsfm_set_autotune": (_i, [_i]),
     "pnsfm_set_conv_variant": (_i, [_i]),
     "pnsfm_set_wgrad_variant": (_i, [_i]),

@@ -674,6 +674,31 @@ def view_synthesis(inv_depth, ref, K, refK, T, padding_mode='zeros'):
     return ViewSynthesisFn.apply(inv_depth, ref, K, refK, T, ops.PADDING_MODES[padding_mode])
 
 
+class NrsProjectFn(Function):
+    """(unit directions [3,h,w], ray surface [3,h,w]) -> expected candidate coordinates [h,w,2] (row, col): the softmax over the
+    41x41 patch of ray-surface dot products of GenericCamera.project, fused; differentiable w.r.t. both inputs."""
+
+    @staticmethod
+    def forward(ctx, direction, ray, temperature):
+        direction, ray = direction.contiguous(), ray.contiguous()
+        coords, stat = ops.nrs_project_forward(direction, ray, temperature)
+        ctx.save_for_backward(direction, ray, coords, stat)
+        ctx.temperature = temperature
+        return coords
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        direction, ray, coords, stat = ctx.saved_tensors
+        gdir, gray = ops.nrs_project_backward(direction, ray, coords, stat, g.contiguous(), ctx.temperature,
+                                              want_dir=ctx.needs_input_grad[0], want_ray=ctx.needs_input_grad[1])
+        return gdir, gray, None
+
+
+def nrs_project(direction, ray, temperature):
+    return NrsProjectFn.apply(direction, ray, temperature)
+
+
 REDUCE_MIN, REDUCE_MEAN = 0, 1
 
 

@@ -394,6 +394,28 @@ def supervised_loss_backward(pred, gt, ws, grad_out, method, sparse):
     return dpred
 
 
+# ------------------------------------------------------------------------------------------------ NRS
+def nrs_project_forward(direction, ray, temperature):
+    """direction, ray: [3,h,w] -> (coords [h,w,2] = expected (row, col), stat [h,w,2] for backward)."""
+    _chk(direction, ray); _f32(direction, ray)
+    _, h, w = direction.shape
+    coords = torch.empty((h, w, 2), dtype=torch.float32, device=ray.device)
+    stat = torch.empty((h, w, 2), dtype=torch.float32, device=ray.device)
+    _lib.check(_lib.get().pnsfm_nrs_project_forward(_ptr(direction), _ptr(ray), _ptr(coords), _ptr(stat), h, w, float(temperature),
+                                                    _stream(ray)), "nrs_project_forward")
+    return coords, stat
+
+
+def nrs_project_backward(direction, ray, coords, stat, gcoords, temperature, want_dir=True, want_ray=True):
+    _chk(direction, ray, coords, stat, gcoords); _f32(direction, ray, coords, stat, gcoords)
+    _, h, w = direction.shape
+    gdir = torch.empty_like(direction) if want_dir else None
+    gray = torch.empty_like(ray) if want_ray else None
+    _lib.check(_lib.get().pnsfm_nrs_project_backward(_ptr(direction), _ptr(ray), _ptr(coords), _ptr(stat), _ptr(gcoords), _ptr(gdir),
+                                                     _ptr(gray), h, w, float(temperature), _stream(ray)), "nrs_project_backward")
+    return gdir, gray
+
+
 # ------------------------------------------------------------------------------------- input pipeline
 def resample8(img, kk, bounds, out_size, axis):
     """One axis of PIL's 8-bit separable resample.  img: uint8 [N,H,W,C] (NHWC); kk int32 [out, ksize]; bounds int32 [out, 2]."""

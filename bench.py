@@ -163,8 +163,10 @@ def main():
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the whole step as a hipGraph (packnet_sfm/hip/graph.py); auto = on for 1 GPU, off for N>1 '
-                         '(the per-bucket RCCL all-reduce is launched from autograd hooks while backward runs)')
+                    help='replay the whole step as a hipGraph (packnet_sfm/hip/graph.py).  auto = off: measured on MI355X the replay is '
+                         '3-5 %% SLOWER than eager launches (84-85 vs 88-90 img/s; the step is GPU-bound, eager already hides '
+                         'launch latency behind kernels, and the graph serialises the weight-gradient side stream) -- kept as '
+                         'an option and parity-tested; never available for N>1 (RCCL all-reduces start from autograd hooks)')
     ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps here')
     args = ap.parse_args()
 
@@ -189,7 +191,7 @@ def main():
     batch = synthetic_batch(B, H, W, 1234 + rank, device)
     force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
     ddp = world > 1 or force_ddp
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and not ddp)
+    use_graph = args.graph == 'on'
     if use_graph and ddp:
         raise SystemExit('--graph on is for 1 GPU (collectives are launched from autograd hooks, outside any capture)')
     groups = [{'name': 'Depth', 'params': list(model.depth_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0},
@@ -318,6 +320,11 @@ def main():
                                         'scaling measurement' % (world, ndev))
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
+        try:        # RCCL prints a version banner through C stdio (block-buffered when stdout is a file): push it out FIRST
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(result), flush=True)
     if ddp:
         dist.barrier()

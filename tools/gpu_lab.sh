@@ -20,6 +20,10 @@ alltests)
   echo "== pytest -m gpu (all)"
   timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $O/pytest_all_$TAG.log 2>&1
   tail -15 $O/pytest_all_$TAG.log ;;
+bench_ddp1)
+  echo "== bench, 1 rank but the DDP path forced (reducer over the FlatAdam arenas, RCCL world of 1)"
+  PNSFM_FORCE_DDP=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-prof > $O/bench_ddp1_$TAG.log 2>&1
+  tail -1 $O/bench_ddp1_$TAG.log | cut -c1-700 ;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; tail -3 $O/smoke_$TAG.log ;;
 bench)

@@ -30,6 +30,7 @@ import torch.nn.functional as F  # noqa: E402
 # algorithmic FLOPs of one trained image at 192x640 (fwd + dgrad + wgrad of every conv; SURVEY.md 8d / BASELINE.md 2)
 GFLOP_PER_IMAGE_192x640 = 1232.0
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 LOSS_DEFAULTS = dict(  # configs/default_config.py:88-103 of the reference
     num_scales=4, progressive_scaling=0.0, flip_lr_prob=0.5, rotation_mode='euler', upsample_depth_maps=True,
@@ -279,10 +280,23 @@ def main():
                 # flops the conv kernels actually EXECUTE per step (the Conv3d*Conv2d collapse removes ~35 % of the
                 # reference's 1 232 GFLOP/image) -> utilisation of the matrix pipe over the whole step
                 exec_gflop_step = (fl0 + fl1) / 3.0 / 1e9
+                # Arithmetic of the forward / backward-data kernels.  'bx3': fp32 rebuilt on the bf16 matrix pipe (exact 3-way
+                # bf16 split of every operand, 6 of the 9 piece products, fp32 accumulate: csrc/conv2d_bx3.h) -- each
+                # algorithmic MAC costs 6 bf16 MACs, so the pipe's ceiling in ALGORITHMIC fp32 flops is 2500 / 6 TFLOP/s.
+                # 'f32': v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s.
+                bx3 = HF.get_conv_math() == 'bx3'
+                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if bx3 else FP32_MFMA_PEAK_TFLOPS
                 roofline = {
-                    'bound': 'mfma', 'kernel': 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)',
-                    'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                    'bound': 'mfma',
+                    'kernel': ('conv2d_bx3_kernel (fwd + dgrad implicit GEMM, fp32 from 6 bf16 MFMA products)' if bx3
+                               else 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)'),
+                    'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4),
+                    'peak_detail': ('algorithmic fp32 flops against the bf16 dense MFMA peak (2500 TFLOP/s) / 6 products per MAC; '
+                                    'executed bf16 rate = 6 x achieved = %.0f TFLOP/s; the 6-product instruction stream alone '
+                                    'sustains 1838 TFLOP/s bf16 = 306 fp32-equivalent on this part (tools/micro/bf16x3_check.hip)'
+                                    % (6 * ach)) if bx3 else 'v_mfma_f32_32x32x2_f32 dense peak',
+                    'vs_f32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     'measured_in': '3 eager steps right after the timed region (same kernels and shapes; events cannot '
                                    'bracket nodes of a replayed hipGraph)' if use_graph else '3 eager steps after the timed region',
                     # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
@@ -293,7 +307,8 @@ def main():
                                      'launches': int(n1), 'avg_launch_ms': round(ms1 / max(n1, 1), 4)},
                     'isolated': {       # same kernels, 2 steps with the weight-gradient side stream off
                         'achieved': round(ifl0 / (ims0 * 1e-3) / 1e12, 2) if ims0 > 0 else None,
-                        'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
+                        'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / peak, 4) if ims0 > 0 else None,
+                        'vs_f32_mfma_peak': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
                         'avg_launch_ms': round(ims0 / max(in0, 1), 4),
                         'wgrad_achieved': round(ifl1 / (ims1 * 1e-3) / 1e12, 2) if ims1 > 0 else None},
                     'whole_step_vs_mfma_peak': {

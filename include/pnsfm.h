@@ -65,13 +65,26 @@ int pnsfm_set_autotune(int on);
  * weight slabs double-buffered by LDS-DMA, one barrier per kernel row, up to 160 KB of LDS).  The autotuner times all
  * three; this switch exists for tests.  Clears the tuning cache. */
 int pnsfm_set_conv_variant(int lds_dma);
+/* Arithmetic of the forward / backward-data convolution kernels (stride 1 and 2, K-channels >= 16, k >= 3; other shapes
+ * always use the f32 instruction):
+ *   1 (default) fp32 rebuilt on the bf16 matrix pipe: each fp32 operand is split EXACTLY into three bf16 pieces
+ *     (8+8+8 significand bits) and the product is summed from 6 of the 9 piece products with fp32 accumulation
+ *     (v_mfma_f32_32x32x16_bf16; dropped terms <= 3 * 2^-24 |a||b|) -- measured error against fp64 is BELOW that of the f32
+ *     MFMA chain (tools/micro/bf16x3_check.hip; tests/test_gpu_parity.py::test_conv2d_bx3_error_vs_fp64);
+ *   0 v_mfma_f32_32x32x2_f32 everywhere (env PNSFM_CONV_MATH=f32).
+ * Variants 3..5 of pnsfm_set_conv_variant select the un-tuned LDS plan of the split kernels (3: one patch buffer, 4: two,
+ * 5: two + a whole kernel row of weights per stage).  The packed-weight layout follows from (mode, shape):
+ * pnsfm_conv2d_packed_elems_* already return the larger of the two sizes, but weights packed under one mode must be packed
+ * again after a switch.  Returns the previous mode.  The weight-gradient kernels are f32-MFMA in both modes. */
+int pnsfm_set_conv_math(int mode);
+int pnsfm_get_conv_math(void);
 /* Un-tuned default of the weight-gradient kernel: 0 = generic ((ci, tap) columns, offset table; conv2d.hip), 1 = tap-major
  * (dY fragments kept in registers across the taps, immediate LDS offsets, LDS-DMA double buffering; conv2d_wgrad2.hip) for
  * the shapes it supports (stride 1, k in {1,3,5}, W % 8 == 0, >= 16 channels); the autotuner times both.  For tests. */
 int pnsfm_set_wgrad_variant(int tap_major);
 /* Programmatic entry of the tuning database (what a PNSFM_TUNE_DB line does): key7 = {kind, B, Cin, Cout, H, W, ks} with
  * kind = 0 forward / 1 backward-data / 2 backward-weight, + 10 * stride; for kind 2 the key holds H*W in place of H and the
- * tiling width in place of W (32 for a 1x1 convolution).  forward / backward-data: v0 = NT | variant << 4 | narrow-M << 8,
+ * tiling width in place of W (32 for a 1x1 convolution).  forward / backward-data (+ 100 on `kind` for the split-bf16 arithmetic): v0 = NT | variant << 4 | narrow-M << 8,
  * v1 = K-split; backward-weight: v0 = pixel split, v1 = kernel (0 generic, 1 tap-major).  Used by the determinism sweep
  * (tools/conv_config_sweep.py), which checks EVERY configuration the autotuner may pick against the oracle's convolution. */
 int pnsfm_tune_set(const int* key7, int v0, int v1);

@@ -34,6 +34,22 @@ int conv_pack_MP(int Mc) { return round_up(Mc, 32 * conv_pick_MT(Mc)); }
 // no validity test for the ragged last chunk
 int conv_pack_KP(int Kc) { return round_up(Kc, 16); }
 
+// ---- arithmetic of the forward / backward-data kernels ------------------------------------------------------------------
+// 0: v_mfma_f32_32x32x2_f32 everywhere; 1 (default): fp32 rebuilt from exact bf16 splits on the bf16 matrix pipe
+// (conv2d_bx3.h) for the shapes it supports.  The PACKED WEIGHT LAYOUT follows from (mode, shape), so weights packed under
+// one mode must be re-packed after a switch (the Python side bumps its weight epoch in hip.functional.set_conv_math).
+static int g_conv_math = -1;
+static int conv_math() {
+  if (g_conv_math < 0) {
+    const char* e = getenv("PNSFM_CONV_MATH");
+    g_conv_math = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+  }
+  return g_conv_math;
+}
+// K-channels >= 16 (one bf16 MFMA k-step is 16 channels) and a real stencil (1x1 layers are bandwidth-bound and tiny)
+bool conv_bx3_supported(int Kc, int ks) { return Kc >= 16 && ks >= 3; }
+static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_supported(Kc, ks); }
+
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
 static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
 static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
@@ -68,6 +84,38 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.PW = (W - 1) * S + ks;
   }
   g.G = 0;
+  g.PB = 1;
+  if (DMA >= 3) {
+    // split-bf16 variants (conv2d_bx3.h): 16-channel chunks; LDS = PB patch buffers of 3 planes + 2 weight stages of G taps.
+    //   3: one patch buffer, 4: two patch buffers -- G the largest of {all taps (<= 9), one kernel row, 4, 3, 2, 1} that lets TWO
+    //   workgroups share a CU;  5: two patch buffers and a whole kernel row per stage, one workgroup per CU if need be
+    if (!conv_bx3_supported(Cin, ks)) return false;
+    g.CI = 16;
+    g.KP = round_up(Cin, 16);
+    g.nchunks = g.KP / 16;
+    g.PB = DMA == 3 ? 1 : 2;
+    const int KK = ks * ks;
+    const size_t plane = (size_t)round_up(g.PH * g.PW * 32, 1024);
+    const size_t patch = (size_t)g.PB * 3 * plane;
+    auto smem_bx3 = [&](int G) -> size_t { return patch + 2 * (size_t)G * g.MT * 3072; };
+    const int cand[6] = {KK <= 9 ? KK : ks, ks, 4, 3, 2, 1};
+    g.G = 0;
+    if (DMA == 5) {
+      if (smem_bx3(cand[0]) <= kMaxSmemPipe) g.G = cand[0];
+    } else {
+      for (int i = 0; i < 6 && !g.G; ++i)
+        if (cand[i] <= KK && smem_bx3(cand[i]) <= kPipeTwoBlocks) g.G = cand[i];
+    }
+    for (int i = 0; i < 6 && !g.G; ++i)
+      if (cand[i] <= KK && smem_bx3(cand[i]) <= kMaxSmemPipe) g.G = cand[i];
+    if (!g.G) return false;
+    g.smem_bytes = smem_bx3(g.G);
+    if (want_split < 1) want_split = 1;
+    if (want_split > g.nchunks) want_split = g.nchunks;
+    const int cps3 = ceil_div(g.nchunks, want_split);
+    g.splitK = ceil_div(g.nchunks, cps3);
+    return true;
+  }
   if (DMA == 2) {
     // pipelined variant: LDS = 2 patch buffers + 2 weight-slab buffers of one kernel row (G = ks taps) each.  The K-chunk
     // is the largest of {32 (1x1 only), 16, 8} channels that still lets two workgroups share a CU's 160 KB.
@@ -107,11 +155,29 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
 // grid cannot give every CU ~6 blocks and each split keeps >= 2 channel chunks.  The runtime autotuner below
 // (the analogue of the reference's `cudnn.benchmark = True`, trainers/horovod_trainer.py:19) refines this per shape.
 static int g_default_dma = 0;   // un-tuned default variant (see pnsfm_set_conv_variant)
+static int g_default_bx3 = 3;   // ... of the split-bf16 kernels (3..5)
 
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S) {
   ConvGeom g;
   int NT = 2;
   int DA = g_default_dma;
+  if (conv_use_bx3(Cin, ks)) {
+    // un-tuned split-bf16 default: one patch buffer, two workgroups per CU; K split only when the tiles cannot fill the chip
+    const int D3 = g_default_bx3;
+    if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, D3, S) || (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 512) NT = 1;
+    if (conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, D3, S)) {
+      const long blocks3 = (long)B * g.tiles_per_img * (g.MP / (32 * g.MT));
+      int split3 = 1;
+      if (blocks3 < 400 && g.nchunks >= 4) {
+        split3 = (int)((512 + blocks3 - 1) / blocks3);
+        if (split3 > g.nchunks / 2) split3 = g.nchunks / 2;
+        if (split3 < 1) split3 = 1;
+      }
+      conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, split3, g, D3, S);
+      return g;
+    }
+    NT = 2;
+  }
   if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, 2, 1, g, DA, S) ||
       (long)B * g.tiles_per_img * (g.MP / (32 * g.MT)) < 1024) NT = 1;
   conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, 1, g, DA, S);
@@ -210,7 +276,8 @@ struct ConvArgs {
   int S, Hi, Wi;                // stride (1 | 2) and INPUT size (Hi = H, Wi = W when S == 1)
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
   int pstride;        // DMA variants: floats between the two patch buffers
-  int G;              // pipelined variant: taps per weight stage
+  int G;              // pipelined / bx3 variants: taps per weight stage
+  int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
   float invPW, invPS;
 #ifdef PNSFM_PIPE_TRACE
   long long* trace;   // debug build only (tools/pipe_trace.py): per wave {barrier wait, stage compute, prologue, epilogue} cycles
@@ -274,6 +341,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
       }
   }
 }
+
+#include "conv2d_bx3.h"
 
 // DMA = 0: the halo patch of a channel chunk is staged through registers (8 loads in flight per thread) between two
 //          barriers;
@@ -393,7 +462,8 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     const size_t wstep = wok ? tap_stride : 0;
     float4 wreg = *reinterpret_cast<const float4*>(wsrc);
     if (wact) *reinterpret_cast<float4*>(wbuf + wrow * BM + wc4 * 4) = wreg;
-    __syncthreads();   // patch (DMA: drained by the barrier's vmcnt(0)) and slab 0 visible; previous chunk fully consumed
+    if constexpr (DMA) pnsfm_dma_wait();
+    __syncthreads();   // patch (DMA: landed, see pnsfm_dma_wait) and slab 0 visible; previous chunk fully consumed
 
     const bool dma_next = DMA && (c + 1 < c_end);
     float* dma_dst = smem + (dma_cur ^ 1) * a.pstride;
@@ -592,7 +662,8 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
 #ifdef PNSFM_PIPE_TRACE
     const long long tr0 = __builtin_readcyclecounter();
 #endif
-    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and meets the others: stage s's operands are in LDS, and
+    pnsfm_dma_wait();
+    __syncthreads();   // this wave's DMA has landed and so has the others': stage s's operands are in LDS, and
                        // everyone is done with stage s-1 (its slab buffer, and at a chunk boundary its patch buffer, are free)
 #ifdef PNSFM_PIPE_TRACE
     const long long tr1 = __builtin_readcyclecounter();
@@ -716,6 +787,8 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.invPS = 1.0f / (float)(g.PH * g.PW);
   a.pstride = round_up(g.CI * g.PH * g.PW, 64);
   a.G = g.G;
+  a.PB = g.PB;
+  if (g.DMA >= 3) a.pstride = round_up(g.PH * g.PW * 32, 1024);   // bytes of one bf16 piece plane of the patch
 #ifdef PNSFM_PIPE_TRACE
   a.trace = g_trace_buf;
   a.trace_flags = g_trace_flags;
@@ -732,7 +805,29 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<1, 2, DMAv>), grid, dim3(256), g.smem_bytes, stream, a); \
     else PNSFM_LAUNCH((conv2d_mfma_kernel<1, 1, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);                 \
   } while (0)
-  if (g.DMA == 2) {
+  if (g.DMA >= 3) {
+#ifndef PNSFM_EMU
+#define PNSFM_BX3_ATTR(MTv, NTv)                                                                                   \
+    do {                                                                                                           \
+      static bool done = false;                                                                                    \
+      if (!done && g.smem_bytes > 64 * 1024) {                                                                     \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_bx3_kernel<MTv, NTv>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSmemPipe) != hipSuccess) {    \
+          set_error("%s: cannot raise the dynamic LDS limit", what);                                               \
+          return -1;                                                                                               \
+        }                                                                                                          \
+        done = true;                                                                                               \
+      }                                                                                                            \
+    } while (0)
+#else
+#define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
+#endif
+    if (g.MT == 2 && g.NT == 2) { PNSFM_BX3_ATTR(2, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 2 && g.NT == 1) { PNSFM_BX3_ATTR(2, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 1 && g.NT == 2) { PNSFM_BX3_ATTR(1, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else { PNSFM_BX3_ATTR(1, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
+#undef PNSFM_BX3_ATTR
+  } else if (g.DMA == 2) {
 #ifndef PNSFM_EMU
     // more than 64 KB of dynamic LDS needs an explicit opt-in per kernel (once)
 #define PNSFM_PIPE_ATTR(MTv, NTv)                                                                                  \
@@ -786,22 +881,24 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
   if (S != 1 && S != 2) { set_error("%s: unsupported stride %d", what, S); return -1; }
   ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks, S);
-  if (g.smem_bytes > (g.DMA == 2 ? kMaxSmemPipe : kMaxSmem)) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
-#ifndef PNSFM_EMU
-  if (autotune_enabled()) {
-    const std::array<int, 7> key = {kind_tag + 10 * S, B, Cin, Cout, H, W, ks};
+  if (g.smem_bytes > (g.DMA >= 2 ? kMaxSmemPipe : kMaxSmem)) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
+  {
+    // tuned / pinned configuration of this shape: the autotuner's result, a PNSFM_TUNE_DB line or pnsfm_tune_set (tests pin
+    // configurations the un-tuned heuristics would not pick; that works in every build, the timing search needs a GPU)
+    const bool bx3 = conv_use_bx3(Cin, ks);
+    const std::array<int, 7> key = {kind_tag + 10 * S + (bx3 ? 100 : 0), B, Cin, Cout, H, W, ks};
+    const bool tune = autotune_enabled();        // (first call: reads the environment and loads PNSFM_TUNE_DB under the lock)
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
-    if (it == g_tuned.end() && stream_capturing(stream)) {
-      // a shape first seen inside a hipGraph capture cannot be timed (timing synchronises): un-tuned default, not cached
-    } else {
-    if (it == g_tuned.end()) {
+#ifndef PNSFM_EMU
+    // (a shape first seen inside a hipGraph capture cannot be timed -- timing synchronises: un-tuned default, not cached)
+    if (it == g_tuned.end() && tune && !stream_capturing(stream)) {
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
       for (int cfg = 0; cfg < 6 * nMT; ++cfg) {
-        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % 3, fMT = cfg / 6;
+        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % 3 + (bx3 ? 3 : 0), fMT = cfg / 6;
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -818,10 +915,13 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       it = g_tuned.emplace(key, best).first;
       tune_db_append(key, best);
     }
-    conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], g, (it->second[0] >> 4) & 3, S, (it->second[0] >> 8) & 1);
+#endif
+    if (it != g_tuned.end()) {
+      ConvGeom t;
+      const int DA = (it->second[0] >> 4) & 7;
+      if ((DA >= 3) == bx3 && conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], t, DA, S, (it->second[0] >> 8) & 1)) g = t;
     }
   }
-#endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
   prof_begin(0, flops, stream, meta);
@@ -1115,11 +1215,15 @@ using namespace pnsfm;
 
 extern "C" {
 
+// floats to allocate for a packed weight.  A shape the split-bf16 kernels take needs 6 bytes per element (three bf16 pieces)
+// instead of 4; the size does not depend on the current arithmetic mode, so a mode switch re-packs in place.
 size_t pnsfm_conv2d_packed_elems_fwd(int Cin, int Cout, int ks) {
-  return (size_t)ks * ks * conv_pack_KP(Cin) * conv_pack_MP(Cout);
+  const size_t n = (size_t)ks * ks * conv_pack_KP(Cin) * conv_pack_MP(Cout);
+  return conv_bx3_supported(Cin, ks) ? n + n / 2 : n;
 }
 size_t pnsfm_conv2d_packed_elems_bwd(int Cin, int Cout, int ks) {
-  return (size_t)ks * ks * conv_pack_KP(Cout) * conv_pack_MP(Cin);
+  const size_t n = (size_t)ks * ks * conv_pack_KP(Cout) * conv_pack_MP(Cin);
+  return conv_bx3_supported(Cout, ks) ? n + n / 2 : n;
 }
 
 int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int Cin, int Cout, int ks, void* stream) {
@@ -1128,8 +1232,22 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
   const int KK = ks * ks;
   if (!wp_fwd && !wp_bwd) return 0;
   const int KPf = conv_pack_KP(Cin), MPf = conv_pack_MP(Cout), KPb = conv_pack_KP(Cout), MPb = conv_pack_MP(Cin);
-  const int nf = wp_fwd ? KPf * ceil_div(MPf, 64) : 0, nb = wp_bwd ? KPb * ceil_div(MPb, 64) : 0;
-  PNSFM_LAUNCH(pack_weights_kernel, dim3(nf + nb), dim3(256), 0, s, w, wp_fwd, wp_bwd, Cin, Cout, KK, KPf, MPf, KPb, MPb, nf);
+  // the layout of each direction follows the kernel that will read it (launch_conv takes the same decision)
+  const bool bxf = wp_fwd && conv_use_bx3(Cin, ks), bxb = wp_bwd && conv_use_bx3(Cout, ks);
+  float* const f32f = bxf ? nullptr : wp_fwd;
+  float* const f32b = bxb ? nullptr : wp_bwd;
+  if (f32f || f32b) {
+    const int nf = f32f ? KPf * ceil_div(MPf, 64) : 0, nb = f32b ? KPb * ceil_div(MPb, 64) : 0;
+    PNSFM_LAUNCH(pack_weights_kernel, dim3(nf + nb), dim3(256), 0, s, w, f32f, f32b, Cin, Cout, KK, KPf, MPf, KPb, MPb, nf);
+    int e = check_launch("pack_weights");
+    if (e) return e;
+  }
+  if (bxf || bxb) {
+    const int nchF = KPf / 16, nchB = KPb / 16;
+    const int nf = bxf ? (MPf / 32) * nchF : 0, nb = bxb ? (MPb / 32) * nchB : 0;
+    PNSFM_LAUNCH(pack_bx3_kernel, dim3(nf + nb), dim3(256), 0, s, w, reinterpret_cast<unsigned char*>(bxf ? wp_fwd : nullptr),
+                 reinterpret_cast<unsigned char*>(bxb ? wp_bwd : nullptr), Cin, Cout, KK, nchF, nchB, nf);
+  }
   return check_launch("pack_weights");
 }
 
@@ -1345,10 +1463,20 @@ int pnsfm_set_wgrad_variant(int tap_major) {
 }
 
 int pnsfm_set_conv_variant(int lds_dma) {
-  g_default_dma = lds_dma < 0 ? 0 : (lds_dma > 2 ? 2 : lds_dma);
+  if (lds_dma >= 3) g_default_bx3 = lds_dma > 5 ? 5 : lds_dma;     // 3..5: un-tuned default of the split-bf16 kernels
+  else g_default_dma = lds_dma < 0 ? 0 : lds_dma;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned.clear();
   return 0;
 }
+
+// arithmetic of the forward / backward-data kernels: 0 = f32 MFMA, 1 = split-bf16 (default); returns the previous mode.
+// Packed weights must be re-packed after a switch.
+int pnsfm_set_conv_math(int mode) {
+  const int prev = conv_math();
+  g_conv_math = mode ? 1 : 0;
+  return prev;
+}
+int pnsfm_get_conv_math(void) { return conv_math(); }
 
 }  // extern "C"

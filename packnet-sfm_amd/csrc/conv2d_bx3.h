@@ -1,0 +1,332 @@
+// conv2d_bx3.h -- fp32 convolution on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces and
+// the product is rebuilt from 6 of the 9 piece products.  Included by conv2d.hip (shares ConvArgs / the epilogue / the tuner).
+//
+// Why: v_mfma_f32_32x32x2_f32 caps the chip at 157 TFLOP/s; v_mfma_f32_32x32x16_bf16 does 16x the MACs per cycle.  With
+//   a = a_h + a_m + a_l   (a_h = bf16(a), a_m = bf16(a - a_h), a_l = a - a_h - a_m, round to nearest: 8 + 8 + 8 significand
+//   bits, all three exactly representable in bf16, the sum exact; |a_m| <= 2^-9 |a|, |a_l| <= 2^-18 |a|)
+//   a*b = a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m) + O(2^-26 |a||b|)
+// six bf16 MFMAs (fp32 accumulate in the matrix pipe) deliver the product to ~2^-26 relative -- below the rounding of a
+// single fp32 FMA -- at 16/6 = 2.7x the MAC rate of the f32 instruction.  Measured on MI355X
+// (tools/micro/bf16x3_check.hip, K = 4096 dot products against fp64): max error / sum|a||b| = 9.8e-8 for the 6-product
+// form vs 1.5e-7 for v_mfma_f32_32x32x2_f32 itself (whose K-long fmaf chain rounds 16x more often), 3.9e-4 for plain bf16;
+// sustained 6-product rate 293-319 TFLOP/s fp32-equivalent.  This is NOT a reduced-precision mode: parity tests hold it to
+// the tolerance of the f32 kernels (tests/test_gpu_parity.py::test_conv2d_bx3_*).
+//
+// Implicit-GEMM structure (same tiles as conv2d_mfma_kernel: block = (32*MT output channels) x (4 waves * NT * 32 pixels)):
+//   * K is walked in chunks of 16 input channels = ONE bf16 MFMA k-step per tap; the chunk's halo patch lives in LDS as
+//     three bf16 planes [pixel][16 channels] (32 B per pixel and plane), so the B operand of a lane (pixel n = l&31,
+//     channels 8*(l>>5) .. +7) is ONE ds_read_b128 per plane, conflict-free (consecutive pixels = consecutive 32 B);
+//     the fp32 NCHW input is read through a buffer descriptor (zero padding / ragged channels = hardware range check),
+//     split in registers (4 VALU ops per element) and written with ds_write_b128; the NEXT chunk's loads are issued before
+//     the last stage of the current chunk so their latency hides behind its MFMAs;
+//   * weights are pre-split at pack time (pack_bx3_kernel) into the exact LDS image of the A operand:
+//       [32-row m-block][16-channel chunk][tap][piece h,m,l][k-half][32 rows][8 bf16] = 3072 B per (m-block, chunk, tap)
+//     so a block's whole weight stream is linear in memory and arrives by 16-byte LDS-DMA (buffer_load_dwordx4 ... lds),
+//     double-buffered in stages of G taps: one barrier per G taps;
+//   * per tap and wave: 3*(MT+NT) ds_read_b128 feed 6*MT*NT MFMAs (MT = NT = 2: 12 reads, 24 MFMAs = 768 matrix cycles),
+//     fragments of tap j+1 are read before the MFMAs of tap j are issued.
+// LDS per block = PB*3*PS*32 B (patch) + 2*G*MT*3072 B (weights); the host picks G (and PB) so that two blocks share a CU
+// where possible (the second block's math covers this block's staging).
+#pragma once
+
+#define PNSFM_BX3_SLAB 3072      // bytes per (32-row m-block, 16-channel chunk, tap)
+#define PNSFM_BX3_MAXIT 4        // patch items (pixel, 8-channel half) a thread prefetches in registers (PS <= 512 pixels); larger patches are staged in rounds
+
+// 8 consecutive-k fp32 values -> the three 16-byte operand pieces.  Exact 3-way split with round-to-nearest pieces:
+//   h = bf16(v), m = bf16(v - h), l = v - h - m   (v - h and v - h - m are exact in fp32; l has <= 8 significant bits, so
+//   the last conversion is exact too: v == h + m + l).  |m| <= 2^-9 |v|, |l| <= 2^-18 |v|, signs mixed.
+// 11 VALU instructions per PAIR of values: 3 v_cvt_pk_bf16_f32, 4 unpacks (shift / mask), 4 subtractions.
+__device__ __forceinline__ void bx3_split8(const float (&v)[8], pnsfm_u32x4& H, pnsfm_u32x4& M, pnsfm_u32x4& L) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const unsigned h = pnsfm_cvt_pk_bf16(v[i], v[i + 1]);
+    const float r0 = v[i] - pnsfm_u2f(h << 16), r1 = v[i + 1] - pnsfm_u2f(h & 0xffff0000u);
+    const unsigned m = pnsfm_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - pnsfm_u2f(m << 16), s1 = r1 - pnsfm_u2f(m & 0xffff0000u);
+    H[i >> 1] = h;
+    M[i >> 1] = m;
+    L[i >> 1] = pnsfm_cvt_pk_bf16(s0, s1);
+  }
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
+  PNSFM_DYN_SMEM(unsigned char, smem);
+  constexpr int BM = 32 * MT, MAXIT = (MT * NT == 4) ? PNSFM_BX3_MAXIT - 1 : PNSFM_BX3_MAXIT;   // (2,2): acc + fragments leave fewer registers
+  const int PS = a.PH * a.PW;
+  const int planeB = a.pstride;                  // bytes of one piece plane of the patch
+  const int patchB = 3 * planeB;
+  const int G = a.G;
+  const int stageB = G * MT * PNSFM_BX3_SLAB;
+  unsigned char* const wbuf0 = smem + a.PB * patchB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
+  const int P = a.KS >> 1, KK = a.KS * a.KS;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = Hi * Wi;
+
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int t = blockIdx.x - b * a.tiles_per_img;
+  const int co0 = blockIdx.y * BM;
+  const int c_begin = blockIdx.z * a.chunks_per_split;
+  int c_end = c_begin + a.chunks_per_split;
+  if (c_end > a.nchunks) c_end = a.nchunks;
+
+  // ---- pixel-tile geometry (as conv2d_mfma_kernel)
+  int py0, px0;
+  int boff[NT], oy[NT], ox[NT];
+  bool pvalid[NT];
+  if (a.mode == 0) {
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int y0 = ty * 4 * NT, x0 = tx * 32;
+    py0 = y0 * S - P;
+    px0 = x0 * S - P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = wave * NT + nt;
+      oy[nt] = y0 + row;
+      ox[nt] = x0 + l32;
+      pvalid[nt] = oy[nt] < H;
+      boff[nt] = (row * a.PW + l32) * S;
+    }
+  } else {
+    const int n0 = t * 128 * NT;
+    const int r0 = n0 / W;
+    py0 = r0 * S - P;
+    px0 = -P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wave * NT + nt) * 32 + l32;
+      pvalid[nt] = n < HW;
+      const int yy = pvalid[nt] ? n / W : r0;
+      oy[nt] = yy;
+      ox[nt] = pvalid[nt] ? n - yy * W : 0;
+      boff[nt] = ((yy - r0) * a.PW + ox[nt]) * S;
+    }
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // ---- patch staging.  Item e = (pixel e>>1 of the patch, channel half e&1); its three 16-byte pieces go to byte e*16 of
+  // each plane.  A thread's items sit at the same pixel for every chunk: the byte offset inside a channel image is computed
+  // once; out-of-image pixels carry an out-of-range offset (the buffer load returns 0 for them, as for channels >= Cin).
+  const float* xb = a.x + (size_t)b * a.Cin * HWi;
+  const int nitems = 2 * PS;
+  const int nit = (nitems + 255) >> 8;
+  const bool prefetch = nit <= MAXIT;
+  auto item_off = [&](int e) -> unsigned {
+    const int pix = e >> 1;
+    const int r = pix / a.PW, cc = pix - r * a.PW;
+    const int yy = py0 + r, xx = px0 + cc;
+    const bool ok = e < nitems && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+    return ok ? (unsigned)(((e & 1) * 8 * HWi + yy * Wi + xx) * 4) : PNSFM_DMA_INVALID;
+  };
+  unsigned gv[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) gv[it] = item_off(it * 256 + tid);
+  float raw[MAXIT][8];
+  auto chunk_buf = [&](int c) -> pnsfm_buf {       // descriptor over channels [16c, Cin) of this image
+    const int ci0 = c * 16;
+    const long rem = (long)(a.Cin - ci0) * HWi * 4;
+    return pnsfm_make_buf(xb + (size_t)ci0 * HWi, (unsigned)(rem > 0 ? rem : 0));
+  };
+  auto load_items = [&](int c) {
+    const pnsfm_buf buf = chunk_buf(c);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[it][u] = pnsfm_buf_load(buf, gv[it] + (unsigned)(u * HWi * 4), 0);
+      }
+  };
+  auto write_items = [&](unsigned char* patch) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < nit) {
+        const int e = it * 256 + tid;
+        pnsfm_u32x4 Hh, Mm, Ll;
+        bx3_split8(raw[it], Hh, Mm, Ll);
+        if (e < nitems) {
+          *reinterpret_cast<pnsfm_u32x4*>(patch + e * 16) = Hh;
+          *reinterpret_cast<pnsfm_u32x4*>(patch + planeB + e * 16) = Mm;
+          *reinterpret_cast<pnsfm_u32x4*>(patch + 2 * planeB + e * 16) = Ll;
+        }
+      }
+  };
+  // patches too large for the register prefetch (stride-2 layers, 7x7 with NT = 2): staged in rounds at the chunk boundary
+  auto stage_sync = [&](int c, unsigned char* patch) {
+    const pnsfm_buf buf = chunk_buf(c);
+    for (int e0 = tid; e0 < nitems; e0 += 256) {
+      const unsigned off = item_off(e0);
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pnsfm_buf_load(buf, off + (unsigned)(u * HWi * 4), 0);
+      pnsfm_u32x4 Hh, Mm, Ll;
+      bx3_split8(v, Hh, Mm, Ll);
+      *reinterpret_cast<pnsfm_u32x4*>(patch + e0 * 16) = Hh;
+      *reinterpret_cast<pnsfm_u32x4*>(patch + planeB + e0 * 16) = Mm;
+      *reinterpret_cast<pnsfm_u32x4*>(patch + 2 * planeB + e0 * 16) = Ll;
+    }
+  };
+
+  // ---- weight stream: stage = G taps of one chunk, MT slabs per tap; one DMA instruction moves 1 KB (one piece of one slab)
+  const pnsfm_dma_buf wdesc = pnsfm_make_dma_buf(a.wp, (long)(a.MP / 32) * a.nchunks * KK * PNSFM_BX3_SLAB);
+  const int mb0 = blockIdx.y * MT;
+  const int nwi = G * MT * 3;                    // wave-instructions per stage
+  auto issue_weights = [&](int c, int tap0, unsigned char* dst) {
+    for (int wi = wave; wi < nwi; wi += 4) {
+      const int slab = wi / 3, s = wi - slab * 3;
+      const int tl = slab / MT, mt = slab - tl * MT;
+      if (tap0 + tl < KK) {
+        const unsigned src = (unsigned)((((mb0 + mt) * a.nchunks + c) * KK + tap0 + tl) * PNSFM_BX3_SLAB + s * 1024) + lane * 16;
+        pnsfm_dma16(wdesc, src, reinterpret_cast<float*>(dst + slab * PNSFM_BX3_SLAB + s * 1024));
+      }
+    }
+  };
+
+  // per-lane operand addresses
+  unsigned baddr[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) baddr[nt] = (unsigned)boff[nt] * 32u + half * 16u;
+  const unsigned aaddr = half * 512u + l32 * 16u;
+
+  struct Frag { pnsfm_u32x4 A[MT][3], B[NT][3]; };
+  auto load_frag = [&](Frag& f, const unsigned char* wst, int tl, const unsigned char* patch, int tapoffB) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        f.A[mt][s] = *reinterpret_cast<const pnsfm_u32x4*>(wst + (tl * MT + mt) * PNSFM_BX3_SLAB + s * 1024 + aaddr);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        f.B[nt][s] = *reinterpret_cast<const pnsfm_u32x4*>(patch + s * planeB + baddr[nt] + tapoffB);
+  };
+  auto mma = [&](const Frag& f) {
+    // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); tiles interleaved so consecutive MFMAs are independent
+#define PNSFM_BX3_P(sa, sb)                                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                             \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+        acc[mt][nt] = pnsfm_mfma_bf16(f.A[mt][sa], f.B[nt][sb], acc[mt][nt])
+    PNSFM_BX3_P(2, 0); PNSFM_BX3_P(0, 2); PNSFM_BX3_P(1, 1); PNSFM_BX3_P(1, 0); PNSFM_BX3_P(0, 1); PNSFM_BX3_P(0, 0);
+#undef PNSFM_BX3_P
+  };
+
+  // ---- prologue: first chunk's patch and first stage's weights
+  const int SG = (KK + G - 1) / G;               // stages per chunk
+  issue_weights(c_begin, 0, wbuf0);
+  if (prefetch) { load_items(c_begin); write_items(smem); }
+  else stage_sync(c_begin, smem);
+
+  int pcur = 0, stage = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    unsigned char* const patch = smem + pcur * patchB;
+    const bool more = c + 1 < c_end;
+    for (int sg = 0; sg < SG; ++sg, ++stage) {
+      const int tap0 = sg * G;
+      const int gcount = (KK - tap0 < G) ? KK - tap0 : G;
+      const bool last = sg + 1 == SG;
+      pnsfm_dma_wait();    // this wave's weight DMA for the stage has landed ...
+      __syncthreads();     // ... and so has everyone's; the patch is visible, the previous stage is consumed
+      unsigned char* const wst = wbuf0 + (stage & 1) * stageB;
+      unsigned char* const wnext = wbuf0 + ((stage & 1) ^ 1) * stageB;
+      if (!last) issue_weights(c, tap0 + G, wnext);
+      else if (more) issue_weights(c + 1, 0, wnext);
+      if (last && more && prefetch) load_items(c + 1);
+
+      int ky = tap0 / a.KS, kx = tap0 - ky * a.KS;
+      auto tapoff = [&]() -> int {
+        const int o = (ky * a.PW + kx) * 32;
+        if (++kx == a.KS) { kx = 0; ++ky; }
+        return o;
+      };
+      Frag f0, f1;
+      load_frag(f0, wst, 0, patch, tapoff());
+      for (int j = 0; j < gcount; j += 2) {
+        if (j + 1 < gcount) load_frag(f1, wst, j + 1, patch, tapoff());
+        mma(f0);
+        if (j + 1 < gcount) {
+          if (j + 2 < gcount) load_frag(f0, wst, j + 2, patch, tapoff());
+          mma(f1);
+        }
+      }
+
+      if (last && more) {
+        if (a.PB == 2) {
+          // the other patch buffer was last read two chunks ago: write the next chunk's patch while the other waves finish
+          if (prefetch) write_items(smem + (pcur ^ 1) * patchB);
+          else stage_sync(c + 1, smem + (pcur ^ 1) * patchB);
+        } else {
+          __syncthreads();   // every wave is done with this chunk's patch
+          if (prefetch) write_items(patch);
+          else stage_sync(c + 1, patch);
+        }
+      }
+    }
+    if (a.PB == 2) pcur ^= 1;
+  }
+
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+}
+
+// ---- weight packer for the bx3 kernels: fp32 [Cout][Cin][k][k] -> the split LDS images described above.
+//   forward : M = Cout, K = Cin :  A[m][k][tap] = w[m][k][tap]
+//   backward: M = Cin,  K = Cout:  A[m][k][tap] = w[k][m][KK-1-tap]       (taps flipped: dX = conv(dY, rot180(W)^T))
+// One block per (32-row m-block, 16-channel chunk); taps go through LDS in segments of 8 so that global reads stay runs of
+// (channel, tap) and every output tap is written as one contiguous 3072-byte slab.
+__global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
+                                                       unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int KK, int nchF,
+                                                       int nchB, int nf) {
+  constexpr int TSEG = 8;
+  __shared__ float tile[TSEG][16][33];
+  int blk = blockIdx.x;
+  const bool fwd = blk < nf;
+  if (!fwd) blk -= nf;
+  const int nch = fwd ? nchF : nchB;
+  const int mb = blk / nch, ch = blk - mb * nch;
+  unsigned char* out = (fwd ? wp_fwd : wp_bwd) + (size_t)(mb * nch + ch) * KK * PNSFM_BX3_SLAB;
+  const int m0 = mb * 32, k0 = ch * 16;
+  const int Mn = fwd ? Cout : Cin, Kn = fwd ? Cin : Cout;
+  for (int t0 = 0; t0 < KK; t0 += TSEG) {
+    const int nt = (KK - t0 < TSEG) ? KK - t0 : TSEG;
+    if (fwd) {
+      // for a row m: (k, tap) is contiguous in w
+      for (int e = threadIdx.x; e < 32 * 16 * nt; e += 256) {
+        const int m = e / (16 * nt), r = e - m * (16 * nt), k = r / nt, tt = r - k * nt;
+        float v = 0.f;
+        if (m0 + m < Mn && k0 + k < Kn) v = w[((size_t)(m0 + m) * Cin + k0 + k) * KK + t0 + tt];
+        tile[tt][k][m] = v;
+      }
+    } else {
+      // for a K row (an output channel of w): (m = ci, tap) is contiguous in w; output tap t reads source tap KK-1-t
+      for (int e = threadIdx.x; e < 16 * 32 * nt; e += 256) {
+        const int k = e / (32 * nt), r = e - k * (32 * nt), m = r / nt, tt = r - m * nt;
+        float v = 0.f;
+        if (m0 + m < Mn && k0 + k < Kn) v = w[((size_t)(k0 + k) * Cin + m0 + m) * KK + (KK - 1 - (t0 + tt))];
+        tile[tt][k][m] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nt * 64; e += 256) {
+      const int tt = e >> 6, kh = (e >> 5) & 1, m = e & 31;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = tile[tt][kh * 8 + i][m];
+      pnsfm_u32x4 Hh, Mm, Ll;
+      bx3_split8(v, Hh, Mm, Ll);
+      unsigned char* o = out + (size_t)(t0 + tt) * PNSFM_BX3_SLAB + kh * 512 + m * 16;
+      *reinterpret_cast<pnsfm_u32x4*>(o) = Hh;
+      *reinterpret_cast<pnsfm_u32x4*>(o + 1024) = Mm;
+      *reinterpret_cast<pnsfm_u32x4*>(o + 2048) = Ll;
+    }
+    __syncthreads();
+  }
+}

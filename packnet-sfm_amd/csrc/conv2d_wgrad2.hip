@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
   }
   int cur = 0;
   for (int tt = t_begin; tt < t_end; ++tt) {
-    __syncthreads();    // this wave's DMA has landed (vmcnt(0)), everyone's has, and the other buffer is free again
+    pnsfm_dma_wait();
+    __syncthreads();    // this wave's DMA has landed, everyone's has, and the other buffer is free again
     float* buf = smem + cur * BUF;
     float* nbuf = smem + (cur ^ 1) * BUF;
     const TileOff onext = tile_off(tt + 1 < t_end ? tt + 1 : tt);
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
     }
     cur ^= 1;
   }
+  pnsfm_dma_wait();
   __syncthreads();      // the redundant prefetch behind the last tile must land before this workgroup's LDS is released
 
   // ---- epilogue.  MFMA D layout: row (co) = (r&3) + 8*(r>>2) + 4*half, col (ci) = l32; a lane owns the TG taps of 16

@@ -13,6 +13,13 @@
   hipemu::launch((grid), (block), (shmem), [=]() { (kern)(__VA_ARGS__); })
 typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
+typedef hipemu::u32x4 pnsfm_u32x4;
+static inline f32x16 pnsfm_mfma_bf16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x16 c) { return hipemu::mfma_f32_32x32x16_bf16(a, b, c); }
+static inline unsigned pnsfm_f2u(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
+static inline float pnsfm_u2f(unsigned u) { float v; memcpy(&v, &u, 4); return v; }
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even), `lo` in bits [0,16), `hi` in bits [16,32)
+static inline unsigned pnsfm_bf16_rne(float v) { const unsigned u = pnsfm_f2u(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }
+static inline unsigned pnsfm_cvt_pk_bf16(float lo, float hi) { return pnsfm_bf16_rne(lo) | (pnsfm_bf16_rne(hi) << 16); }
 // LDS-DMA: lane l of the wave copies 4 bytes from its own global address to lds_wave_base[l] (emulated synchronously)
 static inline void pnsfm_glds4(const float* src, float* lds_wave_base) { lds_wave_base[hipemu::my_lane()] = *src; }
 // 16-byte LDS-DMA: lane l copies 4 consecutive floats from its own global address to lds_wave_base[4*l .. 4*l+3]
@@ -41,6 +48,7 @@ static inline void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned voff, float* lds
   }
 }
 #define PNSFM_UNIFORM(i) (i)
+static inline void pnsfm_dma_wait() {}
 // buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
 struct pnsfm_buf { const char* base; unsigned bytes; };
 static inline pnsfm_buf pnsfm_make_buf(const void* base, unsigned bytes) { return pnsfm_buf{(const char*)base, bytes}; }
@@ -58,6 +66,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // v_mfma_f32_32x32x2_f32: exact-f32 matrix FMA, 64 cycles/SIMD, D(32x32) += A(32x2) * B(2x32).
 __device__ __forceinline__ f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x16_bf16: D(32x32) += A(32x16) * B(16x32), bf16 operands (8 per lane: A[m = l&31][k = 8*(l>>5) + i],
+// B[k = 8*(l>>5) + i][n = l&31]), f32 accumulate, 32 cycles/SIMD (8 passes) -- 16x the MAC rate of the f32 form.
+typedef unsigned pnsfm_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pnsfm_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 pnsfm_mfma_bf16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pnsfm_bf16x8, a), __builtin_bit_cast(pnsfm_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pnsfm_f2u(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ float pnsfm_u2f(unsigned u) { return __uint_as_float(u); }
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even), `lo` in bits [0,16), `hi` in bits [16,32)
+typedef __bf16 pnsfm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pnsfm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pnsfm_cvt_pk_bf16(float lo, float hi) {
+  const pnsfm_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pnsfm_bf16x2));
 }
 // global_load_lds_dword: asynchronous global -> LDS copy that bypasses the VGPRs.  Every active lane supplies its own
 // global address; the LDS destination is wave-uniform base (M0) + lane*4.  Completion is tracked by vmcnt; a
@@ -87,6 +111,10 @@ __device__ __forceinline__ void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned vof
   __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 #define PNSFM_DMA_INVALID 0x7ffffff0u     // a voffset that is out of range for every descriptor
+// s_waitcnt vmcnt(0): every LDS-DMA (and load) this wave issued has landed.  REQUIRED before the __syncthreads() that
+// publishes DMA'd data to the other waves: hipcc's own wait insertion only guarantees a wave sees ITS OWN copies, and was
+// seen to leave `s_waitcnt vmcnt(1)` in front of such a barrier (conv2d_bx3_kernel<2,2>: intermittent stale weight slabs).
+__device__ __forceinline__ void pnsfm_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt 0, expcnt 7, lgkmcnt 15
 // tell the compiler a value is wave-uniform (moves it to an SGPR)
 #define PNSFM_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
 // Raw buffer loads (buffer_load_dword v, v_off, s[rsrc], s_off offen): the address is base + s_off + v_off with a
@@ -139,7 +167,9 @@ struct ConvGeom {
   int nchunks, splitK;
   int DMA;            // 0: patch staged through registers; 1: patch double-buffered in LDS, fetched by LDS-DMA;
                       // 2: fully pipelined kernel -- patch AND per-kernel-row weight slabs double-buffered by LDS-DMA
-  int G;              // DMA == 2: taps per weight stage (one kernel row; 1 for 1x1)
+                      // 3..5: split-bf16 kernels (fp32 rebuilt from 6 bf16 MFMA products; conv2d_bx3.h)
+  int G;              // DMA >= 2: taps per weight stage
+  int PB;             // DMA >= 3 (split-bf16 variants, conv2d_bx3.h): patch buffers in LDS
   size_t smem_bytes;
 };
 ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S = 1);   // H, W: output size; S: stride
@@ -147,6 +177,7 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S = 1);  
 int conv_pack_KP(int Kc);
 int conv_pack_MP(int Mc);
 int conv_pick_MT(int Mc);
+bool conv_bx3_supported(int Kc, int ks);   // shapes the split-bf16 forward / backward-data kernels take
 
 // tap-major weight-gradient kernel (conv2d_wgrad2.hip); the generic one lives in conv2d.hip and the autotuner picks
 bool wgrad2_supported(int Cin, int Cout, int H, int W, int ks);

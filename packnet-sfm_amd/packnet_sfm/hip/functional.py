@@ -18,6 +18,23 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+def get_conv_math():
+    from . import _lib
+    return 'bx3' if _lib.get().pnsfm_get_conv_math() else 'f32'
+
+
+def set_conv_math(mode):
+    """Arithmetic of the conv forward / backward-data kernels: 'bx3' (default; fp32 rebuilt from exact bf16 splits on the
+    bf16 matrix pipe, 6 products, fp32 accumulate) or 'f32' (v_mfma_f32_32x32x2_f32).  See include/pnsfm.h
+    (pnsfm_set_conv_math).  The packed-weight layout depends on the mode: every cached packed weight is invalidated.
+    Returns the previous mode."""
+    from . import _lib
+    m = {'bx3': 1, 'f32': 0, 1: 1, 0: 0}[mode]
+    prev = _lib.get().pnsfm_set_conv_math(m)
+    bump_weight_epoch()
+    return 'bx3' if prev else 'f32'
+
+
 # Fused / multi-tensor optimizers (torch.optim.Adam(fused=True), the one bench.py uses) update parameters WITHOUT bumping
 # tensor._version, so the version alone cannot tell a packed weight copy is stale.  Every optimizer step of any
 # torch.optim optimizer therefore advances the epoch (global post-step hook), which re-packs each conv weight on its next
@@ -224,7 +241,7 @@ def join_wgrad_stream(device):
 
 
 class Conv2dFn(Function):
-    """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (exact-fp32 MFMA implicit GEMM)."""
+    """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (fp32 implicit GEMM on the matrix pipe; arithmetic: set_conv_math)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cache, recording=True):

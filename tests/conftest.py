@@ -20,6 +20,9 @@ def emulated_kernels():
     from packnet_sfm.hip import _lib
     import emu_loader
     saved = (_lib._LIB, _lib.REQUIRE_CUDA)
-    emu_loader.use_emulated_kernels()
+    lib = emu_loader.use_emulated_kernels()
+    lib.pnsfm_set_conv_math(1)          # every test starts from the library defaults (tests that switch them need not restore)
+    lib.pnsfm_set_conv_variant(0)
+    lib.pnsfm_set_conv_variant(3)
     yield
     _lib._LIB, _lib.REQUIRE_CUDA = saved

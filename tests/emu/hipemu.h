@@ -56,6 +56,7 @@ struct WaveState {
   int count = 0;
   unsigned gen = 0;
   float a[64], b[64];
+  float a8[64][8], b8[64][8];
   double d[64];
   int alive = 0;
 };
@@ -121,6 +122,33 @@ inline f32x16 mfma_f32_32x32x2f32(float a, float b, f32x16 c) {
     acc = fmaf(W.a[row], W.b[col], acc);            // k = 0
     acc = fmaf(W.a[row + 32], W.b[col + 32], acc);  // k = 1
     c[r] = acc;
+  }
+  wave_barrier(W);
+  return c;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[m = l&31][k = 8*(l>>5) + i] and B[k = 8*(l>>5) + i][n = l&31], i = 0..7, as
+// bf16 pairs packed in 4 dwords (element i in bits [16*(i&1), +16) of dword i>>1); D layout as the f32 forms.  The 16
+// products of a row/column pair are exact in fp32; the hardware's internal summation order is not documented, so the
+// model sums them (and the accumulator) in double and rounds once -- tests that go through it compare with a tolerance.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+inline f32x16 mfma_f32_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  WaveState& W = my_wave();
+  int l = my_lane();
+  for (int i = 0; i < 8; ++i) {
+    unsigned ua = (i & 1) ? (a[i >> 1] & 0xffff0000u) : (a[i >> 1] << 16);
+    unsigned ub = (i & 1) ? (b[i >> 1] & 0xffff0000u) : (b[i >> 1] << 16);
+    memcpy(&W.a8[l][i], &ua, 4);
+    memcpy(&W.b8[l][i], &ub, 4);
+  }
+  wave_barrier(W);
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = c[r];
+    for (int h = 0; h < 2; ++h)
+      for (int i = 0; i < 8; ++i) acc += (double)W.a8[row + 32 * h][i] * (double)W.b8[col + 32 * h][i];
+    c[r] = (float)acc;
   }
   wave_barrier(W);
   return c;

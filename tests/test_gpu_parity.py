@@ -169,18 +169,23 @@ CONV_SHAPES = [  # (B, Cin, Cout, H, W, k): real PackNet01 layer shapes at reduc
 
 @pytest.fixture
 def conv_variant(request):
-    """Pin the forward/backward-data kernel variant (0 register-staged patch, 1 double-buffered LDS-DMA patch, 2 fully
-    pipelined: patch and weight slabs by LDS-DMA) with the autotuner off, so that every variant is exercised, not only the ones the tuner happens to pick."""
-    from packnet_sfm.hip import _lib
+    """Pin the forward/backward-data kernel variant with the autotuner off, so that every variant is exercised, not only the
+    ones the tuner happens to pick.  f32 MFMA: 0 register-staged patch, 1 double-buffered LDS-DMA patch, 2 fully pipelined
+    (patch and weight slabs by LDS-DMA).  Split-bf16 arithmetic (conv2d_bx3.h; the default): 3 one patch buffer, 4 two,
+    5 two + a kernel row of weights per stage."""
+    from packnet_sfm.hip import _lib, functional as HF
     lib = _lib.get()
     lib.pnsfm_set_autotune(0)
+    HF.set_conv_math('bx3' if request.param >= 3 else 'f32')
     lib.pnsfm_set_conv_variant(request.param)
     yield request.param
+    HF.set_conv_math('bx3')
     lib.pnsfm_set_conv_variant(0)
+    lib.pnsfm_set_conv_variant(3)
     lib.pnsfm_set_autotune(1)
 
 
-@pytest.mark.parametrize('conv_variant', [0, 1, 2], indirect=True)
+@pytest.mark.parametrize('conv_variant', [0, 1, 2, 3, 4, 5], indirect=True)
 @pytest.mark.parametrize('shape', CONV_SHAPES)
 def test_conv2d_vs_cpu_oracle(shape, conv_variant):
     from packnet_sfm.hip import ops
@@ -200,6 +205,39 @@ def test_conv2d_vs_cpu_oracle(shape, conv_variant):
     dw, db = ops.conv2d_backward_weight(xd, dyd, ks)
     P.check(dw, wr.grad, 5e-5, 'wgrad')
     P.check(db, br.grad, 5e-5, 'dbias')
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64, 48, 160, 7), (1, 2048, 64, 24, 80, 5), (4, 512, 512, 6, 20, 3)])
+def test_conv2d_bx3_error_vs_fp64(shape):
+    """The split-bf16 arithmetic is not a reduced-precision mode: against an fp64 convolution its forward / backward-data error
+    (scaled by sum |x||w|, the quantity rounding errors are proportional to) stays in the class of the f32-MFMA kernels on the
+    same data -- within 2x of theirs (measured 1.0-1.7x: both are dominated by the fp32 accumulation inside the matrix pipe,
+    not by the 2^-26 of dropped piece products) and below 8 * 2^-24 outright; plain bf16 operands would sit at ~4e-4."""
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))      # mixed magnitudes
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    y64 = F.conv2d(x.double(), w.double(), padding=ks // 2)
+    ymag = F.conv2d(x.double().abs(), w.double().abs(), padding=ks // 2)
+    dx64 = F.conv_transpose2d(dy.double(), w.double(), padding=ks // 2)
+    dxmag = F.conv_transpose2d(dy.double().abs(), w.double().abs(), padding=ks // 2)
+    err = {}
+    try:
+        for mode in ('f32', 'bx3'):
+            HF.set_conv_math(mode)
+            wf, wb = ops.conv2d_pack(w.to(DEV))
+            y = ops.conv2d_forward(x.to(DEV), wf, None, Cout, ks).cpu().double()
+            dx = ops.conv2d_backward_data(dy.to(DEV), wb, Cin, ks).cpu().double()
+            err[mode] = (float(((y - y64).abs() / ymag).max()), float(((dx - dx64).abs() / dxmag).max()))
+    finally:
+        HF.set_conv_math('bx3')
+    print('max |err| / sum|a||b|  (fwd, dgrad):  f32 MFMA %.2e %.2e   split-bf16 %.2e %.2e   [2^-24 = 5.96e-08]'
+          % (err['f32'] + err['bx3']))
+    for i in range(2):
+        assert err['bx3'][i] <= max(2.0 * err['f32'][i], 1.5e-7), err
+        assert err['bx3'][i] <= 8 * 2.0 ** -24, err
 
 
 WGRAD2_SHAPES = [  # (B, Cin, Cout, H, W, k): shapes the tap-major weight-gradient kernel supports (W % 8 == 0, k in 1/3/5)

@@ -81,14 +81,17 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
-@pytest.mark.parametrize('direct_a', [2, 1, 0])
+@pytest.mark.parametrize('direct_a', [5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
-                                   (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5)])
+                                   (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
-    """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; both
-    variants of the forward/backward-data kernel (patch through registers, patch by LDS-DMA, fully pipelined)."""
+    """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; every
+    variant of the forward/backward-data kernel: f32 MFMA (0 patch through registers, 1 patch by LDS-DMA, 2 fully pipelined)
+    and the split-bf16 arithmetic (3 one patch buffer, 4 two, 5 whole kernel rows per stage; shapes with < 16 K-channels or
+    a 1x1 kernel fall through to the f32 kernels there)."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
+    _lib.get().pnsfm_set_conv_math(1 if direct_a >= 3 else 0)
     _lib.get().pnsfm_set_conv_variant(direct_a)
     B, Cin, Cout, H, W, ks = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -105,6 +108,36 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     dw, db = ops.conv2d_backward_weight(x, dy, ks)
     P.check(dw, wr.grad, 1e-5, 'wgrad')
     P.check(db, br.grad, 1e-5, 'dbias')
+
+
+@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1)])
+@pytest.mark.parametrize('shape', [(1, 48, 64, 9, 32, 3), (1, 40, 64, 20, 24, 5), (1, 32, 40, 8, 32, 7)])
+def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
+    """Configurations the un-tuned heuristics never pick for small test shapes (two pixel tiles per wave, narrow M tiles,
+    K splits) pinned through pnsfm_tune_set -- what the autotuner does on the GPU: cfg = (NT, variant, narrow-M, K-split)."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    NT, variant, narrow, split = cfg
+    bx3 = variant >= 3
+    lib.pnsfm_set_conv_math(1 if bx3 else 0)
+    B, Cin, Cout, H, W, ks = shape
+    for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+        key = (ctypes.c_int * 7)(kind + 10 + (100 if bx3 else 0), B, K, M, H, W, ks)
+        assert lib.pnsfm_tune_set(key, NT | (variant << 4) | (narrow << 8), split) == 0
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wf, wb = ops.conv2d_pack(w)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    P.check(ops.conv2d_forward(x, wf, b, Cout, ks), yr, 1e-5, 'fwd')
+    P.check(ops.conv2d_backward_data(dy, wb, Cin, ks), xr.grad, 1e-5, 'dgrad')
+    lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
 @pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
@@ -410,13 +443,15 @@ def test_flat_adam_gradient_slots(emulated_kernels):
     opt._slots.remove()
 
 
-@pytest.mark.parametrize('variant', [0, 2])
-@pytest.mark.parametrize('shape', [(1, 9, 16, 8, 64, 7), (2, 6, 32, 12, 40, 5), (1, 16, 8, 3, 10, 3), (1, 4, 8, 6, 20, 3)])
+@pytest.mark.parametrize('variant', [0, 2, 3])
+@pytest.mark.parametrize('shape', [(1, 9, 16, 8, 64, 7), (2, 6, 32, 12, 40, 5), (1, 16, 8, 3, 10, 3), (1, 4, 8, 6, 20, 3),
+                                   (1, 32, 24, 6, 20, 3)])
 def test_conv2d_stride2(emulated_kernels, shape, variant):
     """PoseNet's stride-2 convs (even and odd input sizes): strided forward / weight-gradient kernels and the
     zero-upsample + stride-1 backward-data path vs torch."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, functional as HF
+    _lib.get().pnsfm_set_conv_math(1 if variant >= 3 else 0)
     _lib.get().pnsfm_set_conv_variant(variant)
     B, Cin, Cout, H, W, ks = shape
     g = torch.Generator().manual_seed(sum(shape))

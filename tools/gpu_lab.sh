@@ -49,6 +49,11 @@ prof)
       python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/rocprof_$TAG.log 2>&1)
   tail -1 $O/rocprof_$TAG.log | cut -c1-400
   f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f | cut -c1-160 ;;
+prof_iso)
+  echo "== rocprofv3 kernel trace, weight-gradient side stream OFF (kernels run alone: the 'isolated' roofline)"
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_iso_$TAG -o bench -- \
+      python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/rocprof_iso_$TAG.log 2>&1)
+  tail -1 $O/rocprof_iso_$TAG.log | cut -c1-400 ;;
 prof_eager)
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eager_$TAG -o bench -- \
       python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --graph off > $O/rocprof_eager_$TAG.log 2>&1)

@@ -1,5 +1,6 @@
-"""Per-step kernel breakdown from a rocprofv3 kernel trace CSV of bench.py: takes the LAST full step (between the last two
-bursts of fused-Adam kernels) and prints time per kernel name."""
+"""Per-step kernel breakdown from a rocprofv3 kernel trace CSV of bench.py: takes step number K (default 5: inside the timed
+region of `--warmup 2 --steps 6`; steps are delimited by the bursts of Adam kernels) and prints time per kernel name.
+usage: step_breakdown.py trace.csv [top] [K]"""
 import collections
 import csv
 import re
@@ -11,7 +12,7 @@ for r in rows:
     r['s'] = int(r['Start_Timestamp'])
     r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name'] or 'adam_flat_kernel' in r['Kernel_Name']]
 bursts, prev = [], None
 for i in adam:
     if prev is None or i - prev > 50:
@@ -19,7 +20,8 @@ for i in adam:
     else:
         bursts[-1][1] = i
     prev = i
-b0, b1 = bursts[-2][1] + 1, bursts[-1][1] + 1
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+b0, b1 = bursts[K - 1][1] + 1, bursts[K][1] + 1
 win = rows[b0:b1]
 wall = (win[-1]['e'] - win[0]['s']) / 1e6
 agg = collections.defaultdict(lambda: [0, 0])
@@ -29,6 +31,6 @@ for r in win:
     agg[n][0] += 1
     agg[n][1] += r['e'] - r['s']
 tot = sum(v[1] for v in agg.values()) / 1e6
-print('last step: wall %.2f ms, kernel-sum %.2f ms, %d launches' % (wall, tot, len(win)))
+print('step %d of %d: wall' % (K, len(bursts)) + ' wall %.2f ms, kernel-sum %.2f ms, %d launches' % (wall, tot, len(win)))
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print('%7.3f ms %5d  %s' % (v[1] / 1e6, v[0], n))

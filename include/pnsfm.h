@@ -78,9 +78,11 @@ int pnsfm_set_conv_variant(int lds_dma);
  * again after a switch.  Returns the previous mode.  The weight-gradient kernels are f32-MFMA in both modes. */
 int pnsfm_set_conv_math(int mode);
 int pnsfm_get_conv_math(void);
-/* Un-tuned default of the weight-gradient kernel: 0 = generic ((ci, tap) columns, offset table; conv2d.hip), 1 = tap-major
- * (dY fragments kept in registers across the taps, immediate LDS offsets, LDS-DMA double buffering; conv2d_wgrad2.hip) for
- * the shapes it supports (stride 1, k in {1,3,5}, W % 8 == 0, >= 16 channels); the autotuner times both.  For tests. */
+/* Un-tuned choice of the weight-gradient kernel: 0 = generic ((ci, tap) columns, offset table; conv2d.hip), 1 = tap-major
+ * f32 MFMA (dY fragments kept in registers across the taps, LDS-DMA double buffering; conv2d_wgrad2.hip; stride 1,
+ * k in {1,3,5}, W % 8 == 0, >= 16 channels), 2 = split-bf16 arithmetic (conv2d_wgrad3.hip: one kernel row per workgroup, dY
+ * straight from global memory, shifted X operands built in registers; stride 1, W % 8 == 0, >= 16 channels; only under
+ * pnsfm_set_conv_math(1)), -1 = library default (2 where it applies, else 0).  The autotuner times all that apply.  For tests. */
 int pnsfm_set_wgrad_variant(int tap_major);
 /* Programmatic entry of the tuning database (what a PNSFM_TUNE_DB line does): key7 = {kind, B, Cin, Cout, H, W, ks} with
  * kind = 0 forward / 1 backward-data / 2 backward-weight, + 10 * stride; for kind 2 the key holds H*W in place of H and the

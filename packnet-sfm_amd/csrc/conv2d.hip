@@ -245,7 +245,8 @@ static void tune_log(int kind, const std::array<int, 7>& k, int cfg, int split, 
   (void)kind;
 }
 
-static int g_wgrad_variant = 0;   // un-tuned default weight-gradient kernel: 0 generic, 1 tap-major (pnsfm_set_wgrad_variant)
+static int g_wgrad_variant = -1;  // un-tuned weight-gradient kernel: -1 library default (split-bf16 where the arithmetic mode and the
+                                  // shape allow, else generic), 0 generic, 1 tap-major, 2 split-bf16 (pnsfm_set_wgrad_variant)
 
 static bool autotune_enabled() {
 #ifdef PNSFM_EMU
@@ -1359,11 +1360,22 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, c);
     return check_launch("conv2d_backward_weight");
   };
+  // split-bf16 kernel (conv2d_wgrad3.hip): part of the split arithmetic mode (pnsfm_set_conv_math), the default there
+  const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H0, W0, ks);
+  auto v3_default_split = [&](int NT) -> int {
+    const int base = wgrad3_base_blocks(Cin, Cout, ks, NT), tiles = wgrad3_total_tiles(B, H0, W0);
+    int split = (2 * 256 + base - 1) / base;            // two workgroups per CU
+    if (split > tiles) split = tiles;
+    return split < 1 ? 1 : split;
+  };
   int variant = (g_wgrad_variant == 1 && v2_ok) ? 1 : 0;
   int split2 = v2_ok ? v2_default_split() : 1;
+  int nt3 = wgrad3_nt2_ok(Cin, ks) ? 2 : 1;
+  int split3 = v3_ok ? v3_default_split(nt3) : 1;
+  if (v3_ok && g_wgrad_variant != 0 && g_wgrad_variant != 1) variant = 2;     // -1 (library default) or 2 (pinned)
 #ifndef PNSFM_EMU
   if (autotune_enabled()) {
-    const std::array<int, 7> key = {2 + 10 * S, B, Cin, Cout, a.cstride, W, ks};
+    const std::array<int, 7> key = {2 + 10 * S + (v3_ok ? 100 : 0), B, Cin, Cout, a.cstride, W, ks};
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it == g_tuned.end() && stream_capturing(s)) {
@@ -1400,15 +1412,41 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
           if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 1; }
         }
       }
+      if (v3_ok) {     // split-bf16 kernel: NT in {1, 2}, pixel splits around two workgroups per CU
+        const int tiles3 = wgrad3_total_tiles(B, H0, W0);
+        for (int NT = 1; NT <= (wgrad3_nt2_ok(Cin, ks) ? 2 : 1); ++NT) {
+          const int base3 = wgrad3_base_blocks(Cin, Cout, ks, NT);
+          int prev = -1;
+          for (int want = 1; want <= tiles3; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
+            const int tps = ceil_div(tiles3, want);
+            const int split = ceil_div(tiles3, tps);
+            if (split == prev) continue;
+            prev = split;
+            if ((long)base3 * split < 200 && split < tiles3) continue;      // cannot fill the chip
+            if ((long)base3 * split > 16L * 256 && split > 1) break;
+            const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split, NT, s); });
+            tune_log(2, key, 2 | (NT << 4), split, ms);
+            if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 2 | (NT << 4); }
+          }
+        }
+      }
       it = g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first;
       tune_db_append(key, it->second);
     }
-    variant = (it->second[1] == 1 && v2_ok) ? 1 : 0;
-    if (variant == 1) split2 = it->second[0]; else a.splitP = it->second[0];
+    variant = ((it->second[1] & 15) == 1 && v2_ok) ? 1 : (((it->second[1] & 15) == 2 && v3_ok) ? 2 : 0);
+    if (variant == 2) { split3 = it->second[0]; nt3 = (it->second[1] >> 4) == 2 ? 2 : 1; }
+    else if (variant == 1) split2 = it->second[0]; else a.splitP = it->second[0];
     }
   }
 #endif
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
+  if (variant == 2) {
+    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3) * split3};
+    prof_begin(1, flops, s, meta);
+    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split3, nt3, s);
+    prof_end(1, s);
+    return rc;
+  }
   if (variant == 1) {
     const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split2, wgrad2_base_blocks(Cin, Cout, ks) * split2};
     prof_begin(1, flops, s, meta);
@@ -1456,7 +1494,7 @@ int pnsfm_tune_set(const int* key7, int v0, int v1) {
 }
 
 int pnsfm_set_wgrad_variant(int tap_major) {
-  g_wgrad_variant = tap_major ? 1 : 0;
+  g_wgrad_variant = (tap_major < 0 || tap_major > 2) ? -1 : tap_major;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tuned.clear();
   return 0;

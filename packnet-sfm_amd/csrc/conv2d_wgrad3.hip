@@ -1,0 +1,319 @@
+// conv2d_wgrad3.hip -- weight gradient of a stride-1 KxK convolution on the bf16 matrix pipe (split-bf16 arithmetic).
+//
+// Replaces the autograd weight gradient of nn.Conv2d in the reference's Conv2D / ResidualConv / Pack / Unpack blocks
+//   (/root/reference/packnet_sfm/networks/layers/packnet/layers01.py:28-36, 57-60, 235-246, 274-281):
+//   dW[co][ci][ky][kx] = sum_{b, y, x} dY[b][co][y][x] * X[b][ci][y + ky - P][x + kx - P]
+// with the arithmetic of conv2d_bx3.h: every fp32 operand is split EXACTLY into three bf16 pieces (h, m, l) and the product
+// is rebuilt from the 6 piece products hh, hm, mh, hl, lh, mm with fp32 accumulation (v_mfma_f32_32x32x16_bf16): fp32-class
+// error at 16/6 the MAC rate of v_mfma_f32_32x32x2_f32.
+//
+// GEMM view PER TAP: M = co, N = ci, K = pixels; one MFMA k-step = 16 consecutive pixels of an image row.
+//   * a workgroup owns ONE KERNEL ROW ky (blockIdx.x = (ci tile, ky)): its waves accumulate the KS taps of that row for a
+//     32(co) x 32*NT(ci) tile each, KS*NT accumulator tiles;  4 waves = WM co tiles x WK pixel shares (WM = 4, 2, 1 for
+//     Cout >= 97, >= 33, smaller): all waves share one X patch in LDS;
+//   * A operand (dY): lane (co = l&31, half = l>>5) needs 8 consecutive pixels -- 32 contiguous bytes of the NCHW tensor: read
+//     straight from global memory (buffer loads, one k-step ahead), split in registers, reused by the KS*NT*6 MFMAs of
+//     the k-step; dY never goes through LDS.  The bias gradient is the running sum of the same registers;
+//   * B operand (X): the patch rows for this ky (TR = 4 rows x 32 + 16 columns, 8 columns of halo either side so that every
+//     8-pixel group is 16-byte aligned) are staged per pixel tile: fp32 rows -> registers (issued before the previous tile's
+//     MFMAs) -> 3 bf16 pieces -> LDS [piece][ci][row][col] (channel stride 8 * odd elements: conflict-free ds_read_b128).
+//     A lane reads the aligned 8-pixel block and its two neighbours (3 ds_read_b128 per piece) and builds the KS shifted
+//     operands in registers: an even shift is a register renaming, an odd shift one v_alignbit_b32 per dword;
+//   * pixel tiles are split over blockIdx.z; partial dW (and the WK pixel shares of a workgroup) meet with fp32 atomics in a
+//     zero-filled buffer.
+// Requires W % 8 == 0 (aligned 8-pixel groups never straddle a row end); other shapes keep the f32 kernels.
+// Roofline: MFMA-bound: 2*Cout*Cin*K*K*B*H*W algorithmic flop against 2500/6 TFLOP/s (bf16 dense peak / 6 products).
+#include "pnsfm_common.h"
+#include "../../include/pnsfm.h"
+
+namespace pnsfm {
+
+struct Wgrad3Args {
+  const float* x;    // [B][Cin][H][W]
+  const float* dy;   // [B][Cout][H][W]
+  float* dw;         // [Cout][Cin][KS][KS]   (zero-filled: atomics)
+  float* dbias;      // [Cout] or null        (zero-filled)
+  int B, Cin, Cout, H, W;
+  int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
+  int ci_tiles;      // gridDim.x = ci_tiles * KS
+};
+
+#ifdef PNSFM_EMU
+static inline unsigned w3_alignbit16(unsigned hi, unsigned lo) { return (lo >> 16) | (hi << 16); }
+#else
+__device__ __forceinline__ unsigned w3_alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+#endif
+
+// 8 consecutive fp32 values -> three 16-byte bf16 pieces (see conv2d_bx3.h: exact, round-to-nearest pieces)
+__device__ __forceinline__ void w3_split8(const float (&v)[8], pnsfm_u32x4& H, pnsfm_u32x4& M, pnsfm_u32x4& L) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const unsigned h = pnsfm_cvt_pk_bf16(v[i], v[i + 1]);
+    const float r0 = v[i] - pnsfm_u2f(h << 16), r1 = v[i + 1] - pnsfm_u2f(h & 0xffff0000u);
+    const unsigned m = pnsfm_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - pnsfm_u2f(m << 16), s1 = r1 - pnsfm_u2f(m & 0xffff0000u);
+    H[i >> 1] = h;
+    M[i >> 1] = m;
+    L[i >> 1] = pnsfm_cvt_pk_bf16(s0, s1);
+  }
+}
+
+template <int KS, int NT, int WM>
+struct Wgrad3Geom {
+  static constexpr int P = KS / 2, KK = KS * KS;
+  static constexpr int WK = 4 / WM;                      // pixel shares of a workgroup
+  static constexpr int TR = 4, TC = 32;                  // pixel tile: 4 rows x 32 columns = 8 k-steps
+  static constexpr int RS = TC + 16;                     // patch row: 8 halo + 32 + 8 halo elements
+  static constexpr int CS = TR * RS + 8;                 // channel stride (elements): 200 = 8 * 25 -> conflict-free b128
+  static constexpr int NCI = 32 * NT;
+  static constexpr int PIECE = NCI * CS;                 // elements of one piece plane
+  static constexpr int SMEM = 3 * PIECE * 2;             // bytes
+  static constexpr int ITEMS = NCI * TR * (RS / 8);      // (channel, row, 8-column group) items of the patch
+  static constexpr int NIT = ITEMS / 256;                // per thread (ITEMS = 768 * NT)
+  static constexpr int KSTEPS = TR * TC / 16;            // 8
+};
+
+template <int KS, int NT, int WM>
+__global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
+  using Gm = Wgrad3Geom<KS, NT, WM>;
+  constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI;
+  constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KSTEPS = Gm::KSTEPS;
+  PNSFM_DYN_SMEM(unsigned char, smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
+  const int wm = wave % WM, wk = wave / WM;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int cit = blockIdx.x / KS, ky = blockIdx.x - cit * KS;
+  const int ci0 = cit * NCI;
+  const int co0 = (blockIdx.y * WM + wm) * 32;
+  const int t_begin = blockIdx.z * a.tiles_per_split;
+  int t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.total_tiles) t_end = a.total_tiles;
+
+  f32x16 acc[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][k][r] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;      // ci tile 0, kernel row 0
+
+  // ---- patch items of this thread: (channel, row, 8-column group); the LDS slot is fixed, the global offset per tile
+  int it_ci[NIT], it_r[NIT], it_g[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = it * 256 + tid;
+    it_ci[it] = e / (TR * (RS / 8));
+    const int rem = e - it_ci[it] * (TR * (RS / 8));
+    it_r[it] = rem / (RS / 8);
+    it_g[it] = rem - it_r[it] * (RS / 8);
+  }
+  float raw[NIT][8];
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+    b = t / a.tiles_per_img;
+    const int tt = t - b * a.tiles_per_img;
+    const int ty = tt / a.tiles_x;
+    y0 = ty * TR;
+    x0 = (tt - ty * a.tiles_x) * TC;
+  };
+  auto load_patch = [&](int t) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+    // descriptor over channels [ci0, Cin) of image b: channels past Cin read as zero
+    const long rem = (long)(a.Cin - ci0) * HW * 4;
+    const pnsfm_buf buf = pnsfm_make_buf(a.x + ((size_t)b * a.Cin + ci0) * HW, (unsigned)(rem > 0 ? rem : 0));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int yy = y0 + it_r[it] + ky - P, xx = x0 - 8 + 8 * it_g[it];
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const unsigned off = ok ? (unsigned)((it_ci[it] * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[it][u] = pnsfm_buf_load(buf, off + 4u * u, 0);
+    }
+  };
+  auto write_patch = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      pnsfm_u32x4 Hh, Mm, Ll;
+      w3_split8(raw[it], Hh, Mm, Ll);
+      unsigned char* d = smem + (size_t)(it_ci[it] * CS + it_r[it] * RS + 8 * it_g[it]) * 2;
+      *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
+      *reinterpret_cast<pnsfm_u32x4*>(d + PIECE * 2) = Mm;
+      *reinterpret_cast<pnsfm_u32x4*>(d + 2 * PIECE * 2) = Ll;
+    }
+  };
+
+  // ---- A operand: dY[co0 + l32][8 pixels] of k-step q (row q / 2, columns 16 * (q & 1) + 8 * half ..) straight from global
+  float araw[2][8];
+  auto load_a = [&](float (&dst)[8], int t, int q) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+    const pnsfm_buf buf = pnsfm_make_buf(a.dy + (size_t)b * a.Cout * HW, (unsigned)((long)a.Cout * HW * 4));
+    const int yy = y0 + (q >> 1), xx = x0 + 16 * (q & 1) + 8 * half;
+    const bool ok = yy < H && xx < W;
+    const unsigned off = ok ? (unsigned)(((co0 + l32) * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(buf, off + 4u * u, 0);
+  };
+
+  const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
+
+  auto kstep = [&](const float (&av)[8], int q) {
+    pnsfm_u32x4 A[3];
+    w3_split8(av, A[0], A[1], A[2]);
+    if (do_bias) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bsum += av[u];
+    }
+    const int koff = ((q >> 1) * RS + 16 * (q & 1)) * 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
+      unsigned Wd[3][12];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE) * 2 + koff;
+        const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
+        if (KS > 1) {
+          const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
+          const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        constexpr int dummy = 0; (void)dummy;
+        const int sh = kx - P;                         // element shift of this tap
+        pnsfm_u32x4 Bv[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
+            else {
+              const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
+              Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
+            }
+          }
+        // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+        acc[nt][kx] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[1], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[0], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[1], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[0], acc[nt][kx]);
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    load_patch(t_begin);
+    load_a(araw[0], t_begin, wk);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();           // every wave is done with the previous tile's patch
+    write_patch();
+    __syncthreads();
+    if (t + 1 < t_end) load_patch(t + 1);          // lands behind this tile's MFMAs
+    // this wave's k-steps: q = wk, wk + WK, ...  (KSTEPS / WK of them, an even count or 2); A double-buffered in registers
+#pragma unroll
+    for (int i = 0; i < KSTEPS / WK; ++i) {
+      const int q = wk + WK * i;
+      if (i + 1 < KSTEPS / WK) load_a(araw[(i + 1) & 1], t, q + WK);
+      else if (t + 1 < t_end) load_a(araw[(i + 1) & 1], t + 1, wk);
+      kstep(araw[i & 1], q);
+    }
+  }
+
+  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half -> co, col = l32 -> ci
+  const size_t N = (size_t)a.Cin * KK;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ci = ci0 + nt * 32 + l32;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * N + (size_t)ci * KK + ky * KS + kx, acc[nt][kx][r]);
+      }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0 && co0 + l32 < a.Cout) atomicAdd(a.dbias + co0 + l32, bsum);
+  }
+}
+
+bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks) {
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) return false;
+  return W % 8 == 0 && Cin >= 16 && Cout >= 16 && H >= 1;
+}
+static int wgrad3_WM(int Cout) { return Cout > 96 ? 4 : (Cout > 32 ? 2 : 1); }
+int wgrad3_total_tiles(int B, int H, int W) { return B * ceil_div(W, 32) * ceil_div(H, 4); }
+int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT) {
+  return ceil_div(Cin, 32 * NT) * ks * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout));
+}
+bool wgrad3_nt2_ok(int Cin, int ks) { return ks <= 3 && Cin > 32; }
+
+template <int KS, int NT, int WM>
+static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
+  using Gm = Wgrad3Geom<KS, NT, WM>;
+#ifndef PNSFM_EMU
+  static bool raised = false;
+  if (!raised && Gm::SMEM > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
+      return -1;
+    }
+    raised = true;
+  }
+#endif
+  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
+  return check_launch("conv2d_backward_weight (split-bf16)");
+}
+
+int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
+                   int split, int NT, hipStream_t s) {
+  if (!wgrad3_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (split-bf16): unsupported shape"); return -1; }
+  if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
+  Wgrad3Args a;
+  a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.tiles_x = ceil_div(W, 32);
+  a.tiles_per_img = a.tiles_x * ceil_div(H, 4);
+  a.total_tiles = B * a.tiles_per_img;
+  if (split < 1) split = 1;
+  if (split > a.total_tiles) split = a.total_tiles;
+  a.tiles_per_split = ceil_div(a.total_tiles, split);
+  const int splitP = ceil_div(a.total_tiles, a.tiles_per_split);
+  a.ci_tiles = ceil_div(Cin, 32 * NT);
+  const size_t N = (size_t)Cin * ks * ks;
+  {   // partial sums always meet with atomics (pixel shares of a workgroup, pixel splits): zero-filled outputs
+    const bool joined = dbias == dw + (size_t)Cout * N;
+    int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
+    if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
+    if (e) { set_error("conv2d_backward_weight: memset failed"); return e; }
+  }
+  const int WM = wgrad3_WM(Cout);
+  dim3 grid(a.ci_tiles * ks, ceil_div(ceil_div(Cout, 32), WM), splitP);
+#define PNSFM_W3(KSv, NTv)                                                \
+  do {                                                                    \
+    if (WM == 4) return launch_wgrad3<KSv, NTv, 4>(a, grid, s);           \
+    if (WM == 2) return launch_wgrad3<KSv, NTv, 2>(a, grid, s);           \
+    return launch_wgrad3<KSv, NTv, 1>(a, grid, s);                        \
+  } while (0)
+  if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); PNSFM_W3(1, 1); }
+  if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); PNSFM_W3(3, 1); }
+  if (ks == 5) PNSFM_W3(5, 1);
+  PNSFM_W3(7, 1);
+#undef PNSFM_W3
+}
+
+}  // namespace pnsfm

@@ -186,6 +186,14 @@ int wgrad2_base_blocks(int Cin, int Cout, int ks);
 int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
                    int split, hipStream_t stream);
 
+// split-bf16 weight-gradient kernel (conv2d_wgrad3.hip)
+bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks);
+bool wgrad3_nt2_ok(int Cin, int ks);
+int wgrad3_total_tiles(int B, int H, int W);
+int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT);
+int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
+                   int split, int NT, hipStream_t stream);
+
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);
 void prof_end(int kind, hipStream_t stream);

@@ -24,5 +24,6 @@ def emulated_kernels():
     lib.pnsfm_set_conv_math(1)          # every test starts from the library defaults (tests that switch them need not restore)
     lib.pnsfm_set_conv_variant(0)
     lib.pnsfm_set_conv_variant(3)
+    lib.pnsfm_set_wgrad_variant(-1)
     yield
     _lib._LIB, _lib.REQUIRE_CUDA = saved

@@ -164,7 +164,32 @@ def test_conv2d_wgrad_tap_major(emulated_kernels, shape):
         P.check(dw, wr.grad, 1e-5, 'wgrad (tap-major)')
         P.check(db, br.grad, 1e-5, 'dbias (tap-major)')
     finally:
-        lib.pnsfm_set_wgrad_variant(0)
+        lib.pnsfm_set_wgrad_variant(-1)
+
+
+@pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
+                                   (1, 40, 64, 6, 24, 5), (3, 17, 31, 7, 40, 1), (1, 32, 40, 6, 40, 7), (1, 48, 129, 5, 16, 3)])
+def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
+    """The split-bf16 weight-gradient kernel (csrc/conv2d_wgrad3.hip) vs torch: k in {1, 3, 5, 7} (even and odd operand shifts),
+    one and two ci tiles per wave, 1 / 2 / 4 co tiles per workgroup, widths that do not fill the 32-column tile, heights that
+    do not fill its 4 rows, odd channel counts -- the library default under the split arithmetic, pinned here."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_conv_math(1)
+    lib.pnsfm_set_wgrad_variant(2)
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone(), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dw, db = ops.conv2d_backward_weight(x, dy, ks)
+    P.check(dw, wr.grad, 1e-5, 'wgrad (split-bf16)')
+    P.check(db, br.grad, 1e-5, 'dbias (split-bf16)')
 
 
 @pytest.mark.parametrize('nf', [8, 4])

@@ -12,15 +12,16 @@
 //     32(co) x 32*NT(ci) tile each, KS*NT accumulator tiles;  4 waves = WM co tiles x WK pixel shares (WM = 4, 2, 1 for
 //     Cout >= 97, >= 33, smaller): all waves share one X patch in LDS;
 //   * A operand (dY): lane (co = l&31, half = l>>5) needs 8 consecutive pixels -- 32 contiguous bytes of the NCHW tensor: read
-//     straight from global memory (buffer loads, one k-step ahead), split in registers, reused by the KS*NT*6 MFMAs of
+//     straight from global memory (buffer loads, up to a whole tile ahead), split in registers, reused by the KS*NT*6 MFMAs of
 //     the k-step; dY never goes through LDS.  The bias gradient is the running sum of the same registers;
 //   * B operand (X): the patch rows for this ky (TR = 4 rows x 32 + 16 columns, 8 columns of halo either side so that every
 //     8-pixel group is 16-byte aligned) are staged per pixel tile: fp32 rows -> registers (issued before the previous tile's
 //     MFMAs) -> 3 bf16 pieces -> LDS [piece][ci][row][col] (channel stride 8 * odd elements: conflict-free ds_read_b128).
 //     A lane reads the aligned 8-pixel block and its two neighbours (3 ds_read_b128 per piece) and builds the KS shifted
 //     operands in registers: an even shift is a register renaming, an odd shift one v_alignbit_b32 per dword;
-//   * pixel tiles are split over blockIdx.z; partial dW (and the WK pixel shares of a workgroup) meet with fp32 atomics in a
-//     zero-filled buffer.
+//   * the WK pixel shares of a workgroup are summed through LDS; pixel tiles are split over blockIdx.z and the partial
+//     tensors of a split launch go to a scratch buffer ([split][ky][co][kx][ci]: coalesced stores) that a second kernel sums
+//     in a fixed order -- no atomics anywhere: the gradient is bit-reproducible run to run.
 // Requires W % 8 == 0 (aligned 8-pixel groups never straddle a row end); other shapes keep the f32 kernels.
 // Roofline: MFMA-bound: 2*Cout*Cin*K*K*B*H*W algorithmic flop against 2500/6 TFLOP/s (bf16 dense peak / 6 products).
 #include "pnsfm_common.h"
@@ -31,8 +32,11 @@ namespace pnsfm {
 struct Wgrad3Args {
   const float* x;    // [B][Cin][H][W]
   const float* dy;   // [B][Cout][H][W]
-  float* dw;         // [Cout][Cin][KS][KS]   (zero-filled: atomics)
-  float* dbias;      // [Cout] or null        (zero-filled)
+  float* dw;         // [Cout][Cin][KS][KS]   written directly when the launch has ONE pixel split ...
+  float* dbias;      // [Cout] or null
+  float* ws;         // ... else partial sums [split][KS(ky)][COP][KS(kx)][CIP] (+ [split][COP] bias partials at ws_bias),
+  float* ws_bias;    //     reduced by wgrad3_reduce_kernel: no atomics, a fixed summation order
+  int COP, CIP;      // padded channel extents of the workspace (whole workgroup tiles)
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
   int ci_tiles;      // gridDim.x = ci_tiles * KS
@@ -71,13 +75,17 @@ struct Wgrad3Geom {
   static constexpr int ITEMS = NCI * TR * (RS / 8);      // (channel, row, 8-column group) items of the patch
   static constexpr int NIT = ITEMS / 256;                // per thread (ITEMS = 768 * NT)
   static constexpr int KSTEPS = TR * TC / 16;            // 8
+  static constexpr int KPW = KSTEPS / WK;                // k-steps of a tile per wave
+  // dY fragments in flight per wave (8 registers each): a whole tile ahead where the accumulators leave room -- the loads
+  // are issued RD k-steps before use, which is what hides the global-memory latency when only one workgroup fits a CU
+  static constexpr int RD = KS >= 7 ? 2 : ((KS == 5 || (NT == 2 && KS > 1)) ? (KPW < 4 ? KPW : 4) : KPW);
 };
 
 template <int KS, int NT, int WM>
 __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
   using Gm = Wgrad3Geom<KS, NT, WM>;
   constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI;
-  constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KSTEPS = Gm::KSTEPS;
+  constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KPW = Gm::KPW, RD = Gm::RD;
   PNSFM_DYN_SMEM(unsigned char, smem);
 
   const int tid = threadIdx.x;
@@ -147,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
   };
 
   // ---- A operand: dY[co0 + l32][8 pixels] of k-step q (row q / 2, columns 16 * (q & 1) + 8 * half ..) straight from global
-  float araw[2][8];
+  float araw[RD][8];
   auto load_a = [&](float (&dst)[8], int t, int q) {
     int b, y0, x0;
     tile_origin(t, b, y0, x0);
@@ -161,13 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
 
   const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
 
-  auto kstep = [&](const float (&av)[8], int q) {
-    pnsfm_u32x4 A[3];
-    w3_split8(av, A[0], A[1], A[2]);
-    if (do_bias) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) bsum += av[u];
-    }
+  auto kstep = [&](const pnsfm_u32x4 (&A)[3], int q) {
     const int koff = ((q >> 1) * RS + 16 * (q & 1)) * 2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -214,39 +216,122 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
 
   if (t_begin < t_end) {
     load_patch(t_begin);
-    load_a(araw[0], t_begin, wk);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) load_a(araw[i], t_begin, wk + WK * i);
   }
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();           // every wave is done with the previous tile's patch
     write_patch();
     __syncthreads();
     if (t + 1 < t_end) load_patch(t + 1);          // lands behind this tile's MFMAs
-    // this wave's k-steps: q = wk, wk + WK, ...  (KSTEPS / WK of them, an even count or 2); A double-buffered in registers
+    // this wave's k-steps: q = wk, wk + WK, ...; the dY fragment of k-step i sits in ring slot i % RD and is replaced, as soon
+    // as it has been split, by the fragment RD k-steps ahead (of this tile or the next)
 #pragma unroll
-    for (int i = 0; i < KSTEPS / WK; ++i) {
+    for (int i = 0; i < KPW; ++i) {
       const int q = wk + WK * i;
-      if (i + 1 < KSTEPS / WK) load_a(araw[(i + 1) & 1], t, q + WK);
-      else if (t + 1 < t_end) load_a(araw[(i + 1) & 1], t + 1, wk);
-      kstep(araw[i & 1], q);
+      pnsfm_u32x4 A[3];
+      w3_split8(araw[i % RD], A[0], A[1], A[2]);
+      if (do_bias) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bsum += araw[i % RD][u];
+      }
+      if (i + RD < KPW) load_a(araw[i % RD], t, q + WK * RD);
+      else if (t + 1 < t_end) load_a(araw[i % RD], t + 1, wk + WK * (i + RD - KPW));
+      kstep(A, q);
     }
   }
 
-  // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*half -> co, col = l32 -> ci
-  const size_t N = (size_t)a.Cin * KK;
+  // ---- epilogue.  The WK pixel shares of the workgroup are summed through LDS (one tap at a time: (WK-1)*WM*NT tiles of
+  // 4 KB), then every output element has exactly ONE writer in this launch: plain stores, no atomics.
+  // D row = (r&3) + 8*(r>>2) + 4*half -> co, col = l32 -> ci
+  if (do_bias) bsum += __shfl_xor(bsum, 32);
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();           // the patch is dead
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ci = ci0 + nt * 32 + l32;
+    for (int kx = 0; kx < KS; ++kx) {
+      if (wk > 0) {
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (size_t)co * N + (size_t)ci * KK + ky * KS + kx, acc[nt][kx][r]);
+          for (int r = 0; r < 16; ++r) red[((((wk - 1) * WM + wm) * NT + nt) * 16 + r) * 64 + lane] = acc[nt][kx][r];
       }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int j = 1; j < WK; ++j)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][kx][r] += red[((((j - 1) * WM + wm) * NT + nt) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (do_bias) {
+      if (wk > 0 && half == 0) red[((wk - 1) * WM + wm) * 32 + l32] = bsum;
+      __syncthreads();
+      if (wk == 0)
+        for (int j = 1; j < WK; ++j) bsum += red[((j - 1) * WM + wm) * 32 + l32];
+    }
   }
-  if (do_bias) {
-    bsum += __shfl_xor(bsum, 32);
-    if (half == 0 && co0 + l32 < a.Cout) atomicAdd(a.dbias + co0 + l32, bsum);
+  if (wk == 0) {
+    if (a.ws == nullptr) {      // the only pixel split: reference layout directly
+      const size_t N = (size_t)a.Cin * KK;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ci = ci0 + nt * 32 + l32;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < a.Cout && ci < a.Cin) a.dw[(size_t)co * N + (size_t)ci * KK + ky * KS + kx] = acc[nt][kx][r];
+          }
+      }
+      if (do_bias && half == 0 && co0 + l32 < a.Cout) a.dbias[co0 + l32] = bsum;
+    } else {                    // partial sums, ci fastest: 128 contiguous bytes per half-wave
+      float* w = a.ws + ((size_t)blockIdx.z * KS + ky) * a.COP * KS * a.CIP;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ci = ci0 + nt * 32 + l32;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            w[((size_t)co * KS + kx) * a.CIP + ci] = acc[nt][kx][r];
+          }
+      }
+      if (do_bias && half == 0) a.ws_bias[(size_t)blockIdx.z * a.COP + co0 + l32] = bsum;
+    }
+  }
+}
+
+// second stage of a pixel-split launch: dW[co][ci][ky][kx] = sum over the Z partial tensors, in a fixed order (deterministic),
+// written as contiguous (ci, tap) runs through LDS.  One workgroup per (co, 32 input channels).
+__global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_bias,
+                                                            float* __restrict__ dw, float* __restrict__ dbias, int Z, int KS,
+                                                            int COP, int CIP, int Cin, int Cout) {
+  __shared__ float tile[32 * 49];
+  const int co = blockIdx.x, cib = blockIdx.y, KK = KS * KS;
+  const size_t zstride = (size_t)KS * COP * KS * CIP;
+  for (int e = threadIdx.x; e < KK * 32; e += 256) {
+    const int tap = e >> 5, cil = e & 31;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    const float* p = ws + (((size_t)ky * COP + co) * KS + kx) * CIP + cib * 32 + cil;
+    float sum = 0.f;
+    for (int z = 0; z < Z; ++z) sum += p[z * zstride];
+    tile[cil * KK + tap] = sum;
+  }
+  __syncthreads();
+  int nci = Cin - cib * 32;
+  if (nci > 32) nci = 32;
+  float* out = dw + ((size_t)co * Cin + cib * 32) * KK;
+  for (int e = threadIdx.x; e < nci * KK; e += 256) out[e] = tile[e];
+  if (dbias && cib == 0 && threadIdx.x == 0) {
+    float sum = 0.f;
+    for (int z = 0; z < Z; ++z) sum += ws_bias[(size_t)z * COP + co];
+    dbias[co] = sum;
   }
 }
 
@@ -294,26 +379,44 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.tiles_per_split = ceil_div(a.total_tiles, split);
   const int splitP = ceil_div(a.total_tiles, a.tiles_per_split);
   a.ci_tiles = ceil_div(Cin, 32 * NT);
-  const size_t N = (size_t)Cin * ks * ks;
-  {   // partial sums always meet with atomics (pixel shares of a workgroup, pixel splits): zero-filled outputs
-    const bool joined = dbias == dw + (size_t)Cout * N;
-    int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
-    if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-    if (e) { set_error("conv2d_backward_weight: memset failed"); return e; }
-  }
   const int WM = wgrad3_WM(Cout);
-  dim3 grid(a.ci_tiles * ks, ceil_div(ceil_div(Cout, 32), WM), splitP);
+  const int co_groups = ceil_div(ceil_div(Cout, 32), WM);
+  a.COP = co_groups * WM * 32;
+  a.CIP = a.ci_tiles * 32 * NT;
+  a.ws = nullptr; a.ws_bias = nullptr;
+  if (splitP > 1) {
+    // pixel-split launch: partial tensors in a stream-ordered scratch allocation, summed by wgrad3_reduce_kernel
+    const size_t part = (size_t)ks * a.COP * ks * a.CIP;
+    void* p = nullptr;
+    if (hipMallocAsync(&p, ((size_t)splitP * (part + a.COP)) * sizeof(float), s) != hipSuccess || !p) {
+      set_error("conv2d_backward_weight: cannot allocate the partial-sum workspace");
+      return -1;
+    }
+    a.ws = (float*)p;
+    a.ws_bias = a.ws + (size_t)splitP * part;
+  }
+  dim3 grid(a.ci_tiles * ks, co_groups, splitP);
+  int rc = 0;
 #define PNSFM_W3(KSv, NTv)                                                \
   do {                                                                    \
-    if (WM == 4) return launch_wgrad3<KSv, NTv, 4>(a, grid, s);           \
-    if (WM == 2) return launch_wgrad3<KSv, NTv, 2>(a, grid, s);           \
-    return launch_wgrad3<KSv, NTv, 1>(a, grid, s);                        \
+    if (WM == 4) rc = launch_wgrad3<KSv, NTv, 4>(a, grid, s);             \
+    else if (WM == 2) rc = launch_wgrad3<KSv, NTv, 2>(a, grid, s);        \
+    else rc = launch_wgrad3<KSv, NTv, 1>(a, grid, s);                     \
   } while (0)
-  if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); PNSFM_W3(1, 1); }
-  if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); PNSFM_W3(3, 1); }
-  if (ks == 5) PNSFM_W3(5, 1);
-  PNSFM_W3(7, 1);
+  if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); else PNSFM_W3(1, 1); }
+  else if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
+  else if (ks == 5) PNSFM_W3(5, 1);
+  else PNSFM_W3(7, 1);
 #undef PNSFM_W3
+  if (a.ws) {
+    if (!rc) {
+      PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 32)), dim3(256), 0, s, (const float*)a.ws, (const float*)a.ws_bias,
+                   dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout);
+      rc = check_launch("conv2d_backward_weight (split-bf16, reduction)");
+    }
+    (void)hipFreeAsync(a.ws, s);
+  }
+  return rc;
 }
 
 }  // namespace pnsfm

@@ -245,5 +245,7 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline int hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline int hipMallocAsync(void** p, size_t n, hipStream_t) { *p = malloc(n); return *p ? 0 : 2; }
+inline int hipFreeAsync(void* p, hipStream_t) { free(p); return 0; }
 inline int hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(int) { return "emu"; }

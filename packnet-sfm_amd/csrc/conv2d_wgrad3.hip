@@ -22,7 +22,8 @@
 //   * the WK pixel shares of a workgroup are summed through LDS; pixel tiles are split over blockIdx.z and the partial
 //     tensors of a split launch go to a scratch buffer ([split][ky][co][kx][ci]: coalesced stores) that a second kernel sums
 //     in a fixed order -- no atomics anywhere: the gradient is bit-reproducible run to run.
-// Requires W % 8 == 0 (aligned 8-pixel groups never straddle a row end); other shapes keep the f32 kernels.
+// Widths that are not a multiple of 8 (20, 4, 2: 8-pixel groups straddle the row end) run a variant that range-checks every
+// element; tiles are 4 rows x 32 columns, or 4 x 16 where that wastes fewer columns (W = 40, 80, 20).  k = 3, 5, 7.
 // Roofline: MFMA-bound: 2*Cout*Cin*K*K*B*H*W algorithmic flop against 2500/6 TFLOP/s (bf16 dense peak / 6 products).
 #include "pnsfm_common.h"
 #include "../../include/pnsfm.h"
@@ -62,30 +63,37 @@ __device__ __forceinline__ void w3_split8(const float (&v)[8], pnsfm_u32x4& H, p
   }
 }
 
-template <int KS, int NT, int WM>
+template <int KS, int NT, int WM, int TCv>
 struct Wgrad3Geom {
   static constexpr int P = KS / 2, KK = KS * KS;
   static constexpr int WK = 4 / WM;                      // pixel shares of a workgroup
-  static constexpr int TR = 4, TC = 32;                  // pixel tile: 4 rows x 32 columns = 8 k-steps
-  static constexpr int RS = TC + 16;                     // patch row: 8 halo + 32 + 8 halo elements
-  static constexpr int CS = TR * RS + 8;                 // channel stride (elements): 200 = 8 * 25 -> conflict-free b128
+  static constexpr int TR = 4, TC = TCv;                 // pixel tile: 4 rows x 32 (16) columns = 8 (4) k-steps
+  static constexpr int SEG = TC / 16;                    // k-steps per tile row
+  static constexpr int RS = TC + 16;                     // patch row: 8 halo + TC + 8 halo elements
+  static constexpr int CS = TR * RS + 8;                 // channel stride (elements): 200 = 8 * 25 / 136 = 8 * 17 -> conflict-free b128
   static constexpr int NCI = 32 * NT;
   static constexpr int PIECE = NCI * CS;                 // elements of one piece plane
   static constexpr int SMEM = 3 * PIECE * 2;             // bytes
   static constexpr int ITEMS = NCI * TR * (RS / 8);      // (channel, row, 8-column group) items of the patch
-  static constexpr int NIT = ITEMS / 256;                // per thread (ITEMS = 768 * NT)
-  static constexpr int KSTEPS = TR * TC / 16;            // 8
+  static constexpr int NIT = ITEMS / 256;                // per thread (ITEMS = 768 * NT or 512 * NT)
+  static constexpr int KSTEPS = TR * SEG;                // 8 or 4
   static constexpr int KPW = KSTEPS / WK;                // k-steps of a tile per wave
   // dY fragments in flight per wave (8 registers each): a whole tile ahead where the accumulators leave room -- the loads
   // are issued RD k-steps before use, which is what hides the global-memory latency when only one workgroup fits a CU
-  static constexpr int RD = KS >= 7 ? 2 : ((KS == 5 || (NT == 2 && KS > 1)) ? (KPW < 4 ? KPW : 4) : KPW);
+  static constexpr int RDW = (KS >= 7 || NT == 2) ? 2 : (KS == 5 ? 4 : 8);
+  static constexpr int RD = 2 * KPW < RDW ? 2 * KPW : RDW;      // up to TWO tiles ahead (RD divides 2 * KPW)
+  // patch prefetch depth in tiles: a 3x3 tile with one ci tile per wave is only 1-2 us of MFMAs -- less than the latency of
+  // the loads issued at its start -- so those kernels keep two tiles of raw patch data in flight
+  static constexpr int PDX = (KS == 3 && NT == 1 && KPW <= 4) ? 2 : 1;
 };
 
-template <int KS, int NT, int WM>
+// MASKED: W % 8 != 0 -- an 8-pixel group may straddle the end of an image row, so every element is range-checked on its own
+// (an out-of-row element gets an out-of-range buffer offset and reads as zero)
+template <int KS, int NT, int WM, int TCv, bool MASKED>
 __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
-  using Gm = Wgrad3Geom<KS, NT, WM>;
-  constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI;
-  constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KPW = Gm::KPW, RD = Gm::RD;
+  using Gm = Wgrad3Geom<KS, NT, WM, TCv>;
+  constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI, SEG = Gm::SEG;
+  constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KPW = Gm::KPW, RD = Gm::RD, PDX = Gm::PDX;
   PNSFM_DYN_SMEM(unsigned char, smem);
 
   const int tid = threadIdx.x;
@@ -119,7 +127,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     it_r[it] = rem / (RS / 8);
     it_g[it] = rem - it_r[it] * (RS / 8);
   }
-  float raw[NIT][8];
+  float raw[PDX][NIT][8];
   auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
     b = t / a.tiles_per_img;
     const int tt = t - b * a.tiles_per_img;
@@ -127,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     y0 = ty * TR;
     x0 = (tt - ty * a.tiles_x) * TC;
   };
-  auto load_patch = [&](int t) {
+  auto load_patch = [&](float (&rw)[NIT][8], int t) {
     int b, y0, x0;
     tile_origin(t, b, y0, x0);
     // descriptor over channels [ci0, Cin) of image b: channels past Cin read as zero
@@ -139,14 +147,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
       const unsigned off = ok ? (unsigned)((it_ci[it] * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) raw[it][u] = pnsfm_buf_load(buf, off + 4u * u, 0);
+      for (int u = 0; u < 8; ++u) rw[it][u] = pnsfm_buf_load(buf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
     }
   };
-  auto write_patch = [&]() {
+  auto write_patch = [&](const float (&rw)[NIT][8]) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       pnsfm_u32x4 Hh, Mm, Ll;
-      w3_split8(raw[it], Hh, Mm, Ll);
+      w3_split8(rw[it], Hh, Mm, Ll);
       unsigned char* d = smem + (size_t)(it_ci[it] * CS + it_r[it] * RS + 8 * it_g[it]) * 2;
       *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
       *reinterpret_cast<pnsfm_u32x4*>(d + PIECE * 2) = Mm;
@@ -154,23 +162,23 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     }
   };
 
-  // ---- A operand: dY[co0 + l32][8 pixels] of k-step q (row q / 2, columns 16 * (q & 1) + 8 * half ..) straight from global
+  // ---- A operand: dY[co0 + l32][8 pixels] of k-step q (row q / SEG, columns 16 * (q % SEG) + 8 * half ..) straight from global
   float araw[RD][8];
   auto load_a = [&](float (&dst)[8], int t, int q) {
     int b, y0, x0;
     tile_origin(t, b, y0, x0);
     const pnsfm_buf buf = pnsfm_make_buf(a.dy + (size_t)b * a.Cout * HW, (unsigned)((long)a.Cout * HW * 4));
-    const int yy = y0 + (q >> 1), xx = x0 + 16 * (q & 1) + 8 * half;
+    const int yy = y0 + q / SEG, xx = x0 + 16 * (q % SEG) + 8 * half;
     const bool ok = yy < H && xx < W;
     const unsigned off = ok ? (unsigned)(((co0 + l32) * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(buf, off + 4u * u, 0);
+    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(buf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
   };
 
   const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
 
   auto kstep = [&](const pnsfm_u32x4 (&A)[3], int q) {
-    const int koff = ((q >> 1) * RS + 16 * (q & 1)) * 2;
+    const int koff = ((q / SEG) * RS + 16 * (q % SEG)) * 2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
@@ -214,30 +222,40 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     }
   };
 
-  if (t_begin < t_end) {
-    load_patch(t_begin);
+  // ---- main loop over this split's pixel tiles, unrolled by two so that ring slots are compile-time:
+  //   patch: raw[par % PDX] holds tile t's rows; once written to LDS it is refilled with tile t + PDX;
+  //   dY:    k-step i of the tile with parity par sits in ring slot (par * KPW + i) % RD and is replaced, as soon as it has been
+  //          split, by the fragment RD k-steps further down this wave's sequence (same tile, next tile or the one after).
 #pragma unroll
-    for (int i = 0; i < RD; ++i) load_a(araw[i], t_begin, wk + WK * i);
-  }
-  for (int t = t_begin; t < t_end; ++t) {
-    __syncthreads();           // every wave is done with the previous tile's patch
-    write_patch();
-    __syncthreads();
-    if (t + 1 < t_end) load_patch(t + 1);          // lands behind this tile's MFMAs
-    // this wave's k-steps: q = wk, wk + WK, ...; the dY fragment of k-step i sits in ring slot i % RD and is replaced, as soon
-    // as it has been split, by the fragment RD k-steps ahead (of this tile or the next)
+  for (int p = 0; p < PDX; ++p)
+    if (t_begin + p < t_end) load_patch(raw[p], t_begin + p);
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-      const int q = wk + WK * i;
-      pnsfm_u32x4 A[3];
-      w3_split8(araw[i % RD], A[0], A[1], A[2]);
-      if (do_bias) {
+  for (int L = 0; L < RD; ++L)
+    if (t_begin + L / KPW < t_end) load_a(araw[L], t_begin + L / KPW, wk + WK * (L % KPW));
+  for (int t0 = t_begin; t0 < t_end; t0 += 2) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bsum += araw[i % RD][u];
+    for (int par = 0; par < 2; ++par) {
+      const int t = t0 + par;
+      if (t < t_end) {
+        __syncthreads();           // every wave is done with the previous tile's patch
+        write_patch(raw[par % PDX]);
+        __syncthreads();
+        if (t + PDX < t_end) load_patch(raw[par % PDX], t + PDX);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          constexpr int dummy = 0; (void)dummy;
+          const int slot = (par * KPW + i) % RD;
+          pnsfm_u32x4 A[3];
+          w3_split8(araw[slot], A[0], A[1], A[2]);
+          if (do_bias) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bsum += araw[slot][u];
+          }
+          const int dt = (i + RD) / KPW, ni = (i + RD) % KPW;
+          if (t + dt < t_end) load_a(araw[slot], t + dt, wk + WK * ni);
+          kstep(A, wk + WK * i);
+        }
       }
-      if (i + RD < KPW) load_a(araw[i % RD], t, q + WK * RD);
-      else if (t + 1 < t_end) load_a(araw[i % RD], t + 1, wk + WK * (i + RD - KPW));
-      kstep(A, q);
     }
   }
 
@@ -336,23 +354,28 @@ __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restr
 }
 
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks) {
-  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) return false;
-  return W % 8 == 0 && Cin >= 16 && Cout >= 16 && H >= 1;
+  if (ks != 3 && ks != 5 && ks != 7) return false;
+  return W >= 1 && Cin >= 16 && Cout >= 16 && H >= 1;
+}
+// tile width: 32 columns unless 16 wastes fewer (W = 40: 64 vs 48 columns per row) or the rows need per-element masking
+static int wgrad3_tc(int W) {
+  if (W % 8 != 0) return 16;
+  return round_up(W, 16) < round_up(W, 32) ? 16 : 32;
 }
 static int wgrad3_WM(int Cout) { return Cout > 96 ? 4 : (Cout > 32 ? 2 : 1); }
-int wgrad3_total_tiles(int B, int H, int W) { return B * ceil_div(W, 32) * ceil_div(H, 4); }
+int wgrad3_total_tiles(int B, int H, int W) { return B * ceil_div(W, wgrad3_tc(W)) * ceil_div(H, 4); }
 int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT) {
   return ceil_div(Cin, 32 * NT) * ks * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout));
 }
 bool wgrad3_nt2_ok(int Cin, int ks) { return ks <= 3 && Cin > 32; }
 
-template <int KS, int NT, int WM>
+template <int KS, int NT, int WM, int TC, bool MASKED>
 static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
-  using Gm = Wgrad3Geom<KS, NT, WM>;
+  using Gm = Wgrad3Geom<KS, NT, WM, TC>;
 #ifndef PNSFM_EMU
   static bool raised = false;
   if (!raised && Gm::SMEM > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
       return -1;
@@ -360,7 +383,7 @@ static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
     raised = true;
   }
 #endif
-  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
+  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
   return check_launch("conv2d_backward_weight (split-bf16)");
 }
 
@@ -371,7 +394,9 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-  a.tiles_x = ceil_div(W, 32);
+  const int tc = wgrad3_tc(W);
+  const bool masked = W % 8 != 0;
+  a.tiles_x = ceil_div(W, tc);
   a.tiles_per_img = a.tiles_x * ceil_div(H, 4);
   a.total_tiles = B * a.tiles_per_img;
   if (split < 1) split = 1;
@@ -397,16 +422,22 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   }
   dim3 grid(a.ci_tiles * ks, co_groups, splitP);
   int rc = 0;
+#define PNSFM_W3T(KSv, NTv, WMv)                                                    \
+  do {                                                                              \
+    if (masked) rc = launch_wgrad3<KSv, NTv, WMv, 16, true>(a, grid, s);            \
+    else if (tc == 16) rc = launch_wgrad3<KSv, NTv, WMv, 16, false>(a, grid, s);    \
+    else rc = launch_wgrad3<KSv, NTv, WMv, 32, false>(a, grid, s);                  \
+  } while (0)
 #define PNSFM_W3(KSv, NTv)                                                \
   do {                                                                    \
-    if (WM == 4) rc = launch_wgrad3<KSv, NTv, 4>(a, grid, s);             \
-    else if (WM == 2) rc = launch_wgrad3<KSv, NTv, 2>(a, grid, s);        \
-    else rc = launch_wgrad3<KSv, NTv, 1>(a, grid, s);                     \
+    if (WM == 4) PNSFM_W3T(KSv, NTv, 4);                                  \
+    else if (WM == 2) PNSFM_W3T(KSv, NTv, 2);                             \
+    else PNSFM_W3T(KSv, NTv, 1);                                          \
   } while (0)
-  if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); else PNSFM_W3(1, 1); }
-  else if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
+  if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
   else if (ks == 5) PNSFM_W3(5, 1);
   else PNSFM_W3(7, 1);
+#undef PNSFM_W3T
 #undef PNSFM_W3
   if (a.ws) {
     if (!rc) {

@@ -87,7 +87,10 @@ class PackedConvWeight:
 
 
 class _WgradStream:
-    """Weight gradients on a side HIP stream (PNSFM_WGRAD_STREAM=1).
+    """Weight gradients on a side HIP stream (PNSFM_WGRAD_STREAM=1; OFF by default since the split-bf16 kernels: with every conv
+    kernel filling the chip on its own, co-scheduling weight- and data-gradient kernels measured 116.6 img/s against 123.8
+    in-line -- the two contend for the same matrix pipes and LDS, and the event traffic costs launches.  It paid with the
+    f32-MFMA kernels of round 1 (+4 %), whose low-resolution layers left CUs idle.)
 
     Within a layer's backward the data gradient is on the critical path (the next layer waits for it) while the weight
     gradient is only needed by the optimizer / the gradient all-reduce.  With a second stream the GPU can co-schedule
@@ -104,7 +107,7 @@ class _WgradStream:
     side stream next to the node's own data gradient, but the compute stream waits for it before the node returns.
     """
     import os as _os
-    enabled = _os.environ.get('PNSFM_WGRAD_STREAM', '1') == '1'
+    enabled = _os.environ.get('PNSFM_WGRAD_STREAM', '0') == '1'
     _streams = {}
     _pending = set()
     _uses = {}          # id(parameter) -> [forward uses whose backward has not run yet, shared-in-this-step flag]

@@ -251,7 +251,9 @@ WGRAD2_SHAPES = [  # (B, Cin, Cout, H, W, k): shapes the tap-major weight-gradie
 ]
 
 
-@pytest.mark.parametrize('shape', WGRAD2_SHAPES + [(1, 64, 64, 48, 160, 7), (2, 64, 256, 24, 80, 7), (1, 2048, 64, 8, 80, 5)])
+@pytest.mark.parametrize('shape', [sh for sh in WGRAD2_SHAPES if sh[5] != 1] +
+                         [(1, 64, 64, 48, 160, 7), (2, 64, 256, 24, 80, 7), (1, 2048, 64, 8, 80, 5), (4, 512, 512, 6, 20, 3), (2, 4096, 128, 6, 20, 3),
+                          (8, 2048, 64, 96, 4, 5)])
 def test_conv2d_wgrad_split_bf16_vs_cpu_oracle(shape):
     """csrc/conv2d_wgrad3.hip pinned (autotuner off) vs the oracle's conv weight/bias gradient -- same tolerance as the f32
     kernels."""

@@ -167,12 +167,14 @@ def test_conv2d_wgrad_tap_major(emulated_kernels, shape):
         lib.pnsfm_set_wgrad_variant(-1)
 
 
-@pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
-                                   (1, 40, 64, 6, 24, 5), (3, 17, 31, 7, 40, 1), (1, 32, 40, 6, 40, 7), (1, 48, 129, 5, 16, 3)])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 3),
+                                   (1, 40, 64, 6, 24, 5), (1, 32, 40, 6, 40, 7), (1, 48, 129, 5, 16, 3), (2, 40, 24, 6, 20, 3),
+                                   (1, 16, 32, 9, 4, 5), (1, 32, 16, 3, 80, 3)])
 def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
-    """The split-bf16 weight-gradient kernel (csrc/conv2d_wgrad3.hip) vs torch: k in {1, 3, 5, 7} (even and odd operand shifts),
-    one and two ci tiles per wave, 1 / 2 / 4 co tiles per workgroup, widths that do not fill the 32-column tile, heights that
-    do not fill its 4 rows, odd channel counts -- the library default under the split arithmetic, pinned here."""
+    """The split-bf16 weight-gradient kernel (csrc/conv2d_wgrad3.hip) vs torch: k in {3, 5, 7} (even and odd operand shifts),
+    one and two ci tiles per wave, 1 / 2 / 4 co tiles per workgroup, 32- and 16-column tiles, widths that are not a multiple
+    of 8 (per-element masking: 20, 4), heights that do not fill the 4 tile rows, odd channel counts, single-split (direct
+    stores) and pixel-split (two-stage reduction) launches -- the library default under the split arithmetic, pinned here."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     lib = _lib.get()

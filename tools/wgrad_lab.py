@@ -8,7 +8,10 @@ from packnet_sfm.hip import _lib, ops, functional as HF
 dev = torch.device('cuda:0')
 SHAPES = [(4, 64, 64, 192, 640, 7), (4, 64, 256, 96, 320, 7), (4, 256, 64, 96, 320, 7), (4, 129, 64, 192, 640, 3),
           (4, 64, 64, 96, 320, 3), (4, 256, 256, 24, 80, 3), (4, 512, 512, 12, 40, 3), (4, 8192, 256, 12, 40, 3),
-          (8, 2048, 64, 4, 320, 5), (4, 512, 128, 24, 80, 5), (4, 128, 128, 48, 160, 3)]
+          (8, 2048, 64, 4, 320, 5), (4, 512, 128, 24, 80, 5), (4, 128, 128, 48, 160, 3), (4, 16384, 512, 6, 20, 3),
+          (4, 512, 512, 6, 20, 3), (8, 2048, 64, 96, 4, 5)]
+if len(sys.argv) > 1:
+    SHAPES = SHAPES[int(sys.argv[1]):]
 
 
 def timeit(fn, reps=5):
@@ -21,7 +24,7 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for mode in ('f32', 'bx3'):
+for mode in ('bx3',):
     HF.set_conv_math(mode)
     for shape in SHAPES:
         B, Cin, Cout, H, W, ks = shape

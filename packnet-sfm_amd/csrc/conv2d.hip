@@ -1361,7 +1361,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     return check_launch("conv2d_backward_weight");
   };
   // split-bf16 kernel (conv2d_wgrad3.hip): part of the split arithmetic mode (pnsfm_set_conv_math), the default there
-  const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H0, W0, ks);
+  const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H0, W0, ks) && wgrad3_fits(B, Cin, Cout, H0, W0);
   auto v3_default_split = [&](int NT) -> int {
     const int base = wgrad3_base_blocks(Cin, Cout, ks, NT), tiles = wgrad3_total_tiles(B, H0, W0);
     int split = (2 * 256 + base - 1) / base;            // two workgroups per CU

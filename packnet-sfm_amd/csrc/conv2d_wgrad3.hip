@@ -117,37 +117,53 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
   float bsum = 0.f;
   const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;      // ci tile 0, kernel row 0
 
-  // ---- patch items of this thread: (channel, row, 8-column group); the LDS slot is fixed, the global offset per tile
-  int it_ci[NIT], it_r[NIT], it_g[NIT];
+  // ---- tile cursors.  Index arithmetic is kept out of the loop: a tile's origin (image, first row, first column) is advanced
+  // incrementally in scalar registers for the current tile and the two behind it (the prefetch targets), and every per-lane
+  // byte offset is split into a loop-invariant lane part and a per-tile scalar part (ONE descriptor per tensor: rows of
+  // padded channels past Cin / Cout read the next image's data or zero, and feed accumulator rows that are never stored).
+  struct Cur { int b, y0, x0; };
+  const int tiles_y = a.tiles_per_img / a.tiles_x;
+  auto advance = [&](Cur& c) {
+    c.x0 += TC;
+    if (c.x0 >= a.tiles_x * TC) {
+      c.x0 = 0;
+      c.y0 += TR;
+      if (c.y0 >= tiles_y * TR) { c.y0 = 0; ++c.b; }
+    }
+  };
+  Cur cur[3];
+  {
+    const int b = t_begin / a.tiles_per_img, tt = t_begin - b * a.tiles_per_img, ty = tt / a.tiles_x;
+    cur[0].b = b; cur[0].y0 = ty * TR; cur[0].x0 = (tt - ty * a.tiles_x) * TC;
+    cur[1] = cur[0]; advance(cur[1]);
+    cur[2] = cur[1]; advance(cur[2]);
+  }
+  const pnsfm_buf xbuf = pnsfm_make_buf(a.x, (unsigned)((size_t)a.B * a.Cin * HW * 4));
+  const pnsfm_buf dybuf = pnsfm_make_buf(a.dy, (unsigned)((size_t)a.B * a.Cout * HW * 4));
+
+  // patch items of this thread: (channel, row, 8-column group); LDS slot and lane part of the global offset are fixed
+  int it_lds[NIT], it_ry[NIT], it_gx[NIT], it_lane[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = it * 256 + tid;
-    it_ci[it] = e / (TR * (RS / 8));
-    const int rem = e - it_ci[it] * (TR * (RS / 8));
-    it_r[it] = rem / (RS / 8);
-    it_g[it] = rem - it_r[it] * (RS / 8);
+    const int ci = e / (TR * (RS / 8));
+    const int rem = e - ci * (TR * (RS / 8));
+    const int r = rem / (RS / 8), g = rem - r * (RS / 8);
+    it_lds[it] = (ci * CS + r * RS + 8 * g) * 2;
+    it_ry[it] = r + ky - P;                       // image row = y0 + it_ry
+    it_gx[it] = 8 * g - 8;                        // image column = x0 + it_gx
+    it_lane[it] = ((ci0 + ci) * HW + it_ry[it] * W + it_gx[it]) * 4;
   }
   float raw[PDX][NIT][8];
-  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
-    b = t / a.tiles_per_img;
-    const int tt = t - b * a.tiles_per_img;
-    const int ty = tt / a.tiles_x;
-    y0 = ty * TR;
-    x0 = (tt - ty * a.tiles_x) * TC;
-  };
-  auto load_patch = [&](float (&rw)[NIT][8], int t) {
-    int b, y0, x0;
-    tile_origin(t, b, y0, x0);
-    // descriptor over channels [ci0, Cin) of image b: channels past Cin read as zero
-    const long rem = (long)(a.Cin - ci0) * HW * 4;
-    const pnsfm_buf buf = pnsfm_make_buf(a.x + ((size_t)b * a.Cin + ci0) * HW, (unsigned)(rem > 0 ? rem : 0));
+  auto load_patch = [&](float (&rw)[NIT][8], const Cur& c) {
+    const int sbase = (c.b * a.Cin * HW + c.y0 * W + c.x0) * 4;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int yy = y0 + it_r[it] + ky - P, xx = x0 - 8 + 8 * it_g[it];
+      const int yy = c.y0 + it_ry[it], xx = c.x0 + it_gx[it];
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const unsigned off = ok ? (unsigned)((it_ci[it] * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
+      const unsigned off = ok ? (unsigned)(sbase + it_lane[it]) : PNSFM_DMA_INVALID;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rw[it][u] = pnsfm_buf_load(buf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
+      for (int u = 0; u < 8; ++u) rw[it][u] = pnsfm_buf_load(xbuf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
     }
   };
   auto write_patch = [&](const float (&rw)[NIT][8]) {
@@ -155,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     for (int it = 0; it < NIT; ++it) {
       pnsfm_u32x4 Hh, Mm, Ll;
       w3_split8(rw[it], Hh, Mm, Ll);
-      unsigned char* d = smem + (size_t)(it_ci[it] * CS + it_r[it] * RS + 8 * it_g[it]) * 2;
+      unsigned char* d = smem + it_lds[it];
       *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
       *reinterpret_cast<pnsfm_u32x4*>(d + PIECE * 2) = Mm;
       *reinterpret_cast<pnsfm_u32x4*>(d + 2 * PIECE * 2) = Ll;
@@ -164,15 +180,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
 
   // ---- A operand: dY[co0 + l32][8 pixels] of k-step q (row q / SEG, columns 16 * (q % SEG) + 8 * half ..) straight from global
   float araw[RD][8];
-  auto load_a = [&](float (&dst)[8], int t, int q) {
-    int b, y0, x0;
-    tile_origin(t, b, y0, x0);
-    const pnsfm_buf buf = pnsfm_make_buf(a.dy + (size_t)b * a.Cout * HW, (unsigned)((long)a.Cout * HW * 4));
-    const int yy = y0 + q / SEG, xx = x0 + 16 * (q % SEG) + 8 * half;
+  const int a_lane = ((co0 + l32) * HW + 8 * half) * 4;
+  auto load_a = [&](float (&dst)[8], const Cur& c, int q) {
+    const int yy = c.y0 + q / SEG, xs = c.x0 + 16 * (q % SEG);
+    const int xx = xs + 8 * half;
     const bool ok = yy < H && xx < W;
-    const unsigned off = ok ? (unsigned)(((co0 + l32) * HW + yy * W + xx) * 4) : PNSFM_DMA_INVALID;
+    const unsigned off = ok ? (unsigned)(a_lane + (c.b * a.Cout * HW + yy * W + xs) * 4) : PNSFM_DMA_INVALID;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(buf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
+    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(dybuf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
   };
 
   const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
@@ -228,10 +243,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
   //          split, by the fragment RD k-steps further down this wave's sequence (same tile, next tile or the one after).
 #pragma unroll
   for (int p = 0; p < PDX; ++p)
-    if (t_begin + p < t_end) load_patch(raw[p], t_begin + p);
+    if (t_begin + p < t_end) load_patch(raw[p], cur[p]);
 #pragma unroll
   for (int L = 0; L < RD; ++L)
-    if (t_begin + L / KPW < t_end) load_a(araw[L], t_begin + L / KPW, wk + WK * (L % KPW));
+    if (t_begin + L / KPW < t_end) load_a(araw[L], cur[L / KPW], wk + WK * (L % KPW));
   for (int t0 = t_begin; t0 < t_end; t0 += 2) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -240,10 +255,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
         __syncthreads();           // every wave is done with the previous tile's patch
         write_patch(raw[par % PDX]);
         __syncthreads();
-        if (t + PDX < t_end) load_patch(raw[par % PDX], t + PDX);
+        if (t + PDX < t_end) load_patch(raw[par % PDX], cur[PDX]);
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-          constexpr int dummy = 0; (void)dummy;
           const int slot = (par * KPW + i) % RD;
           pnsfm_u32x4 A[3];
           w3_split8(araw[slot], A[0], A[1], A[2]);
@@ -251,10 +265,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) bsum += araw[slot][u];
           }
-          const int dt = (i + RD) / KPW, ni = (i + RD) % KPW;
-          if (t + dt < t_end) load_a(araw[slot], t + dt, wk + WK * ni);
+          const int dt = (i + RD) / KPW, ni = (i + RD) % KPW;       // dt <= 2
+          if (t + dt < t_end) load_a(araw[slot], cur[dt], wk + WK * ni);
           kstep(A, wk + WK * i);
         }
+        cur[0] = cur[1]; cur[1] = cur[2]; advance(cur[2]);
       }
     }
   }
@@ -326,26 +341,32 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
 }
 
 // second stage of a pixel-split launch: dW[co][ci][ky][kx] = sum over the Z partial tensors, in a fixed order (deterministic),
-// written as contiguous (ci, tap) runs through LDS.  One workgroup per (co, 32 input channels).
+// written as contiguous (ci, tap) runs through LDS.  One workgroup per (co, 32 input channels); the 256 threads are
+// 8 z-groups x 32 channels: z-group g sums partials g, g + 8, ... of every tap, the groups meet in LDS in a fixed order.
 __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_bias,
                                                             float* __restrict__ dw, float* __restrict__ dbias, int Z, int KS,
                                                             int COP, int CIP, int Cin, int Cout) {
-  __shared__ float tile[32 * 49];
+  __shared__ float part[8][32 * 49];
   const int co = blockIdx.x, cib = blockIdx.y, KK = KS * KS;
+  const int zg = threadIdx.x >> 5, cil = threadIdx.x & 31;
   const size_t zstride = (size_t)KS * COP * KS * CIP;
-  for (int e = threadIdx.x; e < KK * 32; e += 256) {
-    const int tap = e >> 5, cil = e & 31;
+  for (int tap = 0; tap < KK; ++tap) {
     const int ky = tap / KS, kx = tap - ky * KS;
     const float* p = ws + (((size_t)ky * COP + co) * KS + kx) * CIP + cib * 32 + cil;
     float sum = 0.f;
-    for (int z = 0; z < Z; ++z) sum += p[z * zstride];
-    tile[cil * KK + tap] = sum;
+    for (int z = zg; z < Z; z += 8) sum += p[z * zstride];
+    part[zg][cil * KK + tap] = sum;
   }
   __syncthreads();
   int nci = Cin - cib * 32;
   if (nci > 32) nci = 32;
   float* out = dw + ((size_t)co * Cin + cib * 32) * KK;
-  for (int e = threadIdx.x; e < nci * KK; e += 256) out[e] = tile[e];
+  for (int e = threadIdx.x; e < nci * KK; e += 256) {
+    float sum = part[0][e];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) sum += part[g][e];
+    out[e] = sum;
+  }
   if (dbias && cib == 0 && threadIdx.x == 0) {
     float sum = 0.f;
     for (int z = 0; z < Z; ++z) sum += ws_bias[(size_t)z * COP + co];
@@ -356,6 +377,9 @@ __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restr
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks) {
   if (ks != 3 && ks != 5 && ks != 7) return false;
   return W >= 1 && Cin >= 16 && Cout >= 16 && H >= 1;
+}
+bool wgrad3_fits(int B, int Cin, int Cout, int H, int W) {      // one buffer descriptor per tensor, 31-bit byte offsets
+  return (size_t)B * Cin * H * W * 4 < (1ull << 31) && (size_t)B * Cout * H * W * 4 < (1ull << 31);
 }
 // tile width: 32 columns unless 16 wastes fewer (W = 40: 64 vs 48 columns per row) or the rows need per-element masking
 static int wgrad3_tc(int W) {
@@ -390,6 +414,10 @@ static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
                    int split, int NT, hipStream_t s) {
   if (!wgrad3_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (split-bf16): unsupported shape"); return -1; }
+  if ((size_t)B * Cin * H * W * 4 >= (1ull << 31) || (size_t)B * Cout * H * W * 4 >= (1ull << 31)) {
+    set_error("conv2d_backward_weight (split-bf16): tensor too large for 32-bit buffer offsets");
+    return -1;
+  }
   if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;

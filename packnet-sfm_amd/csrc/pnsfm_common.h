@@ -189,6 +189,7 @@ int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int
 // split-bf16 weight-gradient kernel (conv2d_wgrad3.hip)
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks);
 bool wgrad3_nt2_ok(int Cin, int ks);
+bool wgrad3_fits(int B, int Cin, int Cout, int H, int W);
 int wgrad3_total_tiles(int B, int H, int W);
 int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT);
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,

@@ -126,7 +126,8 @@ def measured_traffic():
     if not files:
         return None
     try:
-        d = json.load(open(files[-1]))['pnsfm::conv2d_mfma_kernel']
+        d = json.load(open(files[-1]))
+        d = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
         return {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
                 round(d.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(files[-1], ROOT)}
     except Exception:

@@ -1246,8 +1246,11 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
   if (bxf || bxb) {
     const int nchF = KPf / 16, nchB = KPb / 16;
     const int nf = bxf ? (MPf / 32) * nchF : 0, nb = bxb ? (MPb / 32) * nchB : 0;
-    PNSFM_LAUNCH(pack_bx3_kernel, dim3(nf + nb), dim3(256), 0, s, w, reinterpret_cast<unsigned char*>(bxf ? wp_fwd : nullptr),
-                 reinterpret_cast<unsigned char*>(bxb ? wp_bwd : nullptr), Cin, Cout, KK, nchF, nchB, nf);
+    unsigned char* const pf = reinterpret_cast<unsigned char*>(bxf ? wp_fwd : nullptr);
+    unsigned char* const pb = reinterpret_cast<unsigned char*>(bxb ? wp_bwd : nullptr);
+    if (ks == 3) PNSFM_LAUNCH((pack_bx3_kernel<3>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
+    else if (ks == 5) PNSFM_LAUNCH((pack_bx3_kernel<5>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
+    else PNSFM_LAUNCH((pack_bx3_kernel<7>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
   }
   return check_launch("pack_weights");
 }

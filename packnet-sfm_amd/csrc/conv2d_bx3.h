@@ -280,12 +280,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
 // ---- weight packer for the bx3 kernels: fp32 [Cout][Cin][k][k] -> the split LDS images described above.
 //   forward : M = Cout, K = Cin :  A[m][k][tap] = w[m][k][tap]
 //   backward: M = Cin,  K = Cout:  A[m][k][tap] = w[k][m][KK-1-tap]       (taps flipped: dX = conv(dY, rot180(W)^T))
-// One block per (32-row m-block, 16-channel chunk); taps go through LDS in segments of 8 so that global reads stay runs of
-// (channel, tap) and every output tap is written as one contiguous 3072-byte slab.
+// One block per (32-row m-block, 16-channel chunk); taps go through LDS -- all 9 of a 3x3 at once, one kernel row at a time for
+// 5x5 / 7x7 -- so that global reads are runs of (channel, tap) and every output tap is written as one contiguous 3072-byte
+// slab.  KS is a template parameter: the index arithmetic of the copy loops divides by compile-time constants only.
+template <int KS>
 __global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
-                                                       unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int KK, int nchF,
+                                                       unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int nchF,
                                                        int nchB, int nf) {
-  constexpr int TSEG = 8;
+  constexpr int KK = KS * KS, TSEG = (KS == 3) ? 9 : KS;
   __shared__ float tile[TSEG][16][33];
   int blk = blockIdx.x;
   const bool fwd = blk < nf;
@@ -296,26 +298,25 @@ __global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__
   const int m0 = mb * 32, k0 = ch * 16;
   const int Mn = fwd ? Cout : Cin, Kn = fwd ? Cin : Cout;
   for (int t0 = 0; t0 < KK; t0 += TSEG) {
-    const int nt = (KK - t0 < TSEG) ? KK - t0 : TSEG;
     if (fwd) {
       // for a row m: (k, tap) is contiguous in w
-      for (int e = threadIdx.x; e < 32 * 16 * nt; e += 256) {
-        const int m = e / (16 * nt), r = e - m * (16 * nt), k = r / nt, tt = r - k * nt;
+      for (int e = threadIdx.x; e < 32 * 16 * TSEG; e += 256) {
+        const int m = e / (16 * TSEG), r = e - m * (16 * TSEG), k = r / TSEG, tt = r - k * TSEG;
         float v = 0.f;
         if (m0 + m < Mn && k0 + k < Kn) v = w[((size_t)(m0 + m) * Cin + k0 + k) * KK + t0 + tt];
         tile[tt][k][m] = v;
       }
     } else {
       // for a K row (an output channel of w): (m = ci, tap) is contiguous in w; output tap t reads source tap KK-1-t
-      for (int e = threadIdx.x; e < 16 * 32 * nt; e += 256) {
-        const int k = e / (32 * nt), r = e - k * (32 * nt), m = r / nt, tt = r - m * nt;
+      for (int e = threadIdx.x; e < 16 * 32 * TSEG; e += 256) {
+        const int k = e / (32 * TSEG), r = e - k * (32 * TSEG), m = r / TSEG, tt = r - m * TSEG;
         float v = 0.f;
         if (m0 + m < Mn && k0 + k < Kn) v = w[((size_t)(k0 + k) * Cin + m0 + m) * KK + (KK - 1 - (t0 + tt))];
         tile[tt][k][m] = v;
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nt * 64; e += 256) {
+    for (int e = threadIdx.x; e < TSEG * 64; e += 256) {
       const int tt = e >> 6, kh = (e >> 5) & 1, m = e & 31;
       float v[8];
 #pragma unroll

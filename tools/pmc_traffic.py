@@ -37,16 +37,22 @@ for k in f:
               'hbm_bytes_per_launch': fb + wb}
 if layer_csv:
     # algorithmic bytes of a conv launch = its input + output + weight tensors once (fp32)
-    acc = {'0': [0.0, 0], '1': [0.0, 0]}
+    acc = {}
     for r in csv.DictReader(open(layer_csv)):
         B, Cin, Cout, H, W, ks = (int(r[k]) for k in ('B', 'Cin', 'Cout', 'H', 'W', 'ks'))
         px = H if r['kind'] == '1' else H * W          # the wgrad rows carry H*W in the H column
         by = 4.0 * (B * Cin * px + B * Cout * px + Cout * Cin * ks * ks)
-        acc[r['kind']][0] += by
-        acc[r['kind']][1] += 1
-    for kind, name in (('0', 'pnsfm::conv2d_mfma_kernel'), ('1', 'pnsfm::conv2d_wgrad_kernel')):
-        if name in res and acc[kind][1]:
-            res[name]['algorithmic_bytes_per_launch'] = acc[kind][0] / acc[kind][1]
+        # which kernel family ran the launch: the split-bf16 kernels take >= 16 K-channels and k >= 3 (the autotuner may
+        # still have preferred an f32 kernel for a few weight-gradient shapes, e.g. W = 20)
+        split = Cin >= 16 and ks >= 3 and (r['kind'] == '0' or Cout >= 16)
+        name = {('0', True): 'pnsfm::conv2d_bx3_kernel', ('0', False): 'pnsfm::conv2d_mfma_kernel',
+                ('1', True): 'pnsfm::conv2d_wgrad3_kernel', ('1', False): 'pnsfm::conv2d_wgrad_kernel'}[(r['kind'], split)]
+        a = acc.setdefault(name, [0.0, 0])
+        a[0] += by
+        a[1] += 1
+    for name, a in acc.items():
+        if name in res and a[1]:
+            res[name]['algorithmic_bytes_per_launch'] = a[0] / a[1]
 res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` with a '
                 'primed tuning database (PNSFM_TUNE_DB: every launch is a training-step launch, no autotune candidates); '
                 'bytes = counter*1024 averaged over the launches of each kernel; FETCH_SIZE is quoted raw (4-byte/lane loads are '

@@ -22,8 +22,8 @@
 //   * the WK pixel shares of a workgroup are summed through LDS; pixel tiles are split over blockIdx.z and the partial
 //     tensors of a split launch go to a scratch buffer ([split][ky][co][kx][ci]: coalesced stores) that a second kernel sums
 //     in a fixed order -- no atomics anywhere: the gradient is bit-reproducible run to run.
-// Widths that are not a multiple of 8 (20, 4, 2: 8-pixel groups straddle the row end) run a variant that range-checks every
-// element; tiles are 4 rows x 32 columns, or 4 x 16 where that wastes fewer columns (W = 40, 80, 20).  k = 3, 5, 7.
+// Widths that are a multiple of 4 but not of 8 (20, 4: the upper half of an 8-pixel group may lie past the row end) run a
+// variant that range-checks the two halves separately; tiles are 4 rows x 32 columns, or 4 x 16 where that wastes fewer columns (W = 40, 80, 20).  k = 3, 5, 7.
 // Roofline: MFMA-bound: 2*Cout*Cin*K*K*B*H*W algorithmic flop against 2500/6 TFLOP/s (bf16 dense peak / 6 products).
 #include "pnsfm_common.h"
 #include "../../include/pnsfm.h"
@@ -87,8 +87,8 @@ struct Wgrad3Geom {
   static constexpr int PDX = (KS == 3 && NT == 1 && KPW <= 4) ? 2 : 1;
 };
 
-// MASKED: W % 8 != 0 -- an 8-pixel group may straddle the end of an image row, so every element is range-checked on its own
-// (an out-of-row element gets an out-of-range buffer offset and reads as zero)
+// MASKED: W % 8 == 4 -- the upper half of an 8-pixel group may lie past the end of an image row: the two 4-pixel halves are
+// range-checked separately (an out-of-row half gets an out-of-range buffer offset and reads as zero)
 template <int KS, int NT, int WM, int TCv, bool MASKED>
 __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
   using Gm = Wgrad3Geom<KS, NT, WM, TCv>;
@@ -162,8 +162,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
       const int yy = c.y0 + it_ry[it], xx = c.x0 + it_gx[it];
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
       const unsigned off = ok ? (unsigned)(sbase + it_lane[it]) : PNSFM_DMA_INVALID;
+      // MASKED (W % 8 == 4): the upper 4 pixels of the group may lie past the row end -- they get their own range check
+      const unsigned off4 = (MASKED && xx + 4 >= W) ? PNSFM_DMA_INVALID : off + 16u;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rw[it][u] = pnsfm_buf_load(xbuf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
+      for (int u = 0; u < 8; ++u) rw[it][u] = pnsfm_buf_load(xbuf, u < 4 ? off + 4u * u : off4 + 4u * (u - 4), 0);
     }
   };
   auto write_patch = [&](const float (&rw)[NIT][8]) {
@@ -186,8 +188,9 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     const int xx = xs + 8 * half;
     const bool ok = yy < H && xx < W;
     const unsigned off = ok ? (unsigned)(a_lane + (c.b * a.Cout * HW + yy * W + xs) * 4) : PNSFM_DMA_INVALID;
+    const unsigned off4 = (MASKED && xx + 4 >= W) ? PNSFM_DMA_INVALID : off + 16u;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(dybuf, (MASKED && xx + u >= W) ? PNSFM_DMA_INVALID : off + 4u * u, 0);
+    for (int u = 0; u < 8; ++u) dst[u] = pnsfm_buf_load(dybuf, u < 4 ? off + 4u * u : off4 + 4u * (u - 4), 0);
   };
 
   const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restr
 
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks) {
   if (ks != 3 && ks != 5 && ks != 7) return false;
-  return W >= 1 && Cin >= 16 && Cout >= 16 && H >= 1;
+  return W % 4 == 0 && Cin >= 16 && Cout >= 16 && H >= 1;      // rows of 4-pixel groups (16-byte aligned)
 }
 bool wgrad3_fits(int B, int Cin, int Cout, int H, int W) {      // one buffer descriptor per tensor, 31-bit byte offsets
   return (size_t)B * Cin * H * W * 4 < (1ull << 31) && (size_t)B * Cout * H * W * 4 < (1ull << 31);

@@ -331,6 +331,9 @@ def main():
                                    'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (H, W, B, shape_tag),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 6),
                        'wgrad_side_stream': bool(HF._WgradStream.enabled),
+                       'tuning': ('user database %s' % os.environ['PNSFM_TUNE_DB']) if os.environ.get('PNSFM_TUNE_DB') else
+                                 ('shipped database (%d decisions) + autotune for unlisted shapes' % ops.tune_shipped_entries()
+                                  if ops.tune_shipped_entries() else 'autotune during warm-up'),
                        'step_launch': 'hipGraph replay (one graph per flip state)' if use_graph else 'eager',
                        'collective_backend': backend, 'devices_visible': ndev},
             'roofline': roofline,

@@ -60,6 +60,10 @@ int pnsfm_conv2d_backward_weight_strided(const float* x, const float* dy, float*
  * The first call for a new shape times the candidate configurations on the caller's stream (it synchronises), like
  * `torch.backends.cudnn.benchmark = True` in the reference (trainers/horovod_trainer.py:19). */
 int pnsfm_set_autotune(int on);
+/* Number of autotune decisions read from the database shipped next to the library (csrc/tuned_gfx950.db: the autotuner's own
+ * output for the benchmark configurations on an MI355X; 0 when PNSFM_TUNE_DB names a user database, when the file is
+ * missing or when autotuning is off).  Shapes the database does not list are timed on first use as usual. */
+int pnsfm_tune_shipped_entries(void);
 /* Un-tuned default of the forward/backward-data kernel: 0 = halo patch staged through registers, 1 = patch double-buffered
  * by LDS-DMA (global_load_lds) issued in slices between the taps, 2 = the fully pipelined kernel (patch AND per-kernel-row
  * weight slabs double-buffered by LDS-DMA, one barrier per kernel row, up to 160 KB of LDS).  The autotuner times all

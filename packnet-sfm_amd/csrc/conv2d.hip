@@ -20,6 +20,7 @@
 #include "../../include/pnsfm.h"
 
 #include <array>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -211,14 +212,19 @@ static std::mutex g_tune_mu;
 // and appends new ones, so that a later process (a profiling run, a resumed training job) launches no candidates.
 // One text line per decision: kind B Cin Cout H W ks  cfg split.
 static std::string g_tune_db;
+static int g_shipped_entries = 0;   // entries read from the shipped tuned_gfx950.db (0: none / user database in use)
 
 static int tune_db_load(const char* path) {
   FILE* f = fopen(path, "r");
   if (!f) return 0;
+  char line[256];
   int k[7], v[2], n = 0;
-  while (fscanf(f, "%d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &v[0], &v[1]) == 9) {
-    g_tuned[{k[0], k[1], k[2], k[3], k[4], k[5], k[6]}] = {v[0], v[1]};
-    ++n;
+  while (fgets(line, sizeof line, f)) {
+    if (line[0] == '#') continue;
+    if (sscanf(line, "%d %d %d %d %d %d %d %d %d", &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &v[0], &v[1]) == 9) {
+      g_tuned[{k[0], k[1], k[2], k[3], k[4], k[5], k[6]}] = {v[0], v[1]};
+      ++n;
+    }
   }
   fclose(f);
   return n;
@@ -262,6 +268,18 @@ static bool autotune_enabled() {
       g_tune_db = db;
       std::lock_guard<std::mutex> lk(g_tune_mu);
       tune_db_load(db);
+    } else if (g_autotune == 1 && !(db && db[0])) {
+      // no user database: start from the decisions shipped next to the library (tuned_gfx950.db: the autotuner's own output
+      // for the bench / reference configurations on an MI355X, read-only; shapes it does not list are timed as usual;
+      // PNSFM_TUNE_DB=<file> replaces it, PNSFM_TUNE_DB= (empty) or a missing file means start from nothing)
+      Dl_info info;
+      if (!db && dladdr(reinterpret_cast<const void*>(&tune_db_load), &info) && info.dli_fname) {
+        std::string path(info.dli_fname);
+        const size_t slash = path.rfind('/');
+        path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/tuned_gfx950.db";
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_shipped_entries = tune_db_load(path.c_str());
+      }
     }
   }
   return g_autotune == 1;
@@ -858,19 +876,28 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
 }
 
 #ifndef PNSFM_EMU
-// time `reps` back-to-back executions of fn() on `stream`; returns ms per execution (or < 0 on error)
+// time back-to-back executions of fn() on `stream`; returns ms per execution (or < 0 on error).  `reps` executions are the
+// minimum; short kernels are repeated until ~0.4 ms have been measured (<= 12 executions): with 2 executions of a 50 us
+// kernel the run-to-run noise (+-10 %) used to pick different configurations from one process to the next.
 template <class F>
 static float time_on_stream(hipStream_t stream, int reps, F fn) {
   static hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!e0) { if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f; }
   if (fn() != 0) return -1.f;                     // warm-up (also faults in code objects)
-  if (hipEventRecord(e0, stream) != hipSuccess) return -1.f;
-  for (int i = 0; i < reps; ++i) if (fn() != 0) return -1.f;
-  if (hipEventRecord(e1, stream) != hipSuccess) return -1.f;
-  if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
-  return ms / reps;
+  float total = 0.f;
+  int done = 0;
+  while (true) {
+    if (hipEventRecord(e0, stream) != hipSuccess) return -1.f;
+    for (int i = 0; i < reps; ++i) if (fn() != 0) return -1.f;
+    if (hipEventRecord(e1, stream) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+    total += ms;
+    done += reps;
+    if (total >= 0.4f || done >= 12) break;
+  }
+  return total / done;
 }
 #endif
 
@@ -1519,5 +1546,10 @@ int pnsfm_set_conv_math(int mode) {
   return prev;
 }
 int pnsfm_get_conv_math(void) { return conv_math(); }
+
+int pnsfm_tune_shipped_entries(void) {
+  (void)autotune_enabled();      // first call reads the environment / the shipped database
+  return g_shipped_entries;
+}
 
 }  // extern "C"

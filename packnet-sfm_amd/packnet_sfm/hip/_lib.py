@@ -69,6 +69,7 @@ SIGNATURES = {
     "pnsfm_nrs_project_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "pnsfm_set_autotune": (_i, [_i]),
     "pnsfm_set_conv_variant": (_i, [_i]),
+    "pnsfm_tune_shipped_entries": (_i, []),
     "pnsfm_set_conv_math": (_i, [_i]),
     "pnsfm_get_conv_math": (_i, []),
     "pnsfm_set_wgrad_variant": (_i, [_i]),

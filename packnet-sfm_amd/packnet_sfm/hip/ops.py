@@ -41,6 +41,10 @@ def _ptr(t):
 
 
 # ---------------------------------------------------------------------------------------------- conv2d
+def tune_shipped_entries():
+    return int(_lib.get().pnsfm_tune_shipped_entries())
+
+
 def conv2d_packed_sizes(Cin, Cout, ks):
     lib = _lib.get()
     return (int(lib.pnsfm_conv2d_packed_elems_fwd(Cin, Cout, ks)), int(lib.pnsfm_conv2d_packed_elems_bwd(Cin, Cout, ks)))

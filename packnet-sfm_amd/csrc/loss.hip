@@ -25,6 +25,19 @@ __device__ __forceinline__ double block_sum_256d(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// stage 2 of the scalar reductions: out[v] = sum_i part[i * nvals + v] (nvals <= 4), ONE workgroup, fixed order: thread t adds
+// partials t, t + 256, ... and the 256 thread sums meet in a fixed tree (block_sum_256d).
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ part, int n, int nvals, double* __restrict__ out) {
+  __shared__ double red[4];
+  for (int v = 0; v < nvals; ++v) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[(size_t)i * nvals + v];
+    const double tot = block_sum_256d(acc, red);
+    if (threadIdx.x == 0) out[v] = tot;
+    __syncthreads();
+  }
+}
+
 struct Cam {
   float k[9];     // target intrinsics K (row major)
   float ki[9];    // Kinv as the reference builds it (camera.py:72-80): K with 4 entries replaced
@@ -369,8 +382,10 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
     if (reduce_op == 0) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)(best_i | (((clamp_mask >> best_i) & 1) << 7));
     else if (clip_thr != nullptr) argmin[(size_t)b * HW + gy * W + gx] = (uint8_t)clamp_mask;
   }
+  // stage 1 of the pixel mean: one partial per workgroup (loss_sum = the launch's partial buffer); sum_partials_kernel adds
+  // them in a fixed order -- no atomics, the loss is bit-reproducible
   const double s = block_sum_256d((double)contrib, red);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+  if (threadIdx.x == 0) loss_sum[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
 }
 
 // grid as forward. LDS: (1 + J) images x 3 ch x 20x20  +  J x 3 ch x 3 coefficient planes x 18x18.
@@ -505,7 +520,11 @@ __global__ void __launch_bounds__(256) smoothness_fwd_kernel(const float* __rest
   }
   const double tx = block_sum_256d((double)sx, red);
   const double ty = block_sum_256d((double)sy, red);
-  if (threadIdx.x == 0) { atomicAdd(&sums[0], tx); atomicAdd(&sums[1], ty); }
+  if (threadIdx.x == 0) {      // stage 1: partials [block][2]; sum_partials_kernel finishes
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    sums[2 * blk] = tx;
+    sums[2 * blk + 1] = ty;
+  }
 }
 
 __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -584,6 +603,16 @@ __global__ void photometric_clip_finish_kernel(const double* __restrict__ stats,
   }
 }
 
+// stream-ordered scratch for the per-workgroup partial sums of a two-stage reduction (freed behind the finishing kernel)
+static double* partials_alloc(int n, hipStream_t s) {
+  void* p = nullptr;
+  if (hipMallocAsync(&p, (size_t)n * sizeof(double), s) != hipSuccess || !p) {
+    set_error("loss: cannot allocate the partial-sum scratch");
+    return nullptr;
+  }
+  return (double*)p;
+}
+
 int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target, double* loss_sum,
                                    uint8_t* argmin, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
                                    int automask, int reduce_op, float clip_loss, double* stats_ws, float* thr_ws, void* stream) {
@@ -593,17 +622,21 @@ int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const 
   if (!(clip_loss > 0.f) || !stats_ws || !thr_ws) { set_error("photometric_forward_clip: clip_loss must be > 0 with scratch buffers"); return -1; }
   hipStream_t s = (hipStream_t)stream;
   const int ncand = J * (automask ? 2 : 1);
-  int e = (int)hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-  if (!e) e = (int)hipMemsetAsync(stats_ws, 0, 12 * sizeof(double), s);
+  int e = (int)hipMemsetAsync(stats_ws, 0, 12 * sizeof(double), s);
   if (e) { set_error("photometric_forward: memset failed"); return e; }
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const int nblk = (int)(grid.x * grid.y * grid.z);
+  double* part = partials_alloc(nblk, s);
+  if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
-  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)nullptr, stats_ws);
   PNSFM_LAUNCH(photometric_clip_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)stats_ws, thr_ws, ncand,
                (double)B * H * W, clip_loss);
-  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr);
+  PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
+  (void)hipFreeAsync(part, s);
   return check_launch("photometric_forward_clip");
 }
 
@@ -619,12 +652,15 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
   }
   if (automask && reduce_op != 0) { set_error("photometric_forward: automask requires the 'min' reduce op"); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-  if (e) { set_error("photometric_forward: memset failed"); return e; }
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const int nblk = (int)(grid.x * grid.y * grid.z);
+  double* part = partials_alloc(nblk, s);
+  if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
-  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, loss_sum, argmin, J, B, H, W, ssim_weight,
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
+  PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
+  (void)hipFreeAsync(part, s);
   return check_launch("photometric_forward");
 }
 
@@ -655,9 +691,13 @@ int pnsfm_photometric_backward_clip(const float* warped, const float* target, co
 
 int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums, int B, int H, int W, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(sums, 0, 2 * sizeof(double), s);
-  if (e) { set_error("smoothness_forward: memset failed"); return e; }
-  PNSFM_LAUNCH(smoothness_fwd_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), 0, s, inv_norm, image, sums, H, W);
+  dim3 grid(ceil_div(H * W, 256), B);
+  const int nblk = (int)(grid.x * grid.y);
+  double* part = partials_alloc(2 * nblk, s);
+  if (!part) return -1;
+  PNSFM_LAUNCH(smoothness_fwd_kernel, grid, dim3(256), 0, s, inv_norm, image, part, H, W);
+  PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 2, sums);
+  (void)hipFreeAsync(part, s);
   return check_launch("smoothness_forward");
 }
 

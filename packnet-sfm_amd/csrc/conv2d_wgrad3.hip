@@ -389,10 +389,16 @@ static int wgrad3_tc(int W) {
   if (W % 8 != 0) return 16;
   return round_up(W, 16) < round_up(W, 32) ? 16 : 32;
 }
-static int wgrad3_WM(int Cout) { return Cout > 96 ? 4 : (Cout > 32 ? 2 : 1); }
+// co tiles per workgroup: the most the layer can fill (4, 2, 1 for Cout >= 97, >= 33, smaller) unless the caller asks for fewer
+// -- fewer co tiles = more pixel shares per workgroup (WK = 4 / WM) and more workgroups: parallelism for the low-resolution
+// layers WITHOUT a pixel split (no partial tensors, no second kernel)
+int wgrad3_WM(int Cout, int want) {
+  const int most = Cout > 96 ? 4 : (Cout > 32 ? 2 : 1);
+  return (want == 1 || want == 2 || want == 4) && want < most ? want : most;
+}
 int wgrad3_total_tiles(int B, int H, int W) { return B * ceil_div(W, wgrad3_tc(W)) * ceil_div(H, 4); }
-int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT) {
-  return ceil_div(Cin, 32 * NT) * ks * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout));
+int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM) {
+  return ceil_div(Cin, 32 * NT) * ks * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout, WM));
 }
 bool wgrad3_nt2_ok(int Cin, int ks) { return ks <= 3 && Cin > 32; }
 
@@ -415,7 +421,7 @@ static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
 }
 
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
-                   int split, int NT, hipStream_t s) {
+                   int split, int NT, int WMwant, hipStream_t s) {
   if (!wgrad3_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (split-bf16): unsupported shape"); return -1; }
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31) || (size_t)B * Cout * H * W * 4 >= (1ull << 31)) {
     set_error("conv2d_backward_weight (split-bf16): tensor too large for 32-bit buffer offsets");
@@ -435,7 +441,7 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.tiles_per_split = ceil_div(a.total_tiles, split);
   const int splitP = ceil_div(a.total_tiles, a.tiles_per_split);
   a.ci_tiles = ceil_div(Cin, 32 * NT);
-  const int WM = wgrad3_WM(Cout);
+  const int WM = wgrad3_WM(Cout, WMwant);
   const int co_groups = ceil_div(ceil_div(Cout, 32), WM);
   a.COP = co_groups * WM * 32;
   a.CIP = a.ci_tiles * 32 * NT;

@@ -194,6 +194,34 @@ def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
     P.check(db, br.grad, 1e-5, 'dbias (split-bf16)')
 
 
+@pytest.mark.parametrize('cfg', [(1, 1, 1), (1, 1, 2), (2, 1, 1), (2, 2, 2), (3, 1, 4)])
+@pytest.mark.parametrize('shape', [(1, 64, 128, 8, 32, 3), (2, 48, 160, 5, 40, 3), (1, 32, 100, 6, 24, 5)])
+def test_conv2d_wgrad_split_bf16_pinned(emulated_kernels, shape, cfg):
+    """wgrad3 configurations the autotuner explores on the GPU, pinned through pnsfm_tune_set: cfg = (pixel split, ci tiles per
+    wave NT, co tiles per workgroup WM) -- WM below the layer's maximum turns waves into extra pixel shares (LDS reduction)."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_conv_math(1)
+    split, NT, WM = cfg
+    B, Cin, Cout, H, W, ks = shape
+    key = (ctypes.c_int * 7)(2 + 10 + 100, B, Cin, Cout, H * W, W, ks)
+    assert lib.pnsfm_tune_set(key, split, 2 | (NT << 4) | (WM << 6)) == 0
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dw, db = ops.conv2d_backward_weight(x, dy, ks)
+    P.check(dw, wr.grad, 1e-5, 'wgrad (split-bf16, pinned)')
+    P.check(db, br.grad, 1e-5, 'dbias (split-bf16, pinned)')
+    lib.pnsfm_set_wgrad_variant(-1)      # clears the pinned entry
+
+
 @pytest.mark.parametrize('nf', [8, 4])
 @pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3)])
 def test_conv3d_raw(emulated_kernels, shape, nf):

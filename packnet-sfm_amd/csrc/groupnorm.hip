@@ -210,26 +210,42 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
 //   csum[(b*C+c)*2 + {0,1}] = channel totals (for dgamma / dbeta);  gsum[(b*G+g)*2 + {0,1}] = { mean_g(dz*gamma), mean_g(dz*gamma*xhat) }
 __global__ void __launch_bounds__(256) gn_bwd_group_kernel(const double* __restrict__ red_ws, const float* __restrict__ gamma,
                                                             double* __restrict__ csum, float* __restrict__ gsum, int B, int C,
-                                                            int G, int nchunk, double n) {
+                                                            int G, int nchunk, double n, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
   const int bg = blockIdx.x * 256 + threadIdx.x;
-  if (bg >= B * G) return;
-  const int cpg = C / G;
-  const int b = bg / G, gi = bg - b * G;
-  double A = 0.0, Bq = 0.0;
-  for (int k = 0; k < cpg; ++k) {
-    const int c = gi * cpg + k;
-    double r1 = 0.0, r2 = 0.0;
-    for (int j = 0; j < nchunk; ++j) {
-      r1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
-      r2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
+  if (bg < B * G) {
+    const int cpg = C / G;
+    const int b = bg / G, gi = bg - b * G;
+    double A = 0.0, Bq = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      const int c = gi * cpg + k;
+      double r1 = 0.0, r2 = 0.0;
+      for (int j = 0; j < nchunk; ++j) {
+        r1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
+        r2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
+      }
+      csum[((size_t)b * C + c) * 2 + 0] = r1;
+      csum[((size_t)b * C + c) * 2 + 1] = r2;
+      A += (double)gamma[c] * r1;
+      Bq += (double)gamma[c] * r2;
     }
-    csum[((size_t)b * C + c) * 2 + 0] = r1;
-    csum[((size_t)b * C + c) * 2 + 1] = r2;
-    A += (double)gamma[c] * r1;
-    Bq += (double)gamma[c] * r2;
+    gsum[bg * 2 + 0] = (float)(A / n);
+    gsum[bg * 2 + 1] = (float)(Bq / n);
   }
-  gsum[bg * 2 + 0] = (float)(A / n);
-  gsum[bg * 2 + 1] = (float)(Bq / n);
+  // one workgroup holds every (b, g) (B * G <= 256: always, for the networks here): it also finishes dgamma / dbeta -- the
+  // sums over the batch of the channel totals it has just written -- instead of a fourth launch (gn_bwd_params_kernel)
+  if (dgamma != nullptr) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int b = 0; b < B; ++b) {
+        s1 += csum[((size_t)b * C + c) * 2 + 0];
+        s2 += csum[((size_t)b * C + c) * 2 + 1];
+      }
+      dbeta[c] = (float)s1;
+      dgamma[c] = (float)s2;
+    }
+  }
 }
 
 // ---- backward, pass 2: dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat))
@@ -365,14 +381,16 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   else PNSFM_LAUNCH((gn_bwd_reduce_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_reduce");
   if (e) return e;
+  const bool one_group_block = B * G <= 256;      // then the group kernel finishes dgamma / dbeta itself
   PNSFM_LAUNCH(gn_bwd_group_kernel, dim3(ceil_div(B * G, 256)), dim3(256), 0, s, (const double*)red_ws, gamma, csum, gsum, B, C, G,
-               g.nchunk, (double)(C / G) * (double)HW);
+               g.nchunk, (double)(C / G) * (double)HW, one_group_block ? dgamma : (float*)nullptr,
+               one_group_block ? dbeta : (float*)nullptr);
   e = check_launch("gn_bwd_group");
   if (e) return e;
   if (vec) PNSFM_LAUNCH((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
   else PNSFM_LAUNCH((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_apply");
-  if (e) return e;
+  if (e || one_group_block) return e;
   PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)csum, dgamma, dbeta, B, C);
   return check_launch("gn_bwd_params");
 }

@@ -9,7 +9,8 @@
 
 One "step" = zero_grad -> PackNet01 + PoseNet forward -> multi-view photometric loss (4 scales, SSIM+L1, automask,
 smoothness) -> backward -> (N>1: RCCL gradient all-reduce, overlapped with backward) -> Adam, on a synthetic
-KITTI-shaped batch of 192x640 triplets, batch 4 per GPU (BASELINE.json configs[1]); fp32 end to end.
+KITTI-shaped batch of 192x640 triplets, batch 4 per GPU (BASELINE.json configs[1]); fp32 tensors end to end, the conv
+GEMMs computed as fp32-from-exact-bf16-splits on the bf16 matrix pipe (PNSFM_CONV_MATH=f32 for the f32 MFMA).
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are defined.
 """
 import argparse

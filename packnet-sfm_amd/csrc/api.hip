@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <mutex>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 namespace pnsfm {
@@ -25,6 +27,39 @@ int check_launch(const char* what) {
     return e;
   }
   return 0;
+}
+
+// ---- per-stream scratch ---------------------------------------------------------------------------------------------
+// Two-stage reductions (wgrad3's pixel splits, the loss scalars) need a few KB .. tens of MB that live from one kernel to
+// the next ON THE SAME STREAM.  The library keeps one grow-only device buffer per stream: stream order already serialises
+// its users, so nothing is allocated, freed or synchronised in steady state (hipMallocAsync / hipFreeAsync per call measured
+// -3.3 % on the training step: 126.2 -> 121.8 img/s), and the pointers are stable under hipGraph capture.  A buffer that
+// has to grow is replaced; the old one is kept until process exit because kernels already enqueued may still use it
+// (growth only happens while the first steps discover the sizes).
+struct Scratch { void* p = nullptr; size_t cap = 0; };
+static std::mutex g_scratch_mu;
+static std::vector<std::pair<hipStream_t, Scratch>> g_scratch;
+
+void* scratch_get(hipStream_t stream, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  Scratch* sc = nullptr;
+  for (auto& e : g_scratch)
+    if (e.first == stream) { sc = &e.second; break; }
+  if (!sc) { g_scratch.emplace_back(stream, Scratch()); sc = &g_scratch.back().second; }
+  if (bytes > sc->cap) {
+    size_t cap = sc->cap ? sc->cap : (size_t)1 << 20;
+    while (cap < bytes) cap *= 2;
+    void* p = nullptr;
+#ifdef PNSFM_EMU
+    p = malloc(cap);
+#else
+    if (hipMalloc(&p, cap) != hipSuccess) p = nullptr;
+#endif
+    if (!p) { set_error("cannot allocate %zu bytes of scratch", cap); return nullptr; }
+    sc->p = p;          // (the previous buffer is deliberately not freed, see above)
+    sc->cap = cap;
+  }
+  return sc->p;
 }
 
 // ---- live timing -------------------------------------------------------------------------------

@@ -447,13 +447,10 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.CIP = a.ci_tiles * 32 * NT;
   a.ws = nullptr; a.ws_bias = nullptr;
   if (splitP > 1) {
-    // pixel-split launch: partial tensors in a stream-ordered scratch allocation, summed by wgrad3_reduce_kernel
+    // pixel-split launch: partial tensors in the stream's scratch buffer (api.hip), summed by wgrad3_reduce_kernel
     const size_t part = (size_t)ks * a.COP * ks * a.CIP;
-    void* p = nullptr;
-    if (hipMallocAsync(&p, ((size_t)splitP * (part + a.COP)) * sizeof(float), s) != hipSuccess || !p) {
-      set_error("conv2d_backward_weight: cannot allocate the partial-sum workspace");
-      return -1;
-    }
+    void* p = scratch_get(s, ((size_t)splitP * (part + a.COP)) * sizeof(float));
+    if (!p) return -1;
     a.ws = (float*)p;
     a.ws_bias = a.ws + (size_t)splitP * part;
   }
@@ -482,7 +479,6 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
                    dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout);
       rc = check_launch("conv2d_backward_weight (split-bf16, reduction)");
     }
-    (void)hipFreeAsync(a.ws, s);
   }
   return rc;
 }

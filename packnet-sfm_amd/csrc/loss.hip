@@ -603,15 +603,8 @@ __global__ void photometric_clip_finish_kernel(const double* __restrict__ stats,
   }
 }
 
-// stream-ordered scratch for the per-workgroup partial sums of a two-stage reduction (freed behind the finishing kernel)
-static double* partials_alloc(int n, hipStream_t s) {
-  void* p = nullptr;
-  if (hipMallocAsync(&p, (size_t)n * sizeof(double), s) != hipSuccess || !p) {
-    set_error("loss: cannot allocate the partial-sum scratch");
-    return nullptr;
-  }
-  return (double*)p;
-}
+// per-workgroup partial sums of a two-stage reduction live in the stream's scratch buffer (api.hip)
+static double* partials_alloc(int n, hipStream_t s) { return (double*)scratch_get(s, (size_t)n * sizeof(double)); }
 
 int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target, double* loss_sum,
                                    uint8_t* argmin, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
@@ -636,7 +629,6 @@ int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const 
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
-  (void)hipFreeAsync(part, s);
   return check_launch("photometric_forward_clip");
 }
 
@@ -660,7 +652,6 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
-  (void)hipFreeAsync(part, s);
   return check_launch("photometric_forward");
 }
 
@@ -697,7 +688,6 @@ int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* 
   if (!part) return -1;
   PNSFM_LAUNCH(smoothness_fwd_kernel, grid, dim3(256), 0, s, inv_norm, image, part, H, W);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 2, sums);
-  (void)hipFreeAsync(part, s);
   return check_launch("smoothness_forward");
 }
 

@@ -149,6 +149,8 @@ namespace pnsfm {
 // error plumbing shared by every entry point (api.hip owns the storage)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// grow-only device scratch of the given stream (api.hip): valid until the next scratch_get on the same stream; null on failure
+void* scratch_get(hipStream_t stream, size_t bytes);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

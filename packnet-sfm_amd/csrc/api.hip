@@ -40,7 +40,18 @@ struct Scratch { void* p = nullptr; size_t cap = 0; };
 static std::mutex g_scratch_mu;
 static std::vector<std::pair<hipStream_t, Scratch>> g_scratch;
 
-void* scratch_get(hipStream_t stream, size_t bytes) {
+void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
+  *async_owned = false;
+#ifndef PNSFM_EMU
+  if (stream_capturing(stream)) {
+    // hipGraph capture runs on a stream of its own and may not call hipMalloc: a stream-ordered allocation becomes a pair of
+    // memory nodes of the graph instead (the caller hands it back through scratch_release)
+    void* p = nullptr;
+    if (hipMallocAsync(&p, bytes, stream) != hipSuccess || !p) { set_error("cannot allocate %zu bytes of scratch (capture)", bytes); return nullptr; }
+    *async_owned = true;
+    return p;
+  }
+#endif
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   Scratch* sc = nullptr;
   for (auto& e : g_scratch)
@@ -60,6 +71,14 @@ void* scratch_get(hipStream_t stream, size_t bytes) {
     sc->cap = cap;
   }
   return sc->p;
+}
+
+void scratch_release(void* p, hipStream_t stream, bool async_owned) {
+#ifndef PNSFM_EMU
+  if (async_owned && p) (void)hipFreeAsync(p, stream);
+#else
+  (void)p; (void)stream; (void)async_owned;
+#endif
 }
 
 // ---- live timing -------------------------------------------------------------------------------

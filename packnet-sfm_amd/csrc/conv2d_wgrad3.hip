@@ -446,10 +446,11 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.COP = co_groups * WM * 32;
   a.CIP = a.ci_tiles * 32 * NT;
   a.ws = nullptr; a.ws_bias = nullptr;
+  bool ws_async = false;
   if (splitP > 1) {
     // pixel-split launch: partial tensors in the stream's scratch buffer (api.hip), summed by wgrad3_reduce_kernel
     const size_t part = (size_t)ks * a.COP * ks * a.CIP;
-    void* p = scratch_get(s, ((size_t)splitP * (part + a.COP)) * sizeof(float));
+    void* p = scratch_get(s, ((size_t)splitP * (part + a.COP)) * sizeof(float), &ws_async);
     if (!p) return -1;
     a.ws = (float*)p;
     a.ws_bias = a.ws + (size_t)splitP * part;
@@ -479,6 +480,7 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
                    dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout);
       rc = check_launch("conv2d_backward_weight (split-bf16, reduction)");
     }
+    scratch_release(a.ws, s, ws_async);
   }
   return rc;
 }

@@ -149,8 +149,10 @@ namespace pnsfm {
 // error plumbing shared by every entry point (api.hip owns the storage)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
-// grow-only device scratch of the given stream (api.hip): valid until the next scratch_get on the same stream; null on failure
-void* scratch_get(hipStream_t stream, size_t bytes);
+// grow-only device scratch of the given stream (api.hip): valid until the next scratch_get on the same stream; null on failure.
+// Under hipGraph capture it is a stream-ordered allocation instead (*async_owned): always pair with scratch_release.
+void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned);
+void scratch_release(void* p, hipStream_t stream, bool async_owned);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -216,7 +216,6 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
       }
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
-        constexpr int dummy = 0; (void)dummy;
         const int sh = kx - P;                         // element shift of this tap
         pnsfm_u32x4 Bv[3];
 #pragma unroll

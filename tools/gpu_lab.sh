@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round-2 GPU session: selected parity tests, bench variants (hipGraph on/off, 384x1280, 2-rank rehearsal), the autotuner's
-# full candidate landscape (PNSFM_TUNE_LOG) and a rocprofv3 kernel trace.  usage: tools/gpu_lab.sh <tag> [what...]
+# Round-2 GPU session: parity tests, bench variants (384x1280, forced-DDP, 2-rank rehearsal), the autotuner's full candidate
+# landscape (PNSFM_TUNE_LOG), rocprofv3 kernel traces and PMC passes.  PNSFM_TUNE_DB is set to gpurun_out/tune_<tag>.db: a fresh tag
+# tunes from scratch (that is how csrc/tuned_gfx950.db is regenerated: `gpu_lab.sh <tag> bench bench_c3`, then copy the file).  usage: tools/gpu_lab.sh <tag> [what...]
 TAG=${1:-r02a}; shift
 WHAT=${@:-tests bench bench_eager bench_c3 bench_2rank prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,7 +28,7 @@ bench_ddp1)
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; tail -3 $O/smoke_$TAG.log ;;
 bench)
-  echo "== bench (default: hipGraph replay), tune log on"
+  echo "== bench (defaults: eager launches, FlatAdam), tune log on"
   PNSFM_TUNE_LOG=$O/tunelog_$TAG.txt timeout 900 python bench.py --steps 10 --warmup 3 --layer-table $O/layers_$TAG.csv > $O/bench_$TAG.log 2>&1
   tail -2 $O/bench_$TAG.log | cut -c1-1800 ;;
 bench_eager)

@@ -1393,14 +1393,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   // split-bf16 kernel (conv2d_wgrad3.hip): part of the split arithmetic mode (pnsfm_set_conv_math), the default there
   const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H0, W0, ks) && wgrad3_fits(B, Cin, Cout, H0, W0);
   auto v3_default_split = [&](int NT) -> int {
-    const int base = wgrad3_base_blocks(Cin, Cout, ks, NT, 0, 0), tiles = wgrad3_total_tiles(B, H0, W0);
+    const int base = wgrad3_base_blocks(Cin, Cout, ks, NT, 0), tiles = wgrad3_total_tiles(B, H0, W0);
     int split = (2 * 256 + base - 1) / base;            // two workgroups per CU
     if (split > tiles) split = tiles;
     return split < 1 ? 1 : split;
   };
   int variant = (g_wgrad_variant == 1 && v2_ok) ? 1 : 0;
   int split2 = v2_ok ? v2_default_split() : 1;
-  int nt3 = wgrad3_nt2_ok(Cin, ks) ? 2 : 1, wm3 = 0, all3 = 0;
+  int nt3 = wgrad3_nt2_ok(Cin, ks) ? 2 : 1, wm3 = 0;
   int split3 = v3_ok ? v3_default_split(nt3) : 1;
   if (v3_ok && g_wgrad_variant != 0 && g_wgrad_variant != 1) variant = 2;     // -1 (library default) or 2 (pinned)
   {
@@ -1447,23 +1447,22 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         const int tiles3 = wgrad3_total_tiles(B, H0, W0);
         const int wm_most = wgrad3_WM(Cout, 0);
         for (int NT = 1; NT <= (wgrad3_nt2_ok(Cin, ks) ? 2 : 1); ++NT)
-          for (int ALL = 0; ALL <= (wgrad3_allrows_ok(ks, NT) ? 1 : 0); ++ALL)
-            for (int WMv = wm_most; WMv >= 1; WMv >>= 1) {
-              const int base3 = wgrad3_base_blocks(Cin, Cout, ks, NT, WMv, ALL);
-              int prev = -1;
-              for (int want = 1; want <= tiles3; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
-                const int tps = ceil_div(tiles3, want);
-                const int split = ceil_div(tiles3, tps);
-                if (split == prev) continue;
-                prev = split;
-                if ((long)base3 * split < (ALL ? 120 : 200) && split < tiles3) continue;      // cannot fill the chip
-                if ((long)base3 * split > (ALL ? 4L : 16L) * 256 && split > 1) break;
-                if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
-                const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split, NT, WMv, ALL, s); });
-                tune_log(2, key, 2 | (NT << 4) | (WMv << 6) | (ALL << 9), split, ms);
-                if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6) | (ALL << 9); }
-              }
+          for (int WMv = wm_most; WMv >= 1; WMv >>= 1) {
+            const int base3 = wgrad3_base_blocks(Cin, Cout, ks, NT, WMv);
+            int prev = -1;
+            for (int want = 1; want <= tiles3; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
+              const int tps = ceil_div(tiles3, want);
+              const int split = ceil_div(tiles3, tps);
+              if (split == prev) continue;
+              prev = split;
+              if ((long)base3 * split < 200 && split < tiles3) continue;      // cannot fill the chip
+              if ((long)base3 * split > 16L * 256 && split > 1) break;
+              if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
+              const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split, NT, WMv, s); });
+              tune_log(2, key, 2 | (NT << 4) | (WMv << 6), split, ms);
+              if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6); }
             }
+          }
       }
       it = g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first;
       tune_db_append(key, it->second);
@@ -1472,7 +1471,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     (void)tune;
     if (it != g_tuned.end()) {
       variant = ((it->second[1] & 15) == 1 && v2_ok) ? 1 : (((it->second[1] & 15) == 2 && v3_ok) ? 2 : 0);
-      if (variant == 2) { split3 = it->second[0]; nt3 = ((it->second[1] >> 4) & 3) == 2 ? 2 : 1; wm3 = (it->second[1] >> 6) & 7; all3 = (it->second[1] >> 9) & 1; }
+      if (variant == 2) { split3 = it->second[0]; nt3 = ((it->second[1] >> 4) & 3) == 2 ? 2 : 1; wm3 = (it->second[1] >> 6) & 7; }
       else if (variant == 1) split2 = it->second[0];
       else {
         int sp = it->second[0];
@@ -1485,9 +1484,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   }
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
   if (variant == 2) {
-    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3, all3) * split3};
+    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3};
     prof_begin(1, flops, s, meta);
-    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split3, nt3, wm3, all3, s);
+    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split3, nt3, wm3, s);
     prof_end(1, s);
     return rc;
   }

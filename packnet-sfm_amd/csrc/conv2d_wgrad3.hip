@@ -63,66 +63,59 @@ __device__ __forceinline__ void w3_split8(const float (&v)[8], pnsfm_u32x4& H, p
   }
 }
 
-// ALLROWS (3x3 only): the workgroup accumulates ALL kernel rows -- 9 accumulator tiles per wave, one workgroup per CU (512
-// registers per lane): the dY fragment of a k-step is split once for 54 MFMAs instead of 18 and dY / X are read a third as
-// often; the X patch then carries KS - 1 halo rows.
-template <int KS, int NT, int WM, int TCv, bool ALLROWS = false>
+template <int KS, int NT, int WM, int TCv>
 struct Wgrad3Geom {
   static constexpr int P = KS / 2, KK = KS * KS;
-  static constexpr int KYN = ALLROWS ? KS : 1;           // kernel rows per workgroup
-  static constexpr int TG = KYN * KS;                    // taps (accumulator tiles per ci tile) per wave
   static constexpr int WK = 4 / WM;                      // pixel shares of a workgroup
   static constexpr int TR = 4, TC = TCv;                 // pixel tile: 4 rows x 32 (16) columns = 8 (4) k-steps
   static constexpr int SEG = TC / 16;                    // k-steps per tile row
   static constexpr int RS = TC + 16;                     // patch row: 8 halo + TC + 8 halo elements
-  static constexpr int PR = TR + KYN - 1;                // patch rows
-  static constexpr int CS = PR * RS + 8;                 // channel stride (elements): 8 * odd (200, 136, 296, 200) -> conflict-free b128
+  static constexpr int CS = TR * RS + 8;                 // channel stride (elements): 200 = 8 * 25 / 136 = 8 * 17 -> conflict-free b128
   static constexpr int NCI = 32 * NT;
   static constexpr int PIECE = NCI * CS;                 // elements of one piece plane
   static constexpr int SMEM = 3 * PIECE * 2;             // bytes
-  static constexpr int ITEMS = NCI * PR * (RS / 8);      // (channel, row, 8-column group) items of the patch
-  static constexpr int NIT = (ITEMS + 255) / 256;        // per thread
+  static constexpr int ITEMS = NCI * TR * (RS / 8);      // (channel, row, 8-column group) items of the patch
+  static constexpr int NIT = ITEMS / 256;                // per thread (ITEMS = 768 * NT or 512 * NT)
   static constexpr int KSTEPS = TR * SEG;                // 8 or 4
   static constexpr int KPW = KSTEPS / WK;                // k-steps of a tile per wave
   // dY fragments in flight per wave (8 registers each): a whole tile ahead where the accumulators leave room -- the loads
   // are issued RD k-steps before use, which is what hides the global-memory latency when only one workgroup fits a CU
-  static constexpr int RDW = ALLROWS ? 8 : ((KS >= 7 || NT == 2) ? 2 : (KS == 5 ? 4 : 8));
+  static constexpr int RDW = (KS >= 7 || NT == 2) ? 2 : (KS == 5 ? 4 : 8);
   static constexpr int RD = 2 * KPW < RDW ? 2 * KPW : RDW;      // up to TWO tiles ahead (RD divides 2 * KPW)
   // patch prefetch depth in tiles: a 3x3 tile with one ci tile per wave is only 1-2 us of MFMAs -- less than the latency of
   // the loads issued at its start -- so those kernels keep two tiles of raw patch data in flight
-  static constexpr int PDX = ALLROWS ? (KPW <= 4 ? 2 : 1) : ((KS == 3 && NT == 1 && KPW <= 4) ? 2 : 1);
+  static constexpr int PDX = (KS == 3 && NT == 1 && KPW <= 4) ? 2 : 1;
 };
 
 // MASKED: W % 8 == 4 -- the upper half of an 8-pixel group may lie past the end of an image row: the two 4-pixel halves are
 // range-checked separately (an out-of-row half gets an out-of-range buffer offset and reads as zero)
-template <int KS, int NT, int WM, int TCv, bool MASKED, bool ALLROWS>
-__global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
-  using Gm = Wgrad3Geom<KS, NT, WM, TCv, ALLROWS>;
+template <int KS, int NT, int WM, int TCv, bool MASKED>
+__global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
+  using Gm = Wgrad3Geom<KS, NT, WM, TCv>;
   constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI, SEG = Gm::SEG;
   constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KPW = Gm::KPW, RD = Gm::RD, PDX = Gm::PDX;
-  constexpr int KYN = Gm::KYN, TG = Gm::TG, PR = Gm::PR, ITEMS = Gm::ITEMS;
   PNSFM_DYN_SMEM(unsigned char, smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int wm = wave % WM, wk = wave / WM;
   const int H = a.H, W = a.W, HW = H * W;
-  const int cit = ALLROWS ? (int)blockIdx.x : (int)blockIdx.x / KS, ky = ALLROWS ? 0 : (int)blockIdx.x - cit * KS;   // ky: first kernel row
+  const int cit = blockIdx.x / KS, ky = blockIdx.x - cit * KS;
   const int ci0 = cit * NCI;
   const int co0 = (blockIdx.y * WM + wm) * 32;
   const int t_begin = blockIdx.z * a.tiles_per_split;
   int t_end = t_begin + a.tiles_per_split;
   if (t_end > a.total_tiles) t_end = a.total_tiles;
 
-  f32x16 acc[NT][TG];
+  f32x16 acc[NT][KS];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int k = 0; k < TG; ++k)
+    for (int k = 0; k < KS; ++k)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][k][r] = 0.f;
   float bsum = 0.f;
-  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;      // ci tile 0, (first) kernel row 0
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;      // ci tile 0, kernel row 0
 
   // ---- tile cursors.  Index arithmetic is kept out of the loop: a tile's origin (image, first row, first column) is advanced
   // incrementally in scalar registers for the current tile and the two behind it (the prefetch targets), and every per-lane
@@ -152,12 +145,12 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
   int it_lds[NIT], it_ry[NIT], it_gx[NIT], it_lane[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int e = it * 256 + tid;                 // (e >= ITEMS: a padding item of the last round, see it_ok)
-    const int ci = e / (PR * (RS / 8));
-    const int rem = e - ci * (PR * (RS / 8));
+    const int e = it * 256 + tid;
+    const int ci = e / (TR * (RS / 8));
+    const int rem = e - ci * (TR * (RS / 8));
     const int r = rem / (RS / 8), g = rem - r * (RS / 8);
     it_lds[it] = (ci * CS + r * RS + 8 * g) * 2;
-    it_ry[it] = r + ky - P;                       // image row = y0 + it_ry (patch row 0 = kernel row ky)
+    it_ry[it] = r + ky - P;                       // image row = y0 + it_ry
     it_gx[it] = 8 * g - 8;                        // image column = x0 + it_gx
     it_lane[it] = ((ci0 + ci) * HW + it_ry[it] * W + it_gx[it]) * 4;
   }
@@ -167,7 +160,7 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int yy = c.y0 + it_ry[it], xx = c.x0 + it_gx[it];
-      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W && (ITEMS % 256 == 0 || it * 256 + tid < ITEMS);
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
       const unsigned off = ok ? (unsigned)(sbase + it_lane[it]) : PNSFM_DMA_INVALID;
       // MASKED (W % 8 == 4): the upper 4 pixels of the group may lie past the row end -- they get their own range check
       const unsigned off4 = (MASKED && xx + 4 >= W) ? PNSFM_DMA_INVALID : off + 16u;
@@ -180,12 +173,10 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
     for (int it = 0; it < NIT; ++it) {
       pnsfm_u32x4 Hh, Mm, Ll;
       w3_split8(rw[it], Hh, Mm, Ll);
-      if (ITEMS % 256 == 0 || it * 256 + tid < ITEMS) {
-        unsigned char* d = smem + it_lds[it];
-        *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
-        *reinterpret_cast<pnsfm_u32x4*>(d + PIECE * 2) = Mm;
-        *reinterpret_cast<pnsfm_u32x4*>(d + 2 * PIECE * 2) = Ll;
-      }
+      unsigned char* d = smem + it_lds[it];
+      *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
+      *reinterpret_cast<pnsfm_u32x4*>(d + PIECE * 2) = Mm;
+      *reinterpret_cast<pnsfm_u32x4*>(d + 2 * PIECE * 2) = Ll;
     }
   };
 
@@ -207,48 +198,45 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
   auto kstep = [&](const pnsfm_u32x4 (&A)[3], int q) {
     const int koff = ((q / SEG) * RS + 16 * (q % SEG)) * 2;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
+      // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
+      unsigned Wd[3][12];
 #pragma unroll
-      for (int kyi = 0; kyi < KYN; ++kyi) {          // patch row of the k-step's pixels for kernel row ky + kyi
-        // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
-        unsigned Wd[3][12];
+      for (int s = 0; s < 3; ++s) {
+        const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE) * 2 + koff;
+        const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE + kyi * RS) * 2 + koff;
-          const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
+        for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
+        if (KS > 1) {
+          const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
+          const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
-          if (KS > 1) {
-            const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
-            const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
-          }
-        }
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          const int sh = kx - P;                         // element shift of this tap
-          const int tap = kyi * KS + kx;
-          pnsfm_u32x4 Bv[3];
-#pragma unroll
-          for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-              if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
-              else {
-                const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
-                Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
-              }
-            }
-          // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-          acc[nt][tap] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][tap]);
-          acc[nt][tap] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][tap]);
-          acc[nt][tap] = pnsfm_mfma_bf16(A[1], Bv[1], acc[nt][tap]);
-          acc[nt][tap] = pnsfm_mfma_bf16(A[1], Bv[0], acc[nt][tap]);
-          acc[nt][tap] = pnsfm_mfma_bf16(A[0], Bv[1], acc[nt][tap]);
-          acc[nt][tap] = pnsfm_mfma_bf16(A[0], Bv[0], acc[nt][tap]);
+          for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
         }
       }
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int sh = kx - P;                         // element shift of this tap
+        pnsfm_u32x4 Bv[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
+            else {
+              const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
+              Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
+            }
+          }
+        // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+        acc[nt][kx] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[1], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[0], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[1], acc[nt][kx]);
+        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[0], acc[nt][kx]);
+      }
+    }
   };
 
   // ---- main loop over this split's pixel tiles, unrolled by two so that ring slots are compile-time:
@@ -296,7 +284,7 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
     float* red = reinterpret_cast<float*>(smem);
     __syncthreads();           // the patch is dead
 #pragma unroll
-    for (int kx = 0; kx < TG; ++kx) {
+    for (int kx = 0; kx < KS; ++kx) {
       if (wk > 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -328,7 +316,7 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
       for (int nt = 0; nt < NT; ++nt) {
         const int ci = ci0 + nt * 32 + l32;
 #pragma unroll
-        for (int kx = 0; kx < TG; ++kx)      // tap index inside the workgroup's kernel rows: dW tap = ky * KS + kx
+        for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -337,18 +325,17 @@ __global__ void __launch_bounds__(256, ALLROWS ? 1 : 2) conv2d_wgrad3_kernel(Wgr
       }
       if (do_bias && half == 0 && co0 + l32 < a.Cout) a.dbias[co0 + l32] = bsum;
     } else {                    // partial sums, ci fastest: 128 contiguous bytes per half-wave
+      float* w = a.ws + ((size_t)blockIdx.z * KS + ky) * a.COP * KS * a.CIP;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int ci = ci0 + nt * 32 + l32;
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          float* w = a.ws + ((size_t)blockIdx.z * KS + ky + t / KS) * a.COP * KS * a.CIP;
+        for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            w[((size_t)co * KS + t % KS) * a.CIP + ci] = acc[nt][t][r];
+            w[((size_t)co * KS + kx) * a.CIP + ci] = acc[nt][kx][r];
           }
-        }
       }
       if (do_bias && half == 0) a.ws_bias[(size_t)blockIdx.z * a.COP + co0 + l32] = bsum;
     }
@@ -409,19 +396,18 @@ int wgrad3_WM(int Cout, int want) {
   return (want == 1 || want == 2 || want == 4) && want < most ? want : most;
 }
 int wgrad3_total_tiles(int B, int H, int W) { return B * ceil_div(W, wgrad3_tc(W)) * ceil_div(H, 4); }
-int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM, int allrows) {
-  return ceil_div(Cin, 32 * NT) * (allrows ? 1 : ks) * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout, WM));
+int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM) {
+  return ceil_div(Cin, 32 * NT) * ks * ceil_div(ceil_div(Cout, 32), wgrad3_WM(Cout, WM));
 }
-bool wgrad3_allrows_ok(int ks, int NT) { return ks == 3 && NT == 1; }
 bool wgrad3_nt2_ok(int Cin, int ks) { return ks <= 3 && Cin > 32; }
 
-template <int KS, int NT, int WM, int TC, bool MASKED, bool ALLROWS = false>
+template <int KS, int NT, int WM, int TC, bool MASKED>
 static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
-  using Gm = Wgrad3Geom<KS, NT, WM, TC, ALLROWS>;
+  using Gm = Wgrad3Geom<KS, NT, WM, TC>;
 #ifndef PNSFM_EMU
   static bool raised = false;
   if (!raised && Gm::SMEM > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED, ALLROWS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
       return -1;
@@ -429,19 +415,18 @@ static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
     raised = true;
   }
 #endif
-  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED, ALLROWS>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
+  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
   return check_launch("conv2d_backward_weight (split-bf16)");
 }
 
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
-                   int split, int NT, int WMwant, int allrows, hipStream_t s) {
+                   int split, int NT, int WMwant, hipStream_t s) {
   if (!wgrad3_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (split-bf16): unsupported shape"); return -1; }
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31) || (size_t)B * Cout * H * W * 4 >= (1ull << 31)) {
     set_error("conv2d_backward_weight (split-bf16): tensor too large for 32-bit buffer offsets");
     return -1;
   }
   if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
-  if (!wgrad3_allrows_ok(ks, NT)) allrows = 0;
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
@@ -469,7 +454,7 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
     a.ws = (float*)p;
     a.ws_bias = a.ws + (size_t)splitP * part;
   }
-  dim3 grid(a.ci_tiles * (allrows ? 1 : ks), co_groups, splitP);
+  dim3 grid(a.ci_tiles * ks, co_groups, splitP);
   int rc = 0;
 #define PNSFM_W3T(KSv, NTv, WMv)                                                    \
   do {                                                                              \
@@ -483,11 +468,7 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
     else if (WM == 2) PNSFM_W3T(KSv, NTv, 2);                             \
     else PNSFM_W3T(KSv, NTv, 1);                                          \
   } while (0)
-  if (ks == 3 && allrows) {
-    if (masked) { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 16, true, true>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 16, true, true>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 16, true, true>(a, grid, s); }
-    else if (tc == 16) { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 16, false, true>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 16, false, true>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 16, false, true>(a, grid, s); }
-    else { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 32, false, true>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 32, false, true>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 32, false, true>(a, grid, s); }
-  } else if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
+  if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
   else if (ks == 5) PNSFM_W3(5, 1);
   else PNSFM_W3(7, 1);
 #undef PNSFM_W3T

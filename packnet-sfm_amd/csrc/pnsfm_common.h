@@ -196,10 +196,9 @@ bool wgrad3_nt2_ok(int Cin, int ks);
 bool wgrad3_fits(int B, int Cin, int Cout, int H, int W);
 int wgrad3_total_tiles(int B, int H, int W);
 int wgrad3_WM(int Cout, int want);          // co tiles per workgroup (want: 0 = the most the layer fills, or 1 / 2 / 4)
-int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM, int allrows);
-bool wgrad3_allrows_ok(int ks, int NT);      // the all-kernel-rows-per-workgroup variant exists (3x3, one ci tile per wave)
+int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM);
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
-                   int split, int NT, int WM, int allrows, hipStream_t stream);
+                   int split, int NT, int WM, hipStream_t stream);
 
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);

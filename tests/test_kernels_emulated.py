@@ -194,23 +194,20 @@ def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
     P.check(db, br.grad, 1e-5, 'dbias (split-bf16)')
 
 
-@pytest.mark.parametrize('cfg', [(1, 1, 1, 0), (1, 1, 2, 0), (2, 1, 1, 0), (2, 2, 2, 0), (3, 1, 4, 0),
-                                 (1, 1, 4, 1), (2, 1, 2, 1), (1, 1, 1, 1), (3, 1, 4, 1)])
-@pytest.mark.parametrize('shape', [(1, 64, 128, 8, 32, 3), (2, 48, 160, 5, 40, 3), (1, 32, 100, 6, 24, 5), (2, 40, 24, 6, 20, 3)])
+@pytest.mark.parametrize('cfg', [(1, 1, 1), (1, 1, 2), (2, 1, 1), (2, 2, 2), (3, 1, 4)])
+@pytest.mark.parametrize('shape', [(1, 64, 128, 8, 32, 3), (2, 48, 160, 5, 40, 3), (1, 32, 100, 6, 24, 5)])
 def test_conv2d_wgrad_split_bf16_pinned(emulated_kernels, shape, cfg):
     """wgrad3 configurations the autotuner explores on the GPU, pinned through pnsfm_tune_set: cfg = (pixel split, ci tiles per
-    wave NT, co tiles per workgroup WM, all kernel rows per workgroup) -- WM below the layer's maximum turns waves into extra
-    pixel shares (LDS reduction); the all-rows variant (3x3: nine accumulator tiles per wave, patch with halo rows) falls back
-    to one row per workgroup for other kernel sizes."""
+    wave NT, co tiles per workgroup WM) -- WM below the layer's maximum turns waves into extra pixel shares (LDS reduction)."""
     import ctypes
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     lib = _lib.get()
     lib.pnsfm_set_conv_math(1)
-    split, NT, WM, ALL = cfg
+    split, NT, WM = cfg
     B, Cin, Cout, H, W, ks = shape
     key = (ctypes.c_int * 7)(2 + 10 + 100, B, Cin, Cout, H * W, W, ks)
-    assert lib.pnsfm_tune_set(key, split, 2 | (NT << 4) | (WM << 6) | (ALL << 9)) == 0
+    assert lib.pnsfm_tune_set(key, split, 2 | (NT << 4) | (WM << 6)) == 0
     g = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1

@@ -437,7 +437,7 @@ template <class K>
 static int gn_raise_lds(K kernel, size_t bytes, bool* done) {
 #ifndef PNSFM_EMU
   if (!*done && bytes > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {   // + the kernel's static 64 B
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       set_error("groupnorm: cannot raise the dynamic LDS limit");
       return -1;
     }

@@ -307,148 +307,6 @@ __global__ void __launch_bounds__(256) gn_bwd_params_kernel(const double* __rest
   dgamma[c] = (float)s2;
 }
 
-// ---- small maps: one workgroup per (sample, group) --------------------------------------------------------------------
-// When the cpg * HW values of a (sample, group) fit LDS (<= 128 KB: every PackNet01 / PoseNet map at 24x80 and below, the
-// 64-channel maps at 48x160), the three forward launches (statistics, finish, apply) and the first three backward launches
-// collapse into ONE each: x (+res) is read once into LDS, reduced, normalised from LDS.  Those layers are launch-latency
-// bound (5-7 us per launch for < 2 us of data movement), so this is worth ~3 launches x 18 us per layer.
-// A wave owns channels wave, wave + 4, ... of the group: per-channel sums need shuffles only.
-__device__ __forceinline__ double wave_sum_d(double v) {
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
-}
-
-__global__ void __launch_bounds__(256) gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ y, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, int C, int HW, int G, float eps, int act) {
-  PNSFM_DYN_SMEM(float, vals);
-  __shared__ double red[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bg = blockIdx.x, b = bg / G, gi = bg - b * G, cpg = C / G;
-  const size_t base = ((size_t)b * C + (size_t)gi * cpg) * HW;      // the group's channels are contiguous
-  const int n = cpg * HW;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 4 * tid; i < n; i += 1024) {
-    float4 v = *reinterpret_cast<const float4*>(x + base + i);
-    if (res) { const float4 q = *reinterpret_cast<const float4*>(res + base + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-    *reinterpret_cast<float4*>(vals + i) = v;
-    s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-    s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
-  }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
-  if (lane == 0) { red[2 * wave] = s1; red[2 * wave + 1] = s2; }
-  __syncthreads();
-  const double t1 = (red[0] + red[2]) + (red[4] + red[6]), t2 = (red[1] + red[3]) + (red[5] + red[7]);
-  const double m = t1 / (double)n;
-  double var = t2 / (double)n - m * m;
-  if (var < 0.0) var = 0.0;
-  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
-  if (tid == 0) { mean_out[bg] = mu; rstd_out[bg] = rs; }
-  for (int cl = wave; cl < cpg; cl += 4) {
-    const int c = gi * cpg + cl;
-    const float sc = rs * gamma[c], sh = beta[c] - mu * sc;         // z = v * sc + sh
-    const float* vp = vals + cl * HW;
-    float* yp = y + base + (size_t)cl * HW;
-    for (int i = 4 * lane; i < HW; i += 256) {
-      const float4 v = *reinterpret_cast<const float4*>(vp + i);
-      float4 o;
-      o.x = act_fwd(fmaf(v.x, sc, sh), act); o.y = act_fwd(fmaf(v.y, sc, sh), act);
-      o.z = act_fwd(fmaf(v.z, sc, sh), act); o.w = act_fwd(fmaf(v.w, sc, sh), act);
-      *reinterpret_cast<float4*>(yp + i) = o;
-    }
-  }
-}
-
-// backward: dz = dy * act'(z) is kept in LDS; csum[(b*C+c)*2 + {0,1}] = channel totals (for dgamma / dbeta, finished by
-// gn_bwd_params_kernel); dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat))
-__global__ void __launch_bounds__(256) gn_fused_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                            const float* __restrict__ res, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            double* __restrict__ csum, int C, int HW, int G, int act) {
-  PNSFM_DYN_SMEM(float, dzs);
-  __shared__ double red[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bg = blockIdx.x, b = bg / G, gi = bg - b * G, cpg = C / G;
-  const size_t base = ((size_t)b * C + (size_t)gi * cpg) * HW;
-  const float mu = mean[bg], rs = rstd[bg];
-  double A = 0.0, Bq = 0.0;
-  for (int cl = wave; cl < cpg; cl += 4) {
-    const int c = gi * cpg + cl;
-    const float ga = gamma[c], be = beta[c];
-    const size_t off = base + (size_t)cl * HW;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 4 * lane; i < HW; i += 256) {
-      float4 v = *reinterpret_cast<const float4*>(x + off + i);
-      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + off + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-      const float4 d = *reinterpret_cast<const float4*>(dy + off + i);
-      const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
-      float zz[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (vv[k] - mu) * rs;
-        zz[k] = dd[k] * act_grad(fmaf(xh, ga, be), act);
-        s1 += (double)zz[k];
-        s2 += (double)zz[k] * (double)xh;
-      }
-      *reinterpret_cast<float4*>(dzs + cl * HW + i) = make_float4(zz[0], zz[1], zz[2], zz[3]);
-    }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if (lane == 0) {
-      csum[((size_t)b * C + c) * 2 + 0] = s1;
-      csum[((size_t)b * C + c) * 2 + 1] = s2;
-    }
-    A += (double)ga * s1;
-    Bq += (double)ga * s2;
-  }
-  if (lane == 0) { red[2 * wave] = A; red[2 * wave + 1] = Bq; }
-  __syncthreads();
-  const double n = (double)cpg * (double)HW;
-  const float mA = (float)(((red[0] + red[2]) + (red[4] + red[6])) / n), mB = (float)(((red[1] + red[3]) + (red[5] + red[7])) / n);
-  for (int cl = wave; cl < cpg; cl += 4) {
-    const int c = gi * cpg + cl;
-    const float ga = gamma[c];
-    const size_t off = base + (size_t)cl * HW;
-    for (int i = 4 * lane; i < HW; i += 256) {
-      float4 v = *reinterpret_cast<const float4*>(x + off + i);
-      if (res) { const float4 q = *reinterpret_cast<const float4*>(res + off + i); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-      const float4 z = *reinterpret_cast<const float4*>(dzs + cl * HW + i);
-      const float vv[4] = {v.x, v.y, v.z, v.w}, zz[4] = {z.x, z.y, z.z, z.w};
-      float oo[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (vv[k] - mu) * rs;
-        oo[k] = rs * (zz[k] * ga - mA - xh * mB);
-      }
-      *reinterpret_cast<float4*>(dx + off + i) = make_float4(oo[0], oo[1], oo[2], oo[3]);
-    }
-  }
-}
-
-// the fused small-map path applies: float4 rows, the (sample, group) slab fits LDS, enough workgroups to matter
-static bool gn_fused_ok(int B, int C, int HW, int G) {
-  const size_t bytes = (size_t)(C / G) * HW * sizeof(float);
-  return HW % 4 == 0 && bytes <= (size_t)128 * 1024 && B * G >= 16;
-}
-template <class K>
-static int gn_raise_lds(K kernel, size_t bytes, bool* done) {
-#ifndef PNSFM_EMU
-  if (!*done && bytes > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("groupnorm: cannot raise the dynamic LDS limit");
-      return -1;
-    }
-    *done = true;
-  }
-#else
-  (void)kernel; (void)bytes; (void)done;
-#endif
-  return 0;
-}
-
 // Work split: T lanes per channel row so that a lane moves >= 4 float4 per pass when the map allows it; rows of one
 // workgroup are consecutive (b, c) channels; a row is cut into chunks only when B*C rows alone cannot give ~4 workgroups per CU.
 static GnGeom gn_geom(int BC, int HW, bool vec, int max_chunks) {
@@ -490,13 +348,6 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
                                 int act, void* stream) {
   if (C % G != 0 || B <= 0 || HW <= 0) { set_error("groupnorm_forward: bad shape C=%d G=%d", C, G); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  if (gn_fused_ok(B, C, HW, G)) {
-    static bool raised = false;
-    const size_t smem = (size_t)(C / G) * HW * sizeof(float);
-    if (gn_raise_lds(&gn_fused_fwd_kernel, smem, &raised)) return -1;
-    PNSFM_LAUNCH(gn_fused_fwd_kernel, dim3(B * G), dim3(256), smem, s, x, res, gamma, beta, y, mean, rstd, C, HW, G, eps, act);
-    return check_launch("gn_fused_fwd");
-  }
   const bool vec = (HW % 4 == 0);
   const int BC = B * C, cpg = C / G;
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
@@ -526,16 +377,6 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   double* csum = red_ws + (size_t)2 * BC * g.nchunk;
   float* gsum = reinterpret_cast<float*>(csum + (size_t)2 * BC);
   int e = 0;
-  if (gn_fused_ok(B, C, HW, G)) {
-    static bool raised = false;
-    const size_t smem = (size_t)(C / G) * HW * sizeof(float);
-    if (gn_raise_lds(&gn_fused_bwd_kernel, smem, &raised)) return -1;
-    PNSFM_LAUNCH(gn_fused_bwd_kernel, dim3(B * G), dim3(256), smem, s, dy, x, res, gamma, beta, mean, rstd, dx, csum, C, HW, G, act);
-    e = check_launch("gn_fused_bwd");
-    if (e) return e;
-    PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)csum, dgamma, dbeta, B, C);
-    return check_launch("gn_bwd_params");
-  }
   if (vec) PNSFM_LAUNCH((gn_bwd_reduce_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   else PNSFM_LAUNCH((gn_bwd_reduce_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_reduce");

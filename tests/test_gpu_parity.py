@@ -308,10 +308,7 @@ def test_conv2d_wgrad_tap_major_vs_cpu_oracle(shape):
 def test_groupnorm_vs_cpu_oracle():
     from packnet_sfm.hip import functional as HF, ops
     g = torch.Generator().manual_seed(5)
-    # the first three take the fused one-workgroup-per-(sample, group) kernels (slab <= 128 KB of LDS), the last two the
-    # chunked three-launch path
-    for (B, C, H, W, act) in [(2, 64, 48, 160, ops.ACT_ELU), (4, 512, 6, 20, ops.ACT_ELU), (2, 32, 24, 80, ops.ACT_RELU),
-                              (1, 64, 96, 320, ops.ACT_ELU), (2, 128, 48, 160, ops.ACT_RELU)]:
+    for (B, C, H, W, act) in [(2, 64, 48, 160, ops.ACT_ELU), (4, 512, 6, 20, ops.ACT_ELU), (2, 32, 24, 80, ops.ACT_RELU)]:
         x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
         r = torch.randn(B, C, H, W, generator=g)
         ga, be = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)

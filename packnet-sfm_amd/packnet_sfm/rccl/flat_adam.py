@@ -4,7 +4,7 @@ group are each ONE buffer, updated by ONE launch of the gfx950 `adam_flat_kernel
 hipGraph) instead of ~250 per-tensor updates.
 
 SURVEY.md 8(f) N1: the optimizer CONSUMES THE ALL-REDUCE BUCKETS IN PLACE.  The gradient arena is laid out in reverse
-registration order (the order backward produces gradients) and `grad_buckets()` cuts it into the contiguous <=128 MiB
+registration order (the order backward produces gradients) and `grad_buckets()` cuts it into the contiguous <=32 MiB
 slices that `GradBucketReducer` all-reduces, so reduce and update touch the same memory: no second flat gradient buffer,
 no gather pass.  The conv weight-gradient kernels even write straight into their slice of the arena
 (`hip.functional.register_grad_slots`), so for them not even the bucket gather copy exists; gradients produced elsewhere
@@ -71,7 +71,7 @@ class FlatAdam:
         o = group['_offs'][id(p)]
         return group['_grad'][o:o + p.numel()].view_as(p)
 
-    def grad_buckets(self, bucket_bytes=128 << 20):
+    def grad_buckets(self, bucket_bytes=32 << 20):
         """[(flat slice of the gradient arena, [parameters], [their views])] -- contiguous, cut at parameter boundaries, in
         the order backward fills them (last group first).  What GradBucketReducer all-reduces in place."""
         out = []

@@ -69,7 +69,7 @@ class DistributedOptimizer:
     """optimizer.zero_grad() / backward() / optimizer.step() with gradient averaging across ranks in between.
     Gradients are reduced bucket-by-bucket on a side stream while backward is still running."""
 
-    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=128 << 20,
+    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=32 << 20,
                  force_collectives=False):
         self._opt = optimizer
         params = [p for g in optimizer.param_groups for p in g['params']]

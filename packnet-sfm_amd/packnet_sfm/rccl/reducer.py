@@ -10,9 +10,12 @@ MI355X-first choices (not a translation of horovod's tensor-fusion queue):
     produces them).  Autograd hands each parameter its freshly computed gradient tensor (no accumulate pass, no
     zero-fill); when the last gradient of a bucket exists, ONE multi-tensor copy (`torch._foreach_copy_`) gathers the
     bucket and every `param.grad` is re-pointed at its bucket view, so the optimizer reads the reduced values in place;
-  * xGMI is point-to-point and a ring all-reduce is bound by one link (~153 GB/s), so a step wants few, big
-    collectives: the default bucket is 128 MiB (519.5 MB of PackNet01+PoseNet gradients -> 5 collectives; the
-    302 MB pack5 weight is its own bucket), and 288 GB of HBM makes the duplicate flat buffers free;
+  * xGMI is point-to-point and a ring all-reduce is bound by one link (~153 GB/s), so a step wants big collectives --
+    but the LAST bucket of a step completes when backward ends, so its all-reduce is fully exposed: with 128 MiB buckets
+    that was 112 MB (pack4.conv3d ... pre_calc: ~1 ms on 8 GPUs).  The default is therefore 32 MiB (large enough to run at
+    link speed: ~0.2 ms of transfer against ~30 us of latency), cut at parameter boundaries: 519.5 MB of PackNet01+PoseNet
+    gradients -> 10 collectives, the 302 MB pack5 and 75 MB pack4 weights are buckets of their own (they complete in the
+    middle of backward and hide behind the rest of it), <= 32 MB stays exposed at the end;
   * a bucket's all-reduce is enqueued on a dedicated side stream the moment its last gradient has been accumulated
     (post-accumulate-grad hooks), while the compute stream keeps running backward; `synchronize()` joins the side
     stream before the optimizer reads the gradients and applies the 1/world_size averaging.
@@ -75,7 +78,7 @@ class GradBucketReducer:
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
-    def __init__(self, params, bucket_bytes=128 << 20, process_group=None, average=True, force_collectives=False, buckets=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True, force_collectives=False, buckets=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)

@@ -52,11 +52,48 @@ def to_tensor(img):
     return torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float().div(255)
 
 
+CROP_CASES = [  # (config value, (H, W)): the forms the reference's parse_crop_borders accepts (utils/misc.py:77-146)
+    ((), (41, 70)), ((5, 32, 3, 64), (41, 70)), ((-36, 0, -67, 0), (41, 70)), ((-36, -4, 3, -3), (41, 70)),
+    ((0.5, 20, 0.5, 40), (41, 70)), ((0.25, 10, 3, 64), (41, 70)), ((5, 3), (41, 70)), ((-5, -3), (41, 70)), ((-5, 3), (41, 70)),
+    ((-352, 0, 0.5, 1216), (375, 1242)),
+]
+
+
+def parse_crop_borders(borders, shape):
+    """Restatement of the reference's utils/misc.py:77-146 (config crop value + image (H, W) -> (left, top, right, bottom)).
+    Pinned against the reference itself for CROP_CASES by oracle/pin_against_reference.py."""
+    if len(borders) == 0:                                        # :98-99
+        return 0, 0, shape[1], shape[0]
+    b = list(borders)
+    if len(b) == 4:                                              # :103-122  (y, height, x, width) -> [x, y, width, height]
+        b = [b[2], b[0], b[3], b[1]]
+        for lo, hi, size in ((0, 2, shape[1]), (1, 3, shape[0])):
+            if isinstance(b[lo], int):                           # regular crop: negative start from the far edge, extent <= 0 too
+                if b[lo] < 0:
+                    b[lo] += size
+                b[hi] += size if b[hi] <= 0 else b[lo]
+            else:                                                # centre crop: fraction of the image, extent centred on it
+                c, half = b[lo] * size, b[hi] / 2
+                b[lo], b[hi] = int(c - half), int(c + half)
+    elif len(b) == 2:                                            # :124-137  (y, x) -> [x, y]
+        b = [b[1], b[0]]
+        if isinstance(b[0], int):
+            b = (max(0, b[0]), max(0, b[1]), shape[1] + min(0, b[0]), shape[0] + min(0, b[1]))
+        else:
+            cw, ch, half = b[0] * shape[1], b[0] * shape[0], b[1] / 2
+            b = (int(cw - half), int(ch - half), int(cw + half), int(ch + half))
+    else:
+        raise NotImplementedError('Crop tuple must have 2 or 4 values.')
+    assert 0 <= b[0] < b[2] <= shape[1] and 0 <= b[1] < b[3] <= shape[0], 'Crop borders {} are invalid'.format(b)   # :141-144
+    return tuple(b)
+
+
 def train_transforms(sample, image_shape, jittering, crop_train_borders=()):
-    """sample: {'rgb': PIL, 'rgb_context': [PIL], 'intrinsics': np [3,3]} -> as the reference's train_transforms (image keys)."""
+    """sample: {'rgb': PIL, 'rgb_context': [PIL], 'intrinsics': np [3,3]} -> as the reference's train_transforms (image keys;
+    datasets/transforms.py:10-39: crop borders are the CONFIG value, resolved per image through parse_crop_borders :26-28)."""
     sample = dict(sample)
     if len(crop_train_borders) > 0:
-        b = crop_train_borders
+        b = parse_crop_borders(crop_train_borders, sample['rgb'].size[::-1])
         K = np.copy(sample['intrinsics']); K[0, 2] -= b[0]; K[1, 2] -= b[1]
         sample['intrinsics'] = K
         sample['rgb'] = sample['rgb'].crop(b)

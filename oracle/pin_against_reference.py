@@ -548,10 +548,27 @@ def pin_san():
     print('  PackNetSAN01 dense path == PackNetSlim01 (keys and outputs): OK')
 
 
+def pin_crop():
+    """The reference's own parse_crop_borders (utils/misc.py:77-146) on augment_oracle.CROP_CASES: the oracle's restatement must
+    return the same borders; the reference's answers are stored as tests/golden/crop.pt (a few integers)."""
+    from packnet_sfm.utils.misc import parse_crop_borders as ref_parse
+    from oracle import augment_oracle as AO
+    fx = []
+    for spec, shape in AO.CROP_CASES:
+        ref = tuple(int(v) for v in ref_parse(spec, shape))
+        assert ref == tuple(AO.parse_crop_borders(spec, shape)), (spec, shape, ref)
+        fx.append((spec, shape, ref))
+    torch.save(fx, os.path.join(GOLD, 'crop.pt'))
+    print('  parse_crop_borders: oracle == reference on %d cases; wrote crop.pt' % len(fx))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     gen = torch.Generator().manual_seed(20260923)
     only = sys.argv[1:]
+    if only == ['crop']:
+        pin_crop()
+        return
     if only == ['san']:
         pin_san()
         return
@@ -575,6 +592,7 @@ def main():
     fx = case_slim(torch.Generator().manual_seed(20260924))
     torch.save(fx, os.path.join(GOLD, 'slim.pt'))
     pin_san()
+    pin_crop()
     torch.save(case_nrs(torch.Generator().manual_seed(20260925)), os.path.join(GOLD, 'nrs.pt'))
     print('oracle pinned against /root/reference: OK')
 

@@ -31,17 +31,38 @@ int check_launch(const char* what) {
 
 // ---- per-stream scratch ---------------------------------------------------------------------------------------------
 // Two-stage reductions (wgrad3's pixel splits, the loss scalars) need a few KB .. tens of MB that live from one kernel to
-// the next ON THE SAME STREAM.  The library keeps one grow-only device buffer per stream: stream order already serialises
-// its users, so nothing is allocated, freed or synchronised in steady state (hipMallocAsync / hipFreeAsync per call measured
-// -3.3 % on the training step: 126.2 -> 121.8 img/s), and the pointers are stable under hipGraph capture.  A buffer that
-// has to grow is replaced; the old one is kept until process exit because kernels already enqueued may still use it
+// the next ON THE SAME STREAM.  The library keeps one grow-only device buffer per (device, stream) -- the null stream's handle is
+// the same on every device, so the device is part of the key: stream order already serialises its users, so nothing is
+// allocated, freed or synchronised in steady state (hipMallocAsync / hipFreeAsync per call measured -3.3 % on the training
+// step: 126.2 -> 121.8 img/s), and the pointers are stable under hipGraph capture.  This is the ONE place the library owns
+// device memory (include/pnsfm.h): a buffer that has to grow is replaced, and the old one -- kernels already enqueued may
+// still use it -- is retired behind an event recorded on its stream and freed by a later call once that event has completed
 // (growth only happens while the first steps discover the sizes).
 struct Scratch { void* p = nullptr; size_t cap = 0; };
+struct ScratchKey { int dev; hipStream_t stream; };
 static std::mutex g_scratch_mu;
-static std::vector<std::pair<hipStream_t, Scratch>> g_scratch;
+static std::vector<std::pair<ScratchKey, Scratch>> g_scratch;
+#ifndef PNSFM_EMU
+struct Retired { void* p; hipEvent_t done; int dev; };
+static std::vector<Retired> g_retired;
+static void scratch_reap(int dev) {      // g_scratch_mu held
+  for (size_t i = 0; i < g_retired.size();) {
+    if (g_retired[i].dev == dev && hipEventQuery(g_retired[i].done) == hipSuccess) {
+      (void)hipEventDestroy(g_retired[i].done);
+      (void)hipFree(g_retired[i].p);
+      g_retired[i] = g_retired.back();
+      g_retired.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  (void)hipGetLastError();               // hipEventQuery's hipErrorNotReady is not an error of ours
+}
+#endif
 
 void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
   *async_owned = false;
+  int dev = 0;
 #ifndef PNSFM_EMU
   if (stream_capturing(stream)) {
     // hipGraph capture runs on a stream of its own and may not call hipMalloc: a stream-ordered allocation becomes a pair of
@@ -51,23 +72,33 @@ void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
     *async_owned = true;
     return p;
   }
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("scratch: hipGetDevice failed"); return nullptr; }
 #endif
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   Scratch* sc = nullptr;
   for (auto& e : g_scratch)
-    if (e.first == stream) { sc = &e.second; break; }
-  if (!sc) { g_scratch.emplace_back(stream, Scratch()); sc = &g_scratch.back().second; }
+    if (e.first.dev == dev && e.first.stream == stream) { sc = &e.second; break; }
+  if (!sc) { g_scratch.emplace_back(ScratchKey{dev, stream}, Scratch()); sc = &g_scratch.back().second; }
   if (bytes > sc->cap) {
     size_t cap = sc->cap ? sc->cap : (size_t)1 << 20;
     while (cap < bytes) cap *= 2;
     void* p = nullptr;
 #ifdef PNSFM_EMU
     p = malloc(cap);
+    if (p && sc->p) free(sc->p);        // the emulator runs every kernel synchronously: nothing is in flight
 #else
+    scratch_reap(dev);
     if (hipMalloc(&p, cap) != hipSuccess) p = nullptr;
+    if (p && sc->p) {
+      Retired r{sc->p, nullptr, dev};
+      if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess && hipEventRecord(r.done, stream) == hipSuccess)
+        g_retired.push_back(r);         // freed by a later scratch_get, once the stream has passed this point
+      else
+        (void)hipGetLastError();        // cannot track it: keep it alive (a one-off, bounded by the growth steps)
+    }
 #endif
     if (!p) { set_error("cannot allocate %zu bytes of scratch", cap); return nullptr; }
-    sc->p = p;          // (the previous buffer is deliberately not freed, see above)
+    sc->p = p;
     sc->cap = cap;
   }
   return sc->p;
@@ -79,6 +110,25 @@ void scratch_release(void* p, hipStream_t stream, bool async_owned) {
 #else
   (void)p; (void)stream; (void)async_owned;
 #endif
+}
+
+int ensure_lds_limit(const void* kernel, unsigned long long* mask, int bytes, const char* what) {
+#ifndef PNSFM_EMU
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("%s: hipGetDevice failed", what); return -1; }
+  const unsigned long long bit = 1ull << (dev & 63);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (*mask & bit) return 0;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    set_error("%s: cannot raise the dynamic LDS limit", what);
+    return -1;
+  }
+  *mask |= bit;
+#else
+  (void)kernel; (void)mask; (void)bytes; (void)what;
+#endif
+  return 0;
 }
 
 // ---- live timing -------------------------------------------------------------------------------

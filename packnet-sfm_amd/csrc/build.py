@@ -23,7 +23,9 @@ def _stale(target, deps):
 
 def build_hip(force=False, verbose=True):
     srcs = [os.path.join(HERE, s) for s in SOURCES]
-    deps = srcs + [os.path.join(HERE, "pnsfm_common.h"), os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
+    # every header a source includes: editing any of them (conv2d_bx3.h holds the dominant kernel) must trigger a rebuild
+    headers = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h"))
+    deps = srcs + headers + [os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
     if not force and not _stale(LIB, deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

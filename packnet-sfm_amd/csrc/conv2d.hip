@@ -205,7 +205,8 @@ ConvGeom conv_geom(int B, int Cin, int Cout, int H, int W, int ks, int S) {
 // First call for a new (kind, shape): time the candidate (NT, split) configurations on the caller's stream with
 // hipEvents (this synchronises -- it happens during warm-up only) and remember the fastest.  PNSFM_AUTOTUNE=0 disables.
 static int g_autotune = -1;
-static std::map<std::array<int, 7>, std::array<int, 2>> g_tuned;
+static std::map<std::array<int, 7>, std::array<int, 2>> g_tuned;    // database lines + the autotuner's own results
+static std::map<std::array<int, 7>, std::array<int, 2>> g_pinned;   // pnsfm_tune_set: honoured in every build and mode
 static std::mutex g_tune_mu;
 
 // Tuning database (the analogue of MIOpen's user find-db): PNSFM_TUNE_DB=<file> loads earlier decisions at start-up
@@ -284,6 +285,17 @@ static bool autotune_enabled() {
   }
   return g_autotune == 1;
 #endif
+}
+
+// (g_tune_mu held)  Decision for a shape: a pinned entry always wins; database / autotuner entries count only while autotuning is
+// on -- a test that switches it off and selects an un-tuned default variant gets exactly that variant, and the database
+// survives such a test untouched (the setters used to clear the whole map, shipped decisions included: ADVICE r02).
+static const std::array<int, 2>* tune_lookup(const std::array<int, 7>& key, bool tune) {
+  auto p = g_pinned.find(key);
+  if (p != g_pinned.end()) return &p->second;
+  if (!tune) return nullptr;
+  auto it = g_tuned.find(key);
+  return it == g_tuned.end() ? nullptr : &it->second;
 }
 
 struct ConvArgs {
@@ -828,15 +840,10 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
 #ifndef PNSFM_EMU
 #define PNSFM_BX3_ATTR(MTv, NTv)                                                                                   \
     do {                                                                                                           \
-      static bool done = false;                                                                                    \
-      if (!done && g.smem_bytes > 64 * 1024) {                                                                     \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_bx3_kernel<MTv, NTv>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSmemPipe) != hipSuccess) {    \
-          set_error("%s: cannot raise the dynamic LDS limit", what);                                               \
-          return -1;                                                                                               \
-        }                                                                                                          \
-        done = true;                                                                                               \
-      }                                                                                                            \
+      static unsigned long long done = 0; /* one bit per device */                                                 \
+      if (g.smem_bytes > 64 * 1024 &&                                                                              \
+          ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_bx3_kernel<MTv, NTv>), &done, (int)kMaxSmemPipe, what)) \
+        return -1;                                                                                                 \
     } while (0)
 #else
 #define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
@@ -851,15 +858,10 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     // more than 64 KB of dynamic LDS needs an explicit opt-in per kernel (once)
 #define PNSFM_PIPE_ATTR(MTv, NTv)                                                                                  \
     do {                                                                                                           \
-      static bool done = false;                                                                                    \
-      if (!done && g.smem_bytes > 64 * 1024) {                                                                     \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_pipe_kernel<MTv, NTv>),                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxSmemPipe) != hipSuccess) {    \
-          set_error("%s: cannot raise the dynamic LDS limit", what);                                               \
-          return -1;                                                                                               \
-        }                                                                                                          \
-        done = true;                                                                                               \
-      }                                                                                                            \
+      static unsigned long long done = 0; /* one bit per device */                                                 \
+      if (g.smem_bytes > 64 * 1024 &&                                                                              \
+          ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_pipe_kernel<MTv, NTv>), &done, (int)kMaxSmemPipe, what)) \
+        return -1;                                                                                                 \
     } while (0)
 #else
 #define PNSFM_PIPE_ATTR(MTv, NTv) do {} while (0)
@@ -917,10 +919,10 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     const std::array<int, 7> key = {kind_tag + 10 * S + (bx3 ? 100 : 0), B, Cin, Cout, H, W, ks};
     const bool tune = autotune_enabled();        // (first call: reads the environment and loads PNSFM_TUNE_DB under the lock)
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto it = g_tuned.find(key);
+    const std::array<int, 2>* dec = tune_lookup(key, tune);
 #ifndef PNSFM_EMU
     // (a shape first seen inside a hipGraph capture cannot be timed -- timing synchronises: un-tuned default, not cached)
-    if (it == g_tuned.end() && tune && !stream_capturing(stream)) {
+    if (!dec && tune && !stream_capturing(stream)) {
       static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
@@ -940,14 +942,14 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
           if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8), c.splitK}; }
         }
       }
-      it = g_tuned.emplace(key, best).first;
+      dec = &g_tuned.emplace(key, best).first->second;
       tune_db_append(key, best);
     }
 #endif
-    if (it != g_tuned.end()) {
+    if (dec) {
       ConvGeom t;
-      const int DA = (it->second[0] >> 4) & 7;
-      if ((DA >= 3) == bx3 && conv_geom_fixed(B, Cin, Cout, H, W, ks, it->second[0] & 15, it->second[1], t, DA, S, (it->second[0] >> 8) & 1)) g = t;
+      const int DA = ((*dec)[0] >> 4) & 7;
+      if ((DA >= 3) == bx3 && conv_geom_fixed(B, Cin, Cout, H, W, ks, (*dec)[0] & 15, (*dec)[1], t, DA, S, ((*dec)[0] >> 8) & 1)) g = t;
     }
   }
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
@@ -1409,10 +1411,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     const std::array<int, 7> key = {2 + 10 * S + (v3_ok ? 100 : 0), B, Cin, Cout, a.cstride, W, ks};
     const bool tune = autotune_enabled();
     std::lock_guard<std::mutex> lk(g_tune_mu);
-    auto it = g_tuned.find(key);
+    const std::array<int, 2>* dec = tune_lookup(key, tune);
 #ifndef PNSFM_EMU
     // (first seen inside a hipGraph capture: keep the analytic split -- timing would synchronise)
-    if (it == g_tuned.end() && tune && !stream_capturing(s)) {
+    if (!dec && tune && !stream_capturing(s)) {
       float best_ms = 1e30f;
       int best_split = a.splitP, prev_tps = -1;
       const long base = (long)n_tiles * m_tiles;
@@ -1464,17 +1466,17 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
             }
           }
       }
-      it = g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first;
-      tune_db_append(key, it->second);
+      dec = &g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first->second;
+      tune_db_append(key, *dec);
     }
 #endif
-    (void)tune;
-    if (it != g_tuned.end()) {
-      variant = ((it->second[1] & 15) == 1 && v2_ok) ? 1 : (((it->second[1] & 15) == 2 && v3_ok) ? 2 : 0);
-      if (variant == 2) { split3 = it->second[0]; nt3 = ((it->second[1] >> 4) & 3) == 2 ? 2 : 1; wm3 = (it->second[1] >> 6) & 7; }
-      else if (variant == 1) split2 = it->second[0];
+    if (dec) {
+      const int d0 = (*dec)[0], d1 = (*dec)[1];
+      variant = ((d1 & 15) == 1 && v2_ok) ? 1 : (((d1 & 15) == 2 && v3_ok) ? 2 : 0);
+      if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 7; }
+      else if (variant == 1) split2 = d0;
       else {
-        int sp = it->second[0];
+        int sp = d0;
         if (sp < 1) sp = 1;
         if (sp > a.total_tiles) sp = a.total_tiles;
         a.tiles_per_split = ceil_div(a.total_tiles, sp);
@@ -1532,14 +1534,14 @@ int pnsfm_set_autotune(int on) {
 int pnsfm_tune_set(const int* key7, int v0, int v1) {
   if (!key7) { set_error("tune_set: null key"); return -1; }
   std::lock_guard<std::mutex> lk(g_tune_mu);
-  g_tuned[{key7[0], key7[1], key7[2], key7[3], key7[4], key7[5], key7[6]}] = {v0, v1};
+  g_pinned[{key7[0], key7[1], key7[2], key7[3], key7[4], key7[5], key7[6]}] = {v0, v1};
   return 0;
 }
 
 int pnsfm_set_wgrad_variant(int tap_major) {
   g_wgrad_variant = (tap_major < 0 || tap_major > 2) ? -1 : tap_major;
   std::lock_guard<std::mutex> lk(g_tune_mu);
-  g_tuned.clear();
+  g_pinned.clear();       // pins only: database / autotuner decisions stay (they are ignored while autotuning is off)
   return 0;
 }
 
@@ -1547,7 +1549,7 @@ int pnsfm_set_conv_variant(int lds_dma) {
   if (lds_dma >= 3) g_default_bx3 = lds_dma > 5 ? 5 : lds_dma;     // 3..5: un-tuned default of the split-bf16 kernels
   else g_default_dma = lds_dma < 0 ? 0 : lds_dma;
   std::lock_guard<std::mutex> lk(g_tune_mu);
-  g_tuned.clear();
+  g_pinned.clear();       // pins only (see pnsfm_set_wgrad_variant)
   return 0;
 }
 

@@ -272,15 +272,10 @@ static int launch_wgrad2(Wgrad2Args a, dim3 grid, hipStream_t s) {
   using Gm = Wgrad2Geom<KS, FC>;
   const size_t smem = 2 * (size_t)Gm::BUF * sizeof(float);
 #ifndef PNSFM_EMU
-  static bool raised = false;
-  if (!raised && smem > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad2_kernel<KS, FC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
-      return -1;
-    }
-    raised = true;
-  }
+  static unsigned long long raised = 0;      // one bit per device
+  if (smem > 64 * 1024 && ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_wgrad2_kernel<KS, FC>), &raised, 160 * 1024,
+                                           "conv2d_backward_weight"))
+    return -1;
 #endif
   PNSFM_LAUNCH((conv2d_wgrad2_kernel<KS, FC>), grid, dim3(256), smem, s, a);
   return check_launch("conv2d_backward_weight (tap-major)");

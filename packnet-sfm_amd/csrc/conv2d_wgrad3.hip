@@ -405,15 +405,11 @@ template <int KS, int NT, int WM, int TC, bool MASKED>
 static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
   using Gm = Wgrad3Geom<KS, NT, WM, TC>;
 #ifndef PNSFM_EMU
-  static bool raised = false;
-  if (!raised && Gm::SMEM > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      set_error("conv2d_backward_weight: cannot raise the dynamic LDS limit");
-      return -1;
-    }
-    raised = true;
-  }
+  static unsigned long long raised = 0;      // one bit per device
+  if (Gm::SMEM > 64 * 1024 &&
+      ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), &raised, 160 * 1024,
+                       "conv2d_backward_weight"))
+    return -1;
 #endif
   PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
   return check_launch("conv2d_backward_weight (split-bf16)");
@@ -445,13 +441,12 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.COP = co_groups * WM * 32;
   a.CIP = a.ci_tiles * 32 * NT;
   a.ws = nullptr; a.ws_bias = nullptr;
-  bool ws_async = false;
+  // pixel-split launch: partial tensors in the stream's scratch buffer (api.hip), summed by wgrad3_reduce_kernel
+  const size_t part = (size_t)ks * a.COP * ks * a.CIP;
+  ScratchLease lease(s, splitP > 1 ? ((size_t)splitP * (part + a.COP)) * sizeof(float) : 0);
   if (splitP > 1) {
-    // pixel-split launch: partial tensors in the stream's scratch buffer (api.hip), summed by wgrad3_reduce_kernel
-    const size_t part = (size_t)ks * a.COP * ks * a.CIP;
-    void* p = scratch_get(s, ((size_t)splitP * (part + a.COP)) * sizeof(float), &ws_async);
-    if (!p) return -1;
-    a.ws = (float*)p;
+    if (!lease.p) return -1;
+    a.ws = lease.as<float>();
     a.ws_bias = a.ws + (size_t)splitP * part;
   }
   dim3 grid(a.ci_tiles * ks, co_groups, splitP);
@@ -479,7 +474,6 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
                    dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout);
       rc = check_launch("conv2d_backward_weight (split-bf16, reduction)");
     }
-    scratch_release(a.ws, s, ws_async);
   }
   return rc;
 }

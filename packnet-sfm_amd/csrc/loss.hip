@@ -603,8 +603,8 @@ __global__ void photometric_clip_finish_kernel(const double* __restrict__ stats,
   }
 }
 
-// per-workgroup partial sums of a two-stage reduction live in the stream's scratch buffer (api.hip)
-static double* partials_alloc(int n, hipStream_t s, bool* async_owned) { return (double*)scratch_get(s, (size_t)n * sizeof(double), async_owned); }
+// per-workgroup partial sums of a two-stage reduction live in the stream's scratch buffer (api.hip; ScratchLease hands a
+// capture-time allocation back on every return path)
 
 int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target, double* loss_sum,
                                    uint8_t* argmin, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
@@ -619,8 +619,8 @@ int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const 
   if (e) { set_error("photometric_forward: memset failed"); return e; }
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
   const int nblk = (int)(grid.x * grid.y * grid.z);
-  bool part_async = false;
-  double* part = partials_alloc(nblk, s, &part_async);
+  ScratchLease lease(s, (size_t)nblk * sizeof(double));
+  double* part = lease.as<double>();
   if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
@@ -630,7 +630,6 @@ int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const 
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
-  scratch_release(part, s, part_async);
   return check_launch("photometric_forward_clip");
 }
 
@@ -648,14 +647,13 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
   const int nblk = (int)(grid.x * grid.y * grid.z);
-  bool part_async = false;
-  double* part = partials_alloc(nblk, s, &part_async);
+  ScratchLease lease(s, (size_t)nblk * sizeof(double));
+  double* part = lease.as<double>();
   if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
                C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
-  scratch_release(part, s, part_async);
   return check_launch("photometric_forward");
 }
 
@@ -688,12 +686,11 @@ int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* 
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(H * W, 256), B);
   const int nblk = (int)(grid.x * grid.y);
-  bool part_async = false;
-  double* part = partials_alloc(2 * nblk, s, &part_async);
+  ScratchLease lease(s, (size_t)2 * nblk * sizeof(double));
+  double* part = lease.as<double>();
   if (!part) return -1;
   PNSFM_LAUNCH(smoothness_fwd_kernel, grid, dim3(256), 0, s, inv_norm, image, part, H, W);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 2, sums);
-  scratch_release(part, s, part_async);
   return check_launch("smoothness_forward");
 }
 

@@ -149,10 +149,21 @@ namespace pnsfm {
 // error plumbing shared by every entry point (api.hip owns the storage)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
-// grow-only device scratch of the given stream (api.hip): valid until the next scratch_get on the same stream; null on failure.
-// Under hipGraph capture it is a stream-ordered allocation instead (*async_owned): always pair with scratch_release.
+// grow-only device scratch of the given (device, stream) (api.hip): valid until the next scratch_get on the same stream; null on
+// failure.  Under hipGraph capture it is a stream-ordered allocation instead (*async_owned): always pair with scratch_release --
+// ScratchLease does (every return path of an entry point hands a captured allocation back).
 void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned);
 void scratch_release(void* p, hipStream_t stream, bool async_owned);
+struct ScratchLease {
+  void* p;
+  hipStream_t stream;
+  bool async_owned;
+  ScratchLease(hipStream_t s, size_t bytes) : p(nullptr), stream(s), async_owned(false) { if (bytes) p = scratch_get(s, bytes, &async_owned); }
+  ~ScratchLease() { if (p) scratch_release(p, stream, async_owned); }
+  ScratchLease(const ScratchLease&) = delete;
+  ScratchLease& operator=(const ScratchLease&) = delete;
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
@@ -199,6 +210,10 @@ int wgrad3_WM(int Cout, int want);          // co tiles per workgroup (want: 0 =
 int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM);
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
                    int split, int NT, int WM, hipStream_t stream);
+
+// more than 64 KB of dynamic LDS needs hipFuncSetAttribute once per kernel AND device: `mask` (one static per kernel
+// instantiation) remembers the devices already done (api.hip).  0 on success.
+int ensure_lds_limit(const void* kernel, unsigned long long* mask, int bytes, const char* what);
 
 // profiling of the dominant kernels with events on the launch stream (see api.hip)
 void prof_begin(int kind, double flops, hipStream_t stream, const int* meta = nullptr);

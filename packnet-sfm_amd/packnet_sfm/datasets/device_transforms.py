@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from packnet_sfm.hip import ops
+from packnet_sfm.utils.misc import parse_crop_borders
 
 _PRECISION_BITS = 32 - 8 - 2          # libImaging/Resample.c
 
@@ -113,20 +114,22 @@ class DeviceTrainTransform:
     ----------
     image_shape : (H, W) or ()        output resolution
     jittering : (brightness, contrast, saturation, hue) or ()
-    crop_train_borders : (left, top, right, bottom) in pixels, or ()
+    crop_train_borders : the reference's config value -- (y, height, x, width) or (y, x), negative / float forms included --
+                         resolved against every incoming frame size by utils.misc.parse_crop_borders exactly like
+                         train_transforms does (datasets/transforms.py:26-29), or ()
     """
 
     def __init__(self, image_shape=(), jittering=(), crop_train_borders=(), jitter_prob=1.0):
         self.image_shape = tuple(image_shape)
         self.jittering = tuple(jittering)
-        self.borders = tuple(int(b) for b in crop_train_borders)
+        self.crop_spec = tuple(crop_train_borders)
         self.jitter_prob = jitter_prob
-        if self.borders and len(self.borders) != 4:
-            raise ValueError('crop_train_borders: (left, top, right, bottom) in pixels expected')
+        if self.crop_spec and len(self.crop_spec) not in (2, 4):
+            raise NotImplementedError('Crop tuple must have 2 or 4 values.')
 
-    def _geometry(self, frames):
-        if self.borders:
-            l, t, r, b = self.borders
+    def _geometry(self, frames, borders):
+        if borders:
+            l, t, r, b = borders
             frames = frames[:, t:b, l:r]
         if self.image_shape:
             frames = resize_frames(frames, self.image_shape)
@@ -139,15 +142,16 @@ class DeviceTrainTransform:
         B, H0, W0, _ = rgb.shape
         ctx = list(sample.get('rgb_context', []))
         # geometry: every frame of the batch (target + contexts) in one launch per pass
-        allf = self._geometry(torch.cat([rgb] + ctx, 0) if ctx else rgb)
+        borders = parse_crop_borders(self.crop_spec, (H0, W0)) if self.crop_spec else ()
+        allf = self._geometry(torch.cat([rgb] + ctx, 0) if ctx else rgb, borders)
         if 'intrinsics' in sample:
             K = sample['intrinsics'].clone()
-            if self.borders:
-                K[:, 0, 2] -= self.borders[0]
-                K[:, 1, 2] -= self.borders[1]
+            if borders:
+                K[:, 0, 2] -= borders[0]
+                K[:, 1, 2] -= borders[1]
             if self.image_shape:
-                hc = (self.borders[3] - self.borders[1]) if self.borders else H0
-                wc = (self.borders[2] - self.borders[0]) if self.borders else W0
+                hc = (borders[3] - borders[1]) if borders else H0
+                wc = (borders[2] - borders[0]) if borders else W0
                 K[:, 0] *= self.image_shape[1] / wc
                 K[:, 1] *= self.image_shape[0] / hc
             out['intrinsics'] = K

@@ -206,33 +206,58 @@ def set_wgrad_stream(on):
     _WgradStream.enabled = bool(on)
 
 
-# Gradient slots: id(parameter) -> tensor the parameter's gradient should be WRITTEN into (a view of the flat gradient arena
-# of rccl/flat_adam.py, which is also the all-reduce bucket).  Only used when the node's gradient is the parameter's only
-# one this step (leaf, used once, .grad undefined, no hooks -- exactly `side_ok`): then AccumulateGrad just adopts the view.
+# Gradient slots: id(parameter) -> (weak reference to the parameter, tensor its gradient should be WRITTEN into: a view of the
+# flat gradient arena of rccl/flat_adam.py, which is also the all-reduce bucket).  Only used when the node's gradient is the
+# parameter's only one this step (leaf, used once, .grad undefined, no hooks -- exactly `side_ok`): then AccumulateGrad just
+# adopts the view.  The entry dies with the parameter (weakref callback) and is only honoured while the weak reference still
+# points at the very tensor object asking -- CPython reuses ids, so a later model must never find a dead optimizer's arena.
 _GRAD_SLOTS = {}
 
 
+def _drop_slot(key, ref):
+    ent = _GRAD_SLOTS.get(key)
+    if ent is not None and ent[0] is ref:
+        del _GRAD_SLOTS[key]
+
+
 def register_grad_slots(pairs):
-    """pairs: iterable of (parameter, view).  Returns a handle whose .remove() unregisters them."""
-    keys = []
+    """pairs: iterable of (parameter, view).  Returns a handle whose .remove() unregisters them (also done automatically when a
+    parameter is garbage-collected, and when a newer optimizer registers the same parameter: the newer registration wins)."""
+    import weakref
+    mine = []
     for p, v in pairs:
-        _GRAD_SLOTS[id(p)] = v
-        keys.append(id(p))
+        key = id(p)
+        ref = weakref.ref(p, lambda r, key=key: _drop_slot(key, r))
+        _GRAD_SLOTS[key] = (ref, v)
+        mine.append((key, ref))
 
     class _Handle:
         def remove(self):
-            for k in keys:
-                _GRAD_SLOTS.pop(k, None)
+            for key, ref in mine:
+                _drop_slot(key, ref)
+            del mine[:]
     return _Handle()
+
+
+def _slot_of(p):
+    """The registered gradient slot of parameter `p`, or None (stale entries of a collected parameter never match)."""
+    if p is None:
+        return None
+    ent = _GRAD_SLOTS.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    return ent[1]
 
 
 def _slots_for(weight, bias, usable):
     if not usable or not _GRAD_SLOTS:
         return None, None
-    sw = _GRAD_SLOTS.get(id(weight))
-    sb = _GRAD_SLOTS.get(id(bias)) if bias is not None else None
+    sw = _slot_of(weight)
+    sb = _slot_of(bias)
     if sw is None or (bias is not None and sb is None):
         return None, None
+    if tuple(sw.shape) != tuple(weight.shape) or (bias is not None and sb.numel() != bias.numel()):
+        return None, None           # the parameter was re-shaped behind the optimizer's back: plain gradient path
     return sw, sb
 
 

@@ -63,6 +63,11 @@ class FlatAdam:
             self.param_groups.append(group)
             slots += [(p, self.grad_view(group, p)) for p in order]
         self._slots = HF.register_grad_slots(slots) if grad_slots else None
+        if self._slots is not None:
+            # the slots are views of THIS optimizer's gradient arena: they go when the optimizer goes (and, independently,
+            # when a parameter is collected or re-registered by a newer optimizer -- hip/functional.py)
+            import weakref
+            weakref.finalize(self, self._slots.remove)
         HF.bump_weight_epoch()
 
     # ---- arena access -------------------------------------------------------------------------------------------------
@@ -114,27 +119,46 @@ class FlatAdam:
                 p.grad = None
 
     def _gather_grads(self, g):
-        """Make g['_grad'] hold the gradients: no copy for gradients that already live in their arena slice."""
-        src, dst = [], []
+        """Make g['_grad'] hold the gradients: no copy for gradients that already live in their arena slice.  Returns the
+        parameters that have NO gradient this step."""
+        src, dst, missing = [], [], []
         for p in g['_order']:
             view = self.grad_view(g, p)
             if p.grad is None:
                 view.zero_()
+                missing.append(p)
             elif p.grad.data_ptr() != view.data_ptr():
                 src.append(p.grad.detach().reshape(view.shape))
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)
+        return missing
 
     @torch.no_grad()
     def step(self, closure=None):
+        """One Adam update per group = one `adam_flat_kernel` launch over the whole arena.
+
+        A parameter whose .grad is None is SKIPPED like torch.optim.Adam does (parameter, exp_avg and exp_avg_sq keep their
+        values: they are saved around the flat launch and restored -- three small multi-tensor copies, only on steps that
+        have such parameters; e.g. PackNetSAN01's sparse-depth branch on batches without input_depth).  One deviation
+        remains and is deliberate: the step counter is per GROUP (a device-resident scalar, which is what makes the launch
+        hipGraph-replayable), so a parameter that skipped k steps uses the group's step in its bias corrections where torch
+        would use its own, k smaller; `state_dict()` reports the group's step for every parameter.  Under
+        hvd.DistributedOptimizer unused parameters arrive with ZERO gradients (the reducer fills their bucket slice, as
+        horovod's synchronize() does for the reference) and are therefore updated, exactly like the reference's DDP path."""
         loss = closure() if closure is not None else None
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         for g in self.param_groups:
-            self._gather_grads(g)
+            missing = self._gather_grads(g)
             if not capturing:
                 self._sync_group(g)
+            keep = None
+            if missing:
+                views = [g[k][g['_offs'][id(p)]:g['_offs'][id(p)] + p.numel()] for p in missing for k in ('_flat', '_m', '_v')]
+                keep = (views, [v.clone() for v in views])
             ops.adam_flat_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['_hp'])
+            if keep is not None:
+                torch._foreach_copy_(keep[0], keep[1])
         HF.bump_weight_epoch()      # parameters changed through raw pointers: invalidate packed conv weights
         return loss
 

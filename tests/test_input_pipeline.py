@@ -46,7 +46,9 @@ CASES = [  # B, H, W, image_shape, jittering, crop borders, seed
     (2, 37, 124, (19, 64), (0.2, 0.2, 0.2, 0.05), (), 0),          # KITTI-like 2x downscale + the YAML's jitter
     (1, 24, 40, (48, 56), (0.9, 0.9, 0.9, 0.5), (), 1),             # upscale; extreme factors (extrapolating blends, full hue range)
     (2, 40, 64, (), (0.3, 0.0, 0.4, 0.0), (), 2),                   # no resize; zero-width ranges
-    (2, 41, 70, (16, 32), (), (3, 5, 67, 37), 3),                   # crop + resize, no jitter
+    (2, 41, 70, (16, 32), (), (5, 32, 3, 64), 3),                   # crop (y, height, x, width) + resize, no jitter
+    (1, 41, 70, (16, 32), (0.2, 0.2, 0.2, 0.05), (-36, -4, 0.5, 40), 5),   # negative start / extent, float centre crop
+    (1, 41, 70, (), (), (-5, 3), 6),                                # two-value form
     (1, 30, 50, (30, 25), (0.2, 0.2, 0.2, 0.05), (), 4),            # one axis only
 ]
 
@@ -60,6 +62,22 @@ def test_device_train_transform_emulated(emulated_kernels, case):
 @pytest.mark.parametrize('case', CASES + [(4, 375, 1242, (192, 640), (0.2, 0.2, 0.2, 0.05), (), 9)])
 def test_device_train_transform_gpu(case):
     _run_case('cuda', *case)
+
+
+def test_parse_crop_borders_matches_oracle():
+    """utils.misc.parse_crop_borders (what DeviceTrainTransform resolves `crop_train_borders` with) against the oracle's
+    restatement of the reference's rules, itself pinned against the reference by oracle/pin_against_reference.py."""
+    from packnet_sfm.utils.misc import parse_crop_borders
+    for spec, shape in AO.CROP_CASES:
+        assert tuple(parse_crop_borders(spec, shape)) == tuple(AO.parse_crop_borders(spec, shape)), (spec, shape)
+    import os
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'crop.pt'), weights_only=False)
+    assert len(gold) == len(AO.CROP_CASES)
+    for spec, shape, ref in gold:           # the reference's own answers (oracle/pin_against_reference.py crop)
+        assert tuple(parse_crop_borders(spec, shape)) == tuple(ref) == tuple(AO.parse_crop_borders(spec, shape)), (spec, shape)
+    for bad in ((5, 32, 3, 640), (50, 3), (1, 2, 3)):
+        with pytest.raises((AssertionError, NotImplementedError)):
+            parse_crop_borders(bad, (41, 70))
 
 
 def test_hsv_round_trip_all_colours(emulated_kernels):

@@ -526,3 +526,86 @@ def test_conv2d_stride2(emulated_kernels, shape, variant):
     P.check(wh.grad, wr.grad, 1e-5, 'wgrad')
     P.check(bh.grad, br.grad, 1e-5, 'dbias')
     _lib.get().pnsfm_set_conv_variant(0)
+
+
+def test_flat_adam_skips_parameters_without_gradient(emulated_kernels):
+    """torch.optim.Adam skips a parameter whose .grad is None (value and moments frozen); FlatAdam's flat launch must leave such
+    parameters untouched too (they used to decay on stale momentum)."""
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    torch.manual_seed(4)
+    net_a = torch.nn.ModuleList([torch.nn.Linear(5, 7), torch.nn.Linear(5, 3)])
+    net_b = torch.nn.ModuleList([torch.nn.Linear(5, 7), torch.nn.Linear(5, 3)])
+    net_b.load_state_dict(net_a.state_dict())
+    ref = torch.optim.Adam(net_a.parameters(), lr=1e-2, weight_decay=1e-2)
+    opt = FlatAdam([{'params': list(net_b.parameters()), 'lr': 1e-2, 'weight_decay': 1e-2}])
+    x = torch.randn(4, 5)
+    for step in range(4):
+        ref.zero_grad(); opt.zero_grad()
+        use_second = step in (0, 3)                     # the second layer has no gradient on steps 1 and 2
+        for net in (net_a, net_b):
+            out = net[0](x).pow(2).sum() + (net[1](x).pow(2).sum() if use_second else 0.0)
+            out.backward()
+        frozen = [p.detach().clone() for p in net_b[1].parameters()]
+        ref.step(); opt.step()
+        if not use_second:
+            for p, q in zip(net_b[1].parameters(), frozen):
+                assert torch.equal(p.detach(), q), 'a parameter without a gradient moved'
+        for pa, pb in zip(net_a[0].parameters(), net_b[0].parameters()):
+            P.check(pb, pa, 1e-5, 'always-used parameter, step %d' % step)
+    sd = opt.state_dict()['state']
+    rsd = ref.state_dict()['state']
+    for i in (2, 3):                                    # moments of the sometimes-unused layer: frozen while unused, like torch
+        P.check(sd[i]['exp_avg'], rsd[i]['exp_avg'], 1e-5, 'exp_avg %d' % i)
+        P.check(sd[i]['exp_avg_sq'], rsd[i]['exp_avg_sq'], 1e-5, 'exp_avg_sq %d' % i)
+
+
+def test_grad_slots_die_with_their_parameters(emulated_kernels):
+    """hip.functional._GRAD_SLOTS is keyed by id(parameter): entries must vanish with the parameter / optimizer, a newer
+    optimizer over the same parameters must win, and a stale id must never match another tensor."""
+    import gc
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    base = len(HF._GRAD_SLOTS)
+    m = Conv2D(4, 32, 3, 1)
+    opt1 = FlatAdam([{'params': list(m.parameters()), 'lr': 1e-2}])
+    w = m.conv_base.weight
+    assert HF._slot_of(w).data_ptr() == opt1.grad_view(opt1.param_groups[0], w).data_ptr()
+    opt2 = FlatAdam([{'params': list(m.parameters()), 'lr': 1e-2}])       # re-registration: the newer arena wins ...
+    assert HF._slot_of(w).data_ptr() == opt2.grad_view(opt2.param_groups[0], w).data_ptr()
+    del opt1
+    gc.collect()                                                          # ... and the older optimizer's finalizer leaves it alone
+    assert HF._slot_of(w).data_ptr() == opt2.grad_view(opt2.param_groups[0], w).data_ptr()
+    x = torch.randn(1, 4, 6, 8)
+    m(x).pow(2).mean().backward()
+    assert w.grad.data_ptr() == opt2.grad_view(opt2.param_groups[0], w).data_ptr()
+    key = id(w)
+    ent = HF._GRAD_SLOTS[key]
+    other = torch.nn.Parameter(torch.zeros(32, 4, 3, 3))
+    HF._GRAD_SLOTS[id(other)] = ent                                       # simulate id reuse: an entry whose weakref is another tensor
+    assert HF._slot_of(other) is None
+    del HF._GRAD_SLOTS[id(other)]
+    del w, ent, opt2, m
+    gc.collect()
+    assert len(HF._GRAD_SLOTS) == base, 'slots outlived their parameters'
+
+
+def test_conv2d_bx3_edge_inputs_emulated(emulated_kernels):
+    """Same contract as tests/test_gpu_round3.py::test_conv2d_bx3_edge_inputs on the host-emulated kernel sources: values the
+    split cannot represent (+-inf, NaN, |x| >= 3.39e38) poison exactly their receptive field with non-finite outputs."""
+    from packnet_sfm.hip import ops
+    B, Cin, Cout, H, W, ks = 1, 16, 32, 6, 32, 3
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    wf, _ = ops.conv2d_pack(w)
+    clean = ops.conv2d_forward(x, wf, None, Cout, ks)
+    P.check(clean, torch.nn.functional.conv2d(x, w, padding=1), 1e-5, 'clean run')
+    for bad in (float('inf'), float('-inf'), float('nan'), 3.4e38):
+        xb = x.clone()
+        xb[0, 5, 2, 11] = bad
+        y = ops.conv2d_forward(xb, wf, None, Cout, ks)
+        touched = torch.zeros(H, W, dtype=torch.bool)
+        touched[1:4, 10:13] = True
+        assert not torch.isfinite(y[0][:, touched]).any(), bad
+        assert torch.equal(y[0][:, ~touched], clean[0][:, ~touched]), bad

@@ -65,69 +65,147 @@ def build_model(device, depth_net='PackNet01'):
     return model.to(device).train()
 
 
-def _cpu_baseline_one(H, W, threads, batch_size, steps):
-    """The oracle (oracle/packnet_oracle.py: the reference's algorithm restated on stock torch CPU ops) timed on
-    this box's host cores with `threads` intra-op threads: full training steps (fwd + loss + bwd + Adam), 1 warm-up +
-    `steps` timed; returns the best step time in seconds."""
+def _cpu_step_fn(H, W, batch_size):
+    """One CPU training step (fwd + loss + bwd + Adam) of the path, as a closure, and what ran it:
+    'reference' = the reference's own modules imported from /root/reference (only where that checkout exists: this container;
+    oracle/_refstubs.py stubs the third-party imports it lacks), 'port' = oracle/packnet_oracle.py, the restatement of the same
+    algorithm on stock torch CPU ops (the GPU box has no /root/reference)."""
+    batch = synthetic_batch(batch_size, H, W, 1234, 'cpu')
+    if os.path.isdir('/root/reference') and os.environ.get('PNSFM_CPU_BASELINE', '') != 'port':
+        try:
+            return _reference_step_fn(batch), 'reference'
+        except Exception as e:              # the oracle still gives a baseline
+            print('cpu_baseline: reference import failed (%s); timing the port' % e, file=sys.stderr)
     from oracle import packnet_oracle as O
-    torch.set_num_threads(threads)
     sd = {k: v.requires_grad_(True) for k, v in O.init_params(O.packnet01_param_shapes('1A'), seed=42).items()}
     psd = {k: v.requires_grad_(True) for k, v in O.init_params(O.posenet_param_shapes(2), seed=43).items()}
     opt = torch.optim.Adam([{'params': list(sd.values()), 'lr': 2e-4}, {'params': list(psd.values()), 'lr': 2e-4}])
-    batch = synthetic_batch(batch_size, H, W, 1234, 'cpu')
     kw = {k: LOSS_DEFAULTS[k] for k in ('num_scales', 'ssim_loss_weight', 'smooth_loss_weight', 'C1', 'C2',
                                          'photometric_reduce_op', 'automask_loss')}
-    times = []
-    for i in range(1 + steps):
-        t0 = time.time()
+
+    def step():
         opt.zero_grad()
         out = O.selfsup_forward(sd, psd, batch, flip=False, **kw)
         out['loss'].sum().backward()
         opt.step()
-        if i > 0:
-            times.append(time.time() - t0)
-    return min(times)
+    return step, 'port'
 
 
-def cpu_baseline(H, W, seconds_budget=45.0):
-    """CPU baseline = the oracle's training step on the host cores of this box (rank 0, N=1 only).  The intra-op thread
-    count is SWEPT (8/16/32/64, capped at the cores present: oversubscribing all 128+ hardware threads measured 3x slower
-    than 8 threads in round 1) at batch 1, the best count is re-timed at batch 4 (SURVEY.md 8d asks for both), and the
-    best images/sec is reported with `cores` = the threads that produced it.  Bounded sample: every leg is 1 warm-up + 1
-    timed step and the sweep stops when the time budget is spent."""
+def _reference_step_fn(batch):
+    """The reference's SelfSupModel + PackNet01 + PoseNet on CPU, run from a SUBPROCESS-free import: the reference package has the
+    same name as ours (packnet_sfm), so it is loaded under a private alias by temporarily swapping sys.modules."""
+    import importlib
+    saved = {k: v for k, v in sys.modules.items() if k == 'packnet_sfm' or k.startswith('packnet_sfm.')}
+    saved_path = list(sys.path)
+    for k in saved:
+        del sys.modules[k]
+    try:
+        sys.path.insert(0, '/root/reference')
+        sys.dont_write_bytecode = True
+        from oracle import _refstubs
+        _refstubs.install()
+        RefSelfSup = importlib.import_module('packnet_sfm.models.SelfSupModel').SelfSupModel
+        RefPackNet01 = importlib.import_module('packnet_sfm.networks.depth.PackNet01').PackNet01
+        RefPoseNet = importlib.import_module('packnet_sfm.networks.pose.PoseNet').PoseNet
+        torch.manual_seed(42)
+        model = RefSelfSup(**LOSS_DEFAULTS)
+        model.add_depth_net(RefPackNet01(dropout=0.0, version='1A'))
+        model.add_pose_net(RefPoseNet(nb_ref_imgs=2, rotation_mode='euler'))
+        model.train()
+        ref_mods = {k: v for k, v in sys.modules.items() if k == 'packnet_sfm' or k.startswith('packnet_sfm.')}
+    finally:
+        for k in [k for k in sys.modules if k == 'packnet_sfm' or k.startswith('packnet_sfm.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+        sys.path[:] = saved_path
+    opt = torch.optim.Adam([{'params': model.depth_net.parameters(), 'lr': 2e-4}, {'params': model.pose_net.parameters(), 'lr': 2e-4}])
+
+    def step():
+        # the reference's lazy imports (inside forward) must resolve to ITS modules
+        mine = {k: v for k, v in sys.modules.items() if k == 'packnet_sfm' or k.startswith('packnet_sfm.')}
+        for k in mine:
+            del sys.modules[k]
+        sys.modules.update(ref_mods)
+        try:
+            random.seed(0)
+            opt.zero_grad()
+            out = model(batch, progress=0.0)
+            out['loss'].sum().backward()
+            opt.step()
+            ref_mods.update({k: v for k, v in sys.modules.items() if k == 'packnet_sfm' or k.startswith('packnet_sfm.')})
+        finally:
+            for k in [k for k in sys.modules if k == 'packnet_sfm' or k.startswith('packnet_sfm.')]:
+                del sys.modules[k]
+            sys.modules.update(mine)
+    return step
+
+
+def _time_cpu_steps(step, warmup, timed):
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(timed):
+        t0 = time.time()
+        step()
+        out.append(time.time() - t0)
+    return out
+
+
+def cpu_baseline(H, W, seconds_budget=75.0):
+    """CPU baseline on the host cores of this box (rank 0, N=1 only): full training steps (fwd + loss + bwd + Adam) of the
+    reference path -- the reference's own modules where /root/reference exists (`kind: "reference"`), else the oracle port.
+    Bounded sample (BASELINE.md 3 / SURVEY 8d: median of >= 3 steps after a warm-up):
+      1. the intra-op thread count is SWEPT at batch 1 (8/16/32/64, capped at the cores present; 1 warm-up + 1 timed step
+         each -- oversubscribing all 128+ hardware threads measured 3x slower than 8 threads in round 1);
+      2. at the best count the batch-4 step (the bench workload's batch) is timed 1 warm-up + 3 steps: `value` = 4 / MEDIAN.
+    If the budget runs out before step 2 completes, the batch-1 leg at the best count is extended to 3 timed steps instead."""
     ncpu = os.cpu_count() or 8
     saved = torch.get_num_threads()
     t_start = time.time()
-    sweep = {}
+    sweep, kind = {}, None
+    step1, kind = _cpu_step_fn(H, W, 1)
+    first = True
     for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
-        sweep[th] = 1.0 / _cpu_baseline_one(H, W, th, 1, 1)
-        if time.time() - t_start > seconds_budget:
+        torch.set_num_threads(th)
+        sweep[th] = 1.0 / _time_cpu_steps(step1, 1 if first else 0, 1)[0]
+        first = False
+        if time.time() - t_start > 0.35 * seconds_budget:
             break
     best_th = max(sweep, key=sweep.get)
-    best, best_b = sweep[best_th], 1
-    b4 = None
-    if time.time() - t_start < seconds_budget:
-        b4 = 4.0 / _cpu_baseline_one(H, W, best_th, 4, 1)
-        if b4 > best:
-            best, best_b = b4, 4
+    torch.set_num_threads(best_th)
+    est_b4 = 4.0 / sweep[best_th] * 0.75 * 4        # ~4 batch-4 steps at (slightly better than) 4x the batch-1 time
+    times, nb = None, 4
+    if time.time() - t_start + est_b4 < seconds_budget:
+        step4, _ = _cpu_step_fn(H, W, 4)
+        times = _time_cpu_steps(step4, 1, 3)
+    else:
+        nb = 1
+        times = _time_cpu_steps(step1, 0, 3)
+    med = sorted(times)[len(times) // 2]
     torch.set_num_threads(saved)
-    return {'value': round(best, 4), 'unit': 'images/sec', 'cores': best_th, 'kind': 'port',
+    return {'value': round(nb / med, 4), 'unit': 'images/sec', 'cores': best_th, 'kind': kind,
             'thread_sweep_batch1': {str(k): round(v, 4) for k, v in sweep.items()},
-            'batch4_at_best_threads': round(b4, 4) if b4 else None, 'host_cpus': ncpu,
-            'sample': 'oracle (torch CPU fp32 restatement of the reference path), full train step (fwd+loss+bwd+Adam), %dx%d, '
-                      '1 warm-up + 1 timed step per leg; best of the thread sweep at batch 1 and of batch 4 at that thread '
-                      'count (batch %d won)' % (H, W, best_b)}
+            'timed_steps_s': [round(t, 3) for t in times], 'batch': nb, 'host_cpus': ncpu,
+            'sample': '%s, full train step (fwd+loss+bwd+Adam), %dx%d: thread sweep at batch 1 (1 timed step per count), then '
+                      'batch %d at %d threads: 1 warm-up + %d timed steps, value = batch / median'
+                      % ('the reference itself (/root/reference modules on torch CPU fp32)' if kind == 'reference' else
+                         'oracle port (torch CPU fp32 restatement of the reference path; no /root/reference on this box)',
+                         H, W, nb, best_th, len(times))}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json;
-    PMC counters cannot be collected from inside this process).  None if no profile has been committed."""
+def measured_traffic(H, W, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json; PMC
+    counters cannot be collected from inside this process).  Only returned for the workload the passes were collected on
+    (192x640 batch 4 unless the file says otherwise): None for any other shape, and None if no profile has been committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
+        shape = tuple(d.get('workload_shape', (192, 640, 4)))
+        if shape != (H, W, B):
+            return None
         d = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
         return {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
                 round(d.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(files[-1], ROOT)}
@@ -151,6 +229,134 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_of(timed, iso, value, H, W, B, world, ms_per_step, use_graph, nprof):
+    """`roofline` object of one workload from the library's per-launch event timing (pnsfm_prof_*: hipEvents recorded on the
+    launch stream around every conv launch of `nprof` eager steps)."""
+    from packnet_sfm.hip import functional as HF
+    (ms0, fl0, n0), (ms1, fl1, n1) = timed         # forward + backward-data launches, weight-gradient launches
+    (ims0, ifl0, in0), (ims1, ifl1, in1) = iso
+    if not (n0 > 0 and ms0 > 0):
+        return None
+    scale = (H * W) / (192.0 * 640.0)
+    ach = fl0 / (ms0 * 1e-3) / 1e12
+    # flops the conv kernels actually EXECUTE per step (the Conv3d*Conv2d collapse removes ~35 % of the reference's
+    # 1 232 GFLOP/image) -> utilisation of the matrix pipe over the whole step
+    exec_gflop_step = (fl0 + fl1) / float(nprof) / 1e9
+    # Arithmetic of the conv kernels.  'bx3': fp32 rebuilt on the bf16 matrix pipe (exact 3-way bf16 split of every operand, 6
+    # of the 9 piece products, fp32 accumulate: csrc/conv2d_bx3.h) -- each algorithmic MAC costs 6 bf16 MACs, so the pipe's
+    # ceiling in ALGORITHMIC fp32 flops is 2500 / 6 TFLOP/s.  'f32': v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s.
+    bx3 = HF.get_conv_math() == 'bx3'
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if bx3 else FP32_MFMA_PEAK_TFLOPS
+    traffic = measured_traffic(H, W, B)
+    return {
+        'bound': 'mfma',
+        'kernel': ('conv2d_bx3_kernel (fwd + dgrad implicit GEMM, fp32 from 6 bf16 MFMA products)' if bx3
+                   else 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)'),
+        'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+        'peak_detail': ('algorithmic fp32 flops against the bf16 dense MFMA peak (2500 TFLOP/s) / 6 products per MAC; '
+                        'executed bf16 rate = 6 x achieved = %.0f TFLOP/s; the 6-product instruction stream alone '
+                        'sustains 1838 TFLOP/s bf16 = 306 fp32-equivalent on this part (tools/micro/bf16x3_check.hip)'
+                        % (6 * ach)) if bx3 else 'v_mfma_f32_32x32x2_f32 dense peak',
+        'vs_f32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+        'measured_in': ('%d eager steps right after the timed region (same kernels and shapes; events cannot bracket nodes of a '
+                        'replayed hipGraph)' if use_graph else '%d eager steps after the timed region') % nprof,
+        # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
+        'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
+        'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4), 'flop_per_launch_avg': round(fl0 / n0, 1),
+        'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,
+                         'frac': round(fl1 / (ms1 * 1e-3) / 1e12 / peak, 4) if ms1 > 0 else None,
+                         'launches': int(n1), 'avg_launch_ms': round(ms1 / max(n1, 1), 4)},
+        'isolated': {       # same kernels with the weight-gradient side stream off (= the timed kernels by default)
+            'achieved': round(ifl0 / (ims0 * 1e-3) / 1e12, 2) if ims0 > 0 else None,
+            'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / peak, 4) if ims0 > 0 else None,
+            'vs_f32_mfma_peak': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
+            'avg_launch_ms': round(ims0 / max(in0, 1), 4),
+            'wgrad_achieved': round(ifl1 / (ims1 * 1e-3) / 1e12, 2) if ims1 > 0 else None},
+        'whole_step_vs_mfma_peak': {
+            'reference_flops': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            'executed_flops': round(exec_gflop_step / 1e3 / (ms_per_step * 1e-3) / FP32_MFMA_PEAK_TFLOPS, 4),
+            'executed_gflop_per_step': round(exec_gflop_step, 1)},
+    }
+
+
+def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, layer_table='', graph=False):
+    """W untimed warm-up steps, then exactly K timed steps between barrier + synchronize fences; max over ranks.  Returns the
+    measurement (elapsed seconds, final loss, conv-launch timing of a few extra eager steps)."""
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.hip import ops
+    rank, world, device, ddp = ctx['rank'], ctx['world'], ctx['device'], ctx['ddp']
+    batch = synthetic_batch(B, H, W, 1234 + rank, device)
+
+    def eager_step():
+        optimizer.zero_grad()
+        out = model(batch, progress=0.0)
+        out['loss'].backward()
+        optimizer.step()
+        return out['loss']
+
+    def fence():
+        if ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # The library autotunes every layer shape on first use (timing synchronises, so it cannot happen inside a capture) and
+    # the caching allocator settles over the first steps: two untimed EAGER steps always run first, whatever --warmup says.
+    for _ in range(2):
+        eager_step()
+    fence()
+    step = eager_step
+    if graph:
+        from packnet_sfm.hip.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, batch, progress=0.0)
+        step = lambda: graphed(batch)      # noqa: E731  (copies the batch into the static inputs, draws the flip, replays)
+    for _ in range(warmup):
+        loss = step()
+    fence()
+    reducer = getattr(optimizer, '_reducer', None)
+    if reducer is not None:
+        reducer.exposed_reset(True)        # events around the end-of-backward join: all-reduce time NOT hidden behind backward
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    exposed = reducer.exposed_ms() if reducer is not None else None
+    if reducer is not None:
+        reducer.exposed_reset(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = {'elapsed': elapsed, 'loss': float(loss.detach().float().item()), 'timed': None, 'iso': None, 'nprof': 3,
+           'exposed_allreduce_ms_per_step': (round(exposed / steps, 4) if exposed is not None else None)}
+
+    # ---- roofline of the dominant kernel: per-launch hipEvent timing inside the library (pnsfm_prof_*), on the stream
+    # each kernel is launched on.  Events cannot bracket the nodes of a replayed graph, so the SAME step is run eagerly
+    # for a few extra steps right after the timed region: (a) as trained and (b), when weight gradients run on a side stream,
+    # with that stream off, i.e. each kernel alone (kernel quality).  rocprofv3 of this command shows the same kernels.
+    if want_prof:
+        def profiled(nsteps):
+            eager_step()
+            fence()
+            ops.prof_reset()
+            ops.prof_enable(True)
+            for _ in range(nsteps):
+                eager_step()
+            fence()
+            ops.prof_enable(False)
+            return ops.prof_collect(0), ops.prof_collect(1)
+        res['timed'] = profiled(res['nprof'])
+        if rank == 0 and layer_table:
+            ops.prof_dump(layer_table)
+        if HF._WgradStream.enabled:     # weight gradients on a side stream: measure the kernels alone as well
+            HF.set_wgrad_stream(False)
+            res['iso'] = profiled(res['nprof'])
+            HF.set_wgrad_stream(True)
+        else:                           # (default) every kernel already runs alone on the compute stream
+            res['iso'] = res['timed']
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,6 +369,9 @@ def main():
                     help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the short 384x1280 batch-2 measurement (BASELINE.json configs[2] shape) that the default 192x640 '
+                         'single-GPU run appends to its JSON line as `extra`')
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
@@ -191,7 +400,6 @@ def main():
 
     H, W, B = args.height, args.width, args.batch
     model = build_model(device, args.depth_net)
-    batch = synthetic_batch(B, H, W, 1234 + rank, device)
     force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
     ddp = world > 1 or force_ddp
     use_graph = args.graph == 'on'
@@ -207,141 +415,71 @@ def main():
     if ddp:
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                              compression=hvd.Compression.none, force_collectives=force_ddp)
+    ctx = {'rank': rank, 'world': world, 'device': device, 'ddp': ddp}
 
-    def eager_step():
-        optimizer.zero_grad()
-        out = model(batch, progress=0.0)
-        out['loss'].backward()
-        optimizer.step()
-        return out['loss']
+    m = run_workload(model, optimizer, H, W, B, args.steps, args.warmup, ctx, want_prof=not args.no_prof,
+                     layer_table=args.layer_table, graph=use_graph)
+    # configs[2] shape on the same model and optimizer, right behind the headline measurement (single GPU, default shape only)
+    extra = None
+    if world == 1 and not ddp and (H, W, B) == (192, 640, 4) and not args.no_extra and not use_graph and args.depth_net == 'PackNet01':
+        extra = run_workload(model, optimizer, 384, 1280, 2, 6, 1, ctx, want_prof=not args.no_prof)
 
-    def fence():
-        if ddp:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # The library autotunes every layer shape on first use (timing synchronises, so it cannot happen inside a capture) and
-    # the caching allocator settles over the first steps: two untimed EAGER steps always run first, whatever --warmup says.
-    for _ in range(2):
-        eager_step()
-    fence()
-    step = eager_step
-    if use_graph:
-        from packnet_sfm.hip.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, optimizer, batch, progress=0.0)
-        step = lambda: graphed(batch)      # noqa: E731  (copies the batch into the static inputs, draws the flip, replays)
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss.detach().float().item())
-
-    # ---- roofline of the dominant kernel: per-launch hipEvent timing inside the library (pnsfm_prof_*), on the stream
-    # each kernel is launched on.  Events cannot bracket the nodes of a replayed graph, so the SAME step is run eagerly
-    # for a few extra steps right after the timed region: (a) as trained -- weight gradients overlapped with the
-    # data-gradient chain on the side stream, i.e. durations of kernels SHARING the GPU -- and (b) with the side stream
-    # off, i.e. each kernel alone (kernel quality).  rocprofv3 of this command shows the same kernels in both regions.
-    timed = iso = None
-    if not args.no_prof:
-        def profiled(nsteps):
-            eager_step()
-            fence()
-            ops.prof_reset()
-            ops.prof_enable(True)
-            for _ in range(nsteps):
-                eager_step()
-            fence()
-            ops.prof_enable(False)
-            return ops.prof_collect(0), ops.prof_collect(1)
-        timed = profiled(3)
-        if rank == 0 and args.layer_table:
-            ops.prof_dump(args.layer_table)
-        was = HF._WgradStream.enabled
-        if was:                 # weight gradients on a side stream: measure the kernels alone as well
-            HF.set_wgrad_stream(False)
-            iso = profiled(2)
-            HF.set_wgrad_stream(True)
-        else:                   # (default) every kernel already runs alone on the compute stream
-            iso = timed
     if rank == 0:
-        images = B * world * args.steps
-        value = images / elapsed
-        scale = (H * W) / (192.0 * 640.0)
-        roofline = None
-        traffic = measured_traffic()
-        if timed is not None:
-            (ms0, fl0, n0), (ms1, fl1, n1) = timed     # conv2d_mfma_kernel (forward + backward-data), conv2d_wgrad_kernel
-            (ims0, ifl0, in0), (ims1, ifl1, in1) = iso
-            if n0 > 0 and ms0 > 0:
-                ach = fl0 / (ms0 * 1e-3) / 1e12
-                # flops the conv kernels actually EXECUTE per step (the Conv3d*Conv2d collapse removes ~35 % of the
-                # reference's 1 232 GFLOP/image) -> utilisation of the matrix pipe over the whole step
-                exec_gflop_step = (fl0 + fl1) / 3.0 / 1e9
-                # Arithmetic of the forward / backward-data kernels.  'bx3': fp32 rebuilt on the bf16 matrix pipe (exact 3-way
-                # bf16 split of every operand, 6 of the 9 piece products, fp32 accumulate: csrc/conv2d_bx3.h) -- each
-                # algorithmic MAC costs 6 bf16 MACs, so the pipe's ceiling in ALGORITHMIC fp32 flops is 2500 / 6 TFLOP/s.
-                # 'f32': v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s.
-                bx3 = HF.get_conv_math() == 'bx3'
-                peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if bx3 else FP32_MFMA_PEAK_TFLOPS
-                roofline = {
-                    'bound': 'mfma',
-                    'kernel': ('conv2d_bx3_kernel (fwd + dgrad implicit GEMM, fp32 from 6 bf16 MFMA products)' if bx3
-                               else 'conv2d_mfma_kernel (fwd + dgrad implicit GEMM)'),
-                    'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4),
-                    'peak_detail': ('algorithmic fp32 flops against the bf16 dense MFMA peak (2500 TFLOP/s) / 6 products per MAC; '
-                                    'executed bf16 rate = 6 x achieved = %.0f TFLOP/s; the 6-product instruction stream alone '
-                                    'sustains 1838 TFLOP/s bf16 = 306 fp32-equivalent on this part (tools/micro/bf16x3_check.hip)'
-                                    % (6 * ach)) if bx3 else 'v_mfma_f32_32x32x2_f32 dense peak',
-                    'vs_f32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                    'measured_in': '3 eager steps right after the timed region (same kernels and shapes; events cannot '
-                                   'bracket nodes of a replayed hipGraph)' if use_graph else '3 eager steps after the timed region',
-                    # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
-                    'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
-                    'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4),
-                    'flop_per_launch_avg': round(fl0 / n0, 1),
-                    'wgrad_kernel': {'achieved': round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else None,
-                                     'launches': int(n1), 'avg_launch_ms': round(ms1 / max(n1, 1), 4)},
-                    'isolated': {       # same kernels with the weight-gradient side stream off (= the timed kernels by default)
-                        'achieved': round(ifl0 / (ims0 * 1e-3) / 1e12, 2) if ims0 > 0 else None,
-                        'frac': round(ifl0 / (ims0 * 1e-3) / 1e12 / peak, 4) if ims0 > 0 else None,
-                        'vs_f32_mfma_peak': round(ifl0 / (ims0 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if ims0 > 0 else None,
-                        'avg_launch_ms': round(ims0 / max(in0, 1), 4),
-                        'wgrad_achieved': round(ifl1 / (ims1 * 1e-3) / 1e12, 2) if ims1 > 0 else None},
-                    'whole_step_vs_mfma_peak': {
-                        'reference_flops': round(value * GFLOP_PER_IMAGE_192x640 * scale / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'executed_flops': round(exec_gflop_step / 1e3 / (elapsed / args.steps) / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'executed_gflop_per_step': round(exec_gflop_step, 1)},
-                }
+        def line_of(meas, H, W, B, steps, warmup):
+            value = B * world * steps / meas['elapsed']
+            ms_step = 1e3 * meas['elapsed'] / steps
+            roof = None
+            if meas['timed'] is not None:
+                roof = roofline_of(meas['timed'], meas['iso'], value, H, W, B, world, ms_step, use_graph, meas['nprof'])
+            return value, ms_step, roof
+
+        value, ms_step, roofline = line_of(m, H, W, B, args.steps, args.warmup)
         backend = dist.get_backend() if dist.is_initialized() else None
         shape_tag = ('BASELINE.json configs[1]' if (H, W, B) == (192, 640, 4) else
                      ('BASELINE.json configs[2] shape' if (H, W, B) == (384, 1280, 2) else 'custom shape'))
+        bx3 = HF.get_conv_math() == 'bx3'
         result = {
             'metric': 'images/sec %s self-sup train %dx%d' % (args.depth_net, H, W), 'value': round(value, 3), 'unit': 'images/sec',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': args.depth_net + '(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
                                    'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (H, W, B, shape_tag),
-                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(loss_val, 6),
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(m['loss'], 6),
+                       # fp32 tensors and accumulators; the conv GEMMs as 6 bf16 MFMA products of exact 3-way operand splits
+                       'arithmetic': ('fp32 via 6xbf16 MFMA (exact 3-way bf16 operand split, fp32 accumulate; csrc/conv2d_bx3.h, '
+                                      'conv2d_wgrad3.hip; 1x1 / Cin<16 layers on v_mfma_f32_32x32x2_f32)') if bx3 else
+                                     'fp32 on v_mfma_f32_32x32x2_f32',
+                       'optimizer': ('FlatAdam (flat arenas = all-reduce buckets, conv weight gradients written in place)'
+                                     if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)'),
                        'wgrad_side_stream': bool(HF._WgradStream.enabled),
                        'tuning': ('user database %s' % os.environ['PNSFM_TUNE_DB']) if os.environ.get('PNSFM_TUNE_DB') else
                                  ('shipped database (%d decisions) + autotune for unlisted shapes' % ops.tune_shipped_entries()
                                   if ops.tune_shipped_entries() else 'autotune during warm-up'),
                        'step_launch': 'hipGraph replay (one graph per flip state)' if use_graph else 'eager',
-                       'collective_backend': backend, 'devices_visible': ndev},
+                       'collective_backend': backend, 'devices_visible': ndev,
+                       # ranks of the RCCL communicator the gradient all-reduce ran on (null: single process, no collective)
+                       'rccl_ranks': dist.get_world_size() if (dist.is_initialized() and backend == 'nccl') else None},
             'roofline': roofline,
         }
+        if ddp:
+            red = optimizer._reducer
+            result['config']['allreduce'] = {
+                'buckets': len(red.buckets), 'bytes_per_step': red.total_bytes,
+                'largest_bucket_bytes': max(b.flat.numel() * b.flat.element_size() for b in red.buckets),
+                'in_place_on_optimizer_arena': args.optimizer == 'flat',
+                # time the compute stream spent waiting for the communication stream at the end-of-backward join
+                'exposed_ms_per_step': m['exposed_allreduce_ms_per_step']}
         if world > ndev:
             result['config']['note'] = ('%d ranks share %d device(s): functional rehearsal of the N>1 path over gloo, not a '
                                         'scaling measurement' % (world, ndev))
+        if extra is not None:
+            ev, ems, eroof = line_of(extra, 384, 1280, 2, 6, 1)
+            result['extra'] = {'metric': 'images/sec PackNet01 self-sup train 384x1280', 'value': round(ev, 3), 'unit': 'images/sec',
+                               'ms_per_step': round(ems, 3), 'steps': 6, 'warmup': 1, 'n_gpus': 1,
+                               'config': {'workload': 'same model and optimizer, KITTI-shaped 384x1280 triplets, batch 2/GPU '
+                                                      '(BASELINE.json configs[2] shape)', 'global_batch': 2,
+                                          'final_loss': round(extra['loss'], 6)},
+                               'roofline': eroof}
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
         try:        # RCCL prints a version banner through C stdio (block-buffered when stdout is a file): push it out FIRST

@@ -10,7 +10,11 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 (unless typed otherwise), NCHW;
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing syncs;
- *   - outputs are caller-allocated; the library never allocates device memory;
+ *   - outputs and named workspaces are caller-allocated.  The ONE exception: the two-stage reductions (pixel-split weight
+ *     gradients, the loss scalars) keep their partial sums in a grow-only scratch buffer the library hipMalloc's itself, one per
+ *     (device, stream), outside the caller's allocator (csrc/api.hip: a few KB .. tens of MB; a buffer that has to grow is
+ *     replaced and the old one freed once the stream has passed it; under hipGraph capture the scratch is a stream-ordered
+ *     allocation that becomes memory nodes of the graph);
  *   - return value: 0 on success, non-zero on error (pnsfm_last_error() has the message).
  */
 #ifndef PNSFM_H
@@ -67,7 +71,8 @@ int pnsfm_tune_shipped_entries(void);
 /* Un-tuned default of the forward/backward-data kernel: 0 = halo patch staged through registers, 1 = patch double-buffered
  * by LDS-DMA (global_load_lds) issued in slices between the taps, 2 = the fully pipelined kernel (patch AND per-kernel-row
  * weight slabs double-buffered by LDS-DMA, one barrier per kernel row, up to 160 KB of LDS).  The autotuner times all
- * three; this switch exists for tests.  Clears the tuning cache. */
+ * three; this switch exists for tests.  Drops pnsfm_tune_set pins; database / autotuner decisions are kept (and ignored while
+ * autotuning is off). */
 int pnsfm_set_conv_variant(int lds_dma);
 /* Arithmetic of the forward / backward-data convolution kernels (stride 1 and 2, K-channels >= 16, k >= 3; other shapes
  * always use the f32 instruction):
@@ -79,13 +84,15 @@ int pnsfm_set_conv_variant(int lds_dma);
  * Variants 3..5 of pnsfm_set_conv_variant select the un-tuned LDS plan of the split kernels (3: one patch buffer, 4: two,
  * 5: two + a whole kernel row of weights per stage).  The packed-weight layout follows from (mode, shape):
  * pnsfm_conv2d_packed_elems_* already return the larger of the two sizes, but weights packed under one mode must be packed
- * again after a switch.  Returns the previous mode.  The weight-gradient kernels are f32-MFMA in both modes. */
+ * again after a switch.  Returns the previous mode.  Under mode 1 the weight gradient runs the same split arithmetic
+ * (conv2d_wgrad3.hip: stride 1, k in {3,5,7}, W % 4 == 0, >= 16 channels; tests/test_gpu_round3.py holds its error against fp64 to
+ * the f32 kernels' class at the step's real reduction lengths); other shapes and mode 0 use the f32-MFMA weight-gradient kernels. */
 int pnsfm_set_conv_math(int mode);
 int pnsfm_get_conv_math(void);
 /* Un-tuned choice of the weight-gradient kernel: 0 = generic ((ci, tap) columns, offset table; conv2d.hip), 1 = tap-major
  * f32 MFMA (dY fragments kept in registers across the taps, LDS-DMA double buffering; conv2d_wgrad2.hip; stride 1,
  * k in {1,3,5}, W % 8 == 0, >= 16 channels), 2 = split-bf16 arithmetic (conv2d_wgrad3.hip: one kernel row per workgroup, dY
- * straight from global memory, shifted X operands built in registers; stride 1, W % 8 == 0, >= 16 channels; only under
+ * straight from global memory, shifted X operands built in registers; stride 1, W % 4 == 0, >= 16 channels; only under
  * pnsfm_set_conv_math(1)), -1 = library default (2 where it applies, else 0).  The autotuner times all that apply.  For tests. */
 int pnsfm_set_wgrad_variant(int tap_major);
 /* Programmatic entry of the tuning database (what a PNSFM_TUNE_DB line does): key7 = {kind, B, Cin, Cout, H, W, ks} with

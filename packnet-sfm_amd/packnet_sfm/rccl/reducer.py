@@ -78,8 +78,12 @@ class GradBucketReducer:
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True, force_collectives=False, buckets=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True, force_collectives=False, buckets=None,
+                 overlap=None):
         self.group = process_group
+        # overlap=False (or PNSFM_DDP_OVERLAP=0): no collective starts before synchronize() -- the A/B leg that shows what the
+        # side-stream overlap with backward is worth (tests/rccl_two_ranks.py, bench.py)
+        self.overlap = (os.environ.get('PNSFM_DDP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
         self.force = bool(force_collectives) and dist.is_initialized()
@@ -129,6 +133,19 @@ class GradBucketReducer:
         self._launched = 0
         self._next = 0          # index of the next bucket to launch
         self._synced = False
+        self._exposed = None    # [(event before the join, event after it)] while bench.py measures the exposed all-reduce time
+
+    # ---- measurement: how long the compute stream waits for the communication stream at the end-of-backward join ---------
+    def exposed_reset(self, on):
+        self._exposed = [] if (on and self.side_stream is not None) else None
+
+    def exposed_ms(self):
+        """Sum over the recorded steps of the time between reaching the join and passing it on the compute stream = the part
+        of the gradient all-reduce that backward did NOT hide (None when not recording / no side stream)."""
+        if self._exposed is None:
+            return None
+        torch.cuda.synchronize(self.device)
+        return float(sum(a.elapsed_time(b) for a, b in self._exposed))
 
     def _close(self, params):
         b = _Bucket(params, params[0].device, params[0].dtype)
@@ -139,7 +156,7 @@ class GradBucketReducer:
     def _make_hook(self, bucket):
         def hook(param):
             bucket.pending -= 1
-            if bucket.pending == 0:
+            if bucket.pending == 0 and self.overlap:
                 self._launch_ready()
         return hook
 
@@ -212,12 +229,20 @@ class GradBucketReducer:
             self._gather(b)
             self._launch(b)
         self._next = len(self.buckets)
+        cur = torch.cuda.current_stream(self.device) if self.side_stream is not None else None
+        if self._exposed is not None and cur is not None:
+            before = torch.cuda.Event(enable_timing=True)
+            before.record(cur)                 # backward's last kernel is behind this point of the compute stream
         for b in self.buckets:
             if b.work is not None:
-                b.work.wait()
+                b.work.wait()                  # compute stream waits for the collective (stream-ordered, the host does not block)
                 b.work = None
         if self.side_stream is not None and (self.world > 1 or self.force):
-            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+            cur.wait_stream(self.side_stream)
+            if self._exposed is not None:
+                after = torch.cuda.Event(enable_timing=True)
+                after.record(cur)
+                self._exposed.append((before, after))
         if self.average and self.world > 1 and not self._fused_avg:
             scale = 1.0 / self.world
             for b in self.buckets:

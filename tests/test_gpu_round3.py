@@ -145,6 +145,13 @@ def _run_stack(steps, make_opt, x, tgt, check_arena=False):
     return net, losses
 
 
+def _noise_only(net):
+    """Names of conv biases feeding a GroupNorm with ONE channel per group: their gradient is mathematically zero, both runs see
+    pure round-off, and Adam turns the sign of that noise into +-lr steps (they do not influence the output)."""
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    return {n + '.conv_base.bias' for n, m in net.named_modules() if isinstance(m, Conv2D) and m.normalize.num_channels == m.normalize.num_groups}
+
+
 def _stack_inputs():
     g = torch.Generator().manual_seed(5)
     return torch.randn(2, 16, 32, 64, generator=g).to(DEV), torch.randn(2, 16, 32, 64, generator=g).to(DEV)
@@ -160,10 +167,10 @@ def test_flat_adam_arena_slots_on_real_blocks():
     net, lflat = _run_stack(3, lambda n: FlatAdam([{'params': list(n.parameters()), 'lr': 2e-3}]), x, tgt, check_arena=True)
     for a, b in zip(lflat, lref):
         assert abs(a - b) <= 1e-5 * abs(b), (lflat, lref)
+    skip = _noise_only(net)
+    assert skip == {'unpack.conv.conv_base.bias', 'head.conv_base.bias'}, skip
     for (name, p), q in zip(net.named_parameters(), ref.parameters()):
-        # conv biases in front of a GroupNorm have a mathematically zero gradient: Adam turns their round-off into +-lr steps in
-        # BOTH runs (sign of noise) -- they do not influence the output; everything else must agree to 1e-5 of the tensor scale
-        if name.endswith('conv_base.bias') or name.endswith('conv3.bias'):
+        if name in skip:
             continue
         P.check(p, q, 1e-5, 'parameter ' + name, floor=1e-2)
 
@@ -213,11 +220,12 @@ def test_forced_collectives_step_equals_plain_step():
             assert opt._reducer.force and len(opt._reducer.buckets) >= 3
             return opt
         ddp, lddp = _run_stack(3, make, x, tgt, check_arena=True)
-        assert lddp == pytest.approx(lplain, rel=1e-6)
+        assert lddp == pytest.approx(lplain, rel=1e-5)
+        skip = _noise_only(ddp)
         for (name, p), q in zip(ddp.named_parameters(), plain.parameters()):
-            if name.endswith('conv_base.bias') or name.endswith('conv3.bias'):
+            if name in skip:
                 continue
-            P.check(p, q, 1e-6, 'parameter ' + name, floor=1e-2)
+            P.check(p, q, 1e-5, 'parameter ' + name, floor=1e-2)
     finally:
         if created:
             dist.destroy_process_group()
@@ -265,3 +273,31 @@ def test_conv2d_bx3_edge_inputs():
         e = float(((y - y64).abs() / mag).max())
         print('inputs scaled by %.0e: max |err| / sum|x||w| = %.2e' % (scale, e))
         assert e <= 2.0 ** -7, (scale, e)
+
+
+# -------------------------------------------------------------------------- (e) two data-parallel ranks (RCCL when possible)
+def test_two_rank_gradient_averaging():
+    """tests/rccl_two_ranks.py under torch.distributed.run, 2 ranks: averaged gradients == the single-process full batch, the
+    parameters after two steps too, replicas bit-identical.  With >= 2 devices this is RCCL over xGMI (one device per rank) and the
+    step is also timed with the side-stream overlap on / off; on a 1-GPU box the two ranks share the device and the same code
+    runs over gloo with host-staged buckets (functional rehearsal)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(here, 'rccl_two_ranks.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, 'two-rank run failed:\nSTDOUT:\n%s\nSTDERR:\n%s' % (r.stdout[-3000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    print(line)
+    assert res['ok']
+    if torch.cuda.device_count() >= 2:
+        assert res['backend'] == 'nccl' and res['timing'] is not None

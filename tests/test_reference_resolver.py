@@ -117,3 +117,34 @@ def test_reference_loader_builds_our_packnet01_and_restores_a_reference_checkpoi
         print('OK', float(sum(v.double().sum() for v in net.state_dict().values())))
     ''' % (REF, PKG, ckpt, ckpt), [PKG, REF])
     assert out.strip().splitlines()[-1].startswith('OK')
+
+
+def test_reference_horovod_imports_resolve_to_the_rccl_facade():
+    """`import horovod.torch as hvd` (reference trainers/horovod_trainer.py:5, utils/horovod.py:3-7) unchanged: with our tree
+    on the path the import lands on the RCCL facade, and the REFERENCE's own utils/horovod.py -- executed from its file, not our
+    shadowing module -- runs its helpers on it (single process: rank 0 of 1; reduce_value is the identity)."""
+    out = _run('''
+        import importlib.util, torch
+        import horovod.torch as hvd
+        import packnet_sfm.rccl.hvd as facade
+        for name in ('init', 'rank', 'size', 'local_rank', 'allreduce', 'broadcast_parameters', 'DistributedOptimizer', 'Compression'):
+            assert getattr(hvd, name) is getattr(facade, name), name
+        assert hvd.Compression.none is None
+        spec = importlib.util.spec_from_file_location('ref_utils_horovod', %r)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)                     # the reference's file: `try: import horovod.torch as hvd`
+        assert ref.HAS_HOROVOD is True and ref.hvd is hvd
+        assert ref.hvd_init() is True and ref.rank() == 0 and ref.world_size() == 1
+        t = torch.arange(4.)
+        assert torch.equal(ref.reduce_value(t, average=True, name='x'), t)
+        # the reference's trainer module body imports cleanly against the shim (constructing it needs a GPU: set_device)
+        src = open(%r).read()
+        assert 'import horovod.torch as hvd' in src
+        spec = importlib.util.spec_from_file_location('ref_horovod_trainer', %r)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.hvd is hvd and hasattr(mod, 'HorovodTrainer')
+        print('OK')
+    ''' % (os.path.join(REF, 'packnet_sfm', 'utils', 'horovod.py'), os.path.join(REF, 'packnet_sfm', 'trainers', 'horovod_trainer.py'),
+           os.path.join(REF, 'packnet_sfm', 'trainers', 'horovod_trainer.py')), [PKG, REF])
+    assert out.strip().splitlines()[-1] == 'OK'

@@ -47,8 +47,16 @@ static int conv_math() {
   }
   return g_conv_math;
 }
-// K-channels >= 16 (one bf16 MFMA k-step is 16 channels) and a real stencil (1x1 layers are bandwidth-bound and tiny)
-bool conv_bx3_supported(int Kc, int ks) { return Kc >= 16 && ks >= 3; }
+// K-channels >= 16 (one bf16 MFMA k-step is 16 channels).  1x1 layers (the residual shortcuts) joined in round 3: on the f32
+// kernels they ran at 21-35 TFLOP/s -- one tap of 64-cycle MFMAs per staged chunk; PNSFM_BX3_1X1=0 keeps them there (A/B).
+static int g_bx3_1x1 = -1;
+bool conv_bx3_supported(int Kc, int ks) {
+  if (g_bx3_1x1 < 0) {
+    const char* e = getenv("PNSFM_BX3_1X1");
+    g_bx3_1x1 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return Kc >= 16 && (ks >= 3 || (ks == 1 && g_bx3_1x1 == 1));
+}
 static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_supported(Kc, ks); }
 
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
@@ -910,6 +918,11 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
   if (S != 1 && S != 2) { set_error("%s: unsupported stride %d", what, S); return -1; }
+  if (ks == 1 && S == 1 && (H * W) % 32 == 0 && W % 32 != 0) {
+    // no halo: any pixel order works, so a map whose width is not a multiple of 32 is tiled as 32-wide rows of the flattened
+    // image (whole 2-D tiles instead of linear runs whose patches span full-width rows)
+    H = (H * W) / 32; W = 32; Hi = H; Wi = W;
+  }
   ConvGeom g = conv_geom(B, Cin, Cout, H, W, ks, S);
   if (g.smem_bytes > (g.DMA >= 2 ? kMaxSmemPipe : kMaxSmem)) { set_error("%s: image too wide for the LDS halo patch (W=%d)", what, W); return -1; }
   {
@@ -1277,7 +1290,8 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
     const int nf = bxf ? (MPf / 32) * nchF : 0, nb = bxb ? (MPb / 32) * nchB : 0;
     unsigned char* const pf = reinterpret_cast<unsigned char*>(bxf ? wp_fwd : nullptr);
     unsigned char* const pb = reinterpret_cast<unsigned char*>(bxb ? wp_bwd : nullptr);
-    if (ks == 3) PNSFM_LAUNCH((pack_bx3_kernel<3>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
+    if (ks == 1) PNSFM_LAUNCH((pack_bx3_kernel<1>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
+    else if (ks == 3) PNSFM_LAUNCH((pack_bx3_kernel<3>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
     else if (ks == 5) PNSFM_LAUNCH((pack_bx3_kernel<5>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
     else PNSFM_LAUNCH((pack_bx3_kernel<7>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
   }
@@ -1393,9 +1407,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     return check_launch("conv2d_backward_weight");
   };
   // split-bf16 kernel (conv2d_wgrad3.hip): part of the split arithmetic mode (pnsfm_set_conv_math), the default there
-  const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H0, W0, ks) && wgrad3_fits(B, Cin, Cout, H0, W0);
+  // split-bf16 kernel: a 1x1 layer has no halo, so its map is handed over as 32-wide rows of the flattened image when that
+  // is exact (whole 16/32-column tiles instead of ragged ones for W = 40, 80)
+  const bool flat3 = ks == 1 && (H0 * W0) % 32 == 0;
+  const int H3 = flat3 ? (H0 * W0) / 32 : H0, W3 = flat3 ? 32 : W0;
+  const bool v3_ok = S == 1 && conv_math() == 1 && wgrad3_supported(Cin, Cout, H3, W3, ks) && wgrad3_fits(B, Cin, Cout, H3, W3);
   auto v3_default_split = [&](int NT) -> int {
-    const int base = wgrad3_base_blocks(Cin, Cout, ks, NT, 0), tiles = wgrad3_total_tiles(B, H0, W0);
+    const int base = wgrad3_base_blocks(Cin, Cout, ks, NT, 0), tiles = wgrad3_total_tiles(B, H3, W3);
     int split = (2 * 256 + base - 1) / base;            // two workgroups per CU
     if (split > tiles) split = tiles;
     return split < 1 ? 1 : split;
@@ -1446,7 +1464,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         }
       }
       if (v3_ok) {     // split-bf16 kernel: NT in {1, 2} x co tiles per workgroup x pixel splits around two workgroups per CU
-        const int tiles3 = wgrad3_total_tiles(B, H0, W0);
+        const int tiles3 = wgrad3_total_tiles(B, H3, W3);
         const int wm_most = wgrad3_WM(Cout, 0);
         for (int NT = 1; NT <= (wgrad3_nt2_ok(Cin, ks) ? 2 : 1); ++NT)
           for (int WMv = wm_most; WMv >= 1; WMv >>= 1) {
@@ -1460,7 +1478,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
               if ((long)base3 * split < 200 && split < tiles3) continue;      // cannot fill the chip
               if ((long)base3 * split > 16L * 256 && split > 1) break;
               if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
-              const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split, NT, WMv, s); });
+              const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, WMv, s); });
               tune_log(2, key, 2 | (NT << 4) | (WMv << 6), split, ms);
               if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6); }
             }
@@ -1488,7 +1506,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   if (variant == 2) {
     const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3};
     prof_begin(1, flops, s, meta);
-    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split3, nt3, wm3, s);
+    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split3, nt3, wm3, s);
     prof_end(1, s);
     return rc;
   }

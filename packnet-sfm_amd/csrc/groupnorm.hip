@@ -13,7 +13,12 @@
 //   * a workgroup owns ROWS x one pixel chunk, ROWS = channels (b, c) handled by 256/T threads groups of T lanes each, so
 //     that small maps (6x20: 30 float4 per channel) still give every lane work -- T = threads per channel row (power of 2);
 //   * per-(sample, group) statistics and per-(sample, channel) gradient sums are one slot per workgroup row/chunk: no zero
-//     fill, no atomics, deterministic; the consumer adds the <= PNSFM_GN_MAX_SPLIT partials.
+//     fill, no atomics, deterministic; the consumer adds the <= PNSFM_GN_MAX_SPLIT partials;
+//   * round 3: TWO launches per direction instead of three / four.  The bookkeeping kernels of round 2 (gn_finish: mean / rstd
+//     of every group from the slots; gn_bwd_group: group means of the gradient sums, dgamma / dbeta) moved 0 bytes and cost
+//     4.8-7.3 us of launch + dependency latency each, 108 of them per training step (0.65 ms): every workgroup of the apply
+//     kernels now adds the few partial slots of its own rows itself (all of them in the same order: identical bits), and the
+//     rows of sample 0 / chunk 0 also write mean, rstd, dgamma, dbeta.
 #include "pnsfm_common.h"
 #include "../../include/pnsfm.h"
 
@@ -100,35 +105,36 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
   }
 }
 
-// mean / rstd of every (sample, group) from the partial slots (one thread per (b, g); nslot <= a few hundred)
-__global__ void __launch_bounds__(64) gn_finish_kernel(const double* __restrict__ stats, float* __restrict__ mean_out,
-                                                       float* __restrict__ rstd_out, int BG, int nslot, double n, float eps) {
-  const int bg = blockIdx.x * 64 + threadIdx.x;
-  if (bg >= BG) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int k = 0; k < nslot; ++k) {
-    t1 += stats[((size_t)bg * nslot + k) * 2];
-    t2 += stats[((size_t)bg * nslot + k) * 2 + 1];
-  }
-  const double m = t1 / n;
-  double var = t2 / n - m * m;
-  if (var < 0.0) var = 0.0;
-  mean_out[bg] = (float)m;
-  rstd_out[bg] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
+// pass 2: every row adds the partial slots of its group (lanes of the row share the slots, fp64, fixed order), derives
+// mean / rstd exactly like every other row of that group, and normalises + activates its chunk.  The row of the group's first
+// channel in chunk 0 stores mean / rstd for the backward pass.
 template <bool VEC>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ y, int BC, int C, int HW, int G, int act, GnGeom g) {
+                                                        const double* __restrict__ stats, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, float* __restrict__ y, int BC, int C, int HW,
+                                                        int G, int act, double n, float eps, GnGeom g) {
+  __shared__ double red[4];
   const int tid = threadIdx.x;
   const int r = tid / g.T, l = tid - r * g.T;
-  const int bc = blockIdx.x * g.rows + r;
-  if (bc >= BC) return;
+  const int bc_raw = blockIdx.x * g.rows + r;
+  const bool valid = bc_raw < BC;
+  const int bc = valid ? bc_raw : BC - 1;           // surplus rows of the last workgroup shadow a real one (barriers stay uniform)
+  const int cpg = C / G;
   const int b = bc / C, c = bc - b * C;
-  const int gi = c / (C / G);
-  const float mu = mean[b * G + gi], rs = rstd[b * G + gi];
+  const int gi = c / cpg;
+  const int nslot = cpg * g.nchunk;
+  const double* sp = stats + (size_t)(b * G + gi) * nslot * 2;
+  double t1 = 0.0, t2 = 0.0;
+  for (int k = l; k < nslot; k += g.T) { t1 += sp[2 * k]; t2 += sp[2 * k + 1]; }
+  t1 = row_sum(t1, g.T, red);
+  t2 = row_sum(t2, g.T, red);
+  const double m = t1 / n;
+  double var = t2 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (!valid) return;
+  if (l == 0 && c == gi * cpg && blockIdx.y == 0) { mean_out[b * G + gi] = mu; rstd_out[b * G + gi] = rs; }
   const float sc = rs * gamma[c], sh = beta[c] - mu * sc;         // z = v * sc + sh
   const size_t base = (size_t)bc * HW;
   const int beg = blockIdx.y * g.chunk;
@@ -206,62 +212,53 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// ---- backward, pass 1b (one thread per (b, c) for the channel sums, then per (b, g)):
-//   csum[(b*C+c)*2 + {0,1}] = channel totals (for dgamma / dbeta);  gsum[(b*G+g)*2 + {0,1}] = { mean_g(dz*gamma), mean_g(dz*gamma*xhat) }
-__global__ void __launch_bounds__(256) gn_bwd_group_kernel(const double* __restrict__ red_ws, const float* __restrict__ gamma,
-                                                            double* __restrict__ csum, float* __restrict__ gsum, int B, int C,
-                                                            int G, int nchunk, double n, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
-  const int bg = blockIdx.x * 256 + threadIdx.x;
-  if (bg < B * G) {
-    const int cpg = C / G;
-    const int b = bg / G, gi = bg - b * G;
-    double A = 0.0, Bq = 0.0;
-    for (int k = 0; k < cpg; ++k) {
-      const int c = gi * cpg + k;
-      double r1 = 0.0, r2 = 0.0;
-      for (int j = 0; j < nchunk; ++j) {
-        r1 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 0];
-        r2 += red_ws[(((size_t)b * C + c) * nchunk + j) * 2 + 1];
-      }
-      csum[((size_t)b * C + c) * 2 + 0] = r1;
-      csum[((size_t)b * C + c) * 2 + 1] = r2;
-      A += (double)gamma[c] * r1;
-      Bq += (double)gamma[c] * r2;
-    }
-    gsum[bg * 2 + 0] = (float)(A / n);
-    gsum[bg * 2 + 1] = (float)(Bq / n);
-  }
-  // one workgroup holds every (b, g) (B * G <= 256: always, for the networks here): it also finishes dgamma / dbeta -- the
-  // sums over the batch of the channel totals it has just written -- instead of a fourth launch (gn_bwd_params_kernel)
-  if (dgamma != nullptr) {
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int b = 0; b < B; ++b) {
-        s1 += csum[((size_t)b * C + c) * 2 + 0];
-        s2 += csum[((size_t)b * C + c) * 2 + 1];
-      }
-      dbeta[c] = (float)s1;
-      dgamma[c] = (float)s2;
-    }
-  }
-}
-
-// ---- backward, pass 2: dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat))
+// ---- backward, pass 2: dx = rstd * (dz*gamma - mean_g(dz*gamma) - xhat * mean_g(dz*gamma*xhat)).  Every row first adds the
+// pass-1 slots of ITS group (channels of the group x chunks, weighted by gamma: fp64, lanes of the row share the work, the same
+// order in every row of the group); the rows of sample 0 in chunk 0 also finish dgamma / dbeta of their channel (sum of the
+// channel's slots over the batch) -- what gn_bwd_group_kernel / gn_bwd_params_kernel did in two further launches.
 template <bool VEC>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ res, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, const float* __restrict__ gsum,
-                                                            float* __restrict__ dx, int BC, int C, int HW, int G, int act, GnGeom g) {
+                                                            const float* __restrict__ rstd, const double* __restrict__ red_ws,
+                                                            float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int B, int C, int HW, int G, int act,
+                                                            double n, GnGeom g) {
+  __shared__ double red[4];
   const int tid = threadIdx.x;
   const int r = tid / g.T, l = tid - r * g.T;
-  const int bc = blockIdx.x * g.rows + r;
-  if (bc >= BC) return;
+  const int BC = B * C;
+  const int bc_raw = blockIdx.x * g.rows + r;
+  const bool valid = bc_raw < BC;
+  const int bc = valid ? bc_raw : BC - 1;
+  const int cpg = C / G;
   const int b = bc / C, c = bc - b * C;
-  const int gi = c / (C / G);
-  const float mA = gsum[(b * G + gi) * 2 + 0], mB = gsum[(b * G + gi) * 2 + 1];
+  const int gi = c / cpg;
+  double A = 0.0, Bq = 0.0;
+  for (int idx = l; idx < cpg * g.nchunk; idx += g.T) {
+    const int k = idx / g.nchunk;                    // channel of the group, chunk
+    const int c2 = gi * cpg + k;
+    const double* p = red_ws + (((size_t)b * C + c2) * g.nchunk + (idx - k * g.nchunk)) * 2;
+    const double ga2 = (double)gamma[c2];
+    A += ga2 * p[0];
+    Bq += ga2 * p[1];
+  }
+  A = row_sum(A, g.T, red);
+  Bq = row_sum(Bq, g.T, red);
+  // channel totals over the batch (only the rows of sample 0, chunk 0 keep them; cheap enough to stay unconditional, which
+  // keeps row_sum's barriers uniform)
+  double s1 = 0.0, s2 = 0.0;
+  for (int idx = l; idx < B * g.nchunk; idx += g.T) {
+    const int b2 = idx / g.nchunk;
+    const double* p = red_ws + (((size_t)b2 * C + c) * g.nchunk + (idx - b2 * g.nchunk)) * 2;
+    s1 += p[0];
+    s2 += p[1];
+  }
+  s1 = row_sum(s1, g.T, red);
+  s2 = row_sum(s2, g.T, red);
+  if (!valid) return;
+  if (l == 0 && b == 0 && blockIdx.y == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  const float mA = (float)(A / n), mB = (float)(Bq / n);
   const float mu = mean[b * G + gi], rs = rstd[b * G + gi];
   const float ga = gamma[c], be = beta[c];
   const size_t base = (size_t)bc * HW;
@@ -292,19 +289,6 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
       dx[base + i] = rs * (dz * ga - mA - xh * mB);
     }
   }
-}
-
-__global__ void __launch_bounds__(256) gn_bwd_params_kernel(const double* __restrict__ csum, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int B, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    s1 += csum[((size_t)b * C + c) * 2 + 0];
-    s2 += csum[((size_t)b * C + c) * 2 + 1];
-  }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
 }
 
 // Work split: T lanes per channel row so that a lane moves >= 4 float4 per pass when the map allows it; rows of one
@@ -356,12 +340,9 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
   else PNSFM_LAUNCH((gn_stats_kernel<false>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
   int e = check_launch("gn_stats");
   if (e) return e;
-  PNSFM_LAUNCH(gn_finish_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, s, (const double*)stats_ws, mean, rstd, B * G,
-               cpg * g.nchunk, (double)cpg * (double)HW, eps);
-  e = check_launch("gn_finish");
-  if (e) return e;
-  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const float*)mean, (const float*)rstd, y, BC, C, HW, G, act, g);
-  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const float*)mean, (const float*)rstd, y, BC, C, HW, G, act, g);
+  const double n = (double)cpg * (double)HW;
+  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g);
+  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g);
   return check_launch("gn_apply");
 }
 
@@ -374,25 +355,15 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   const int BC = B * C;
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
   dim3 grid(ceil_div(BC, g.rows), g.nchunk);
-  double* csum = red_ws + (size_t)2 * BC * g.nchunk;
-  float* gsum = reinterpret_cast<float*>(csum + (size_t)2 * BC);
   int e = 0;
   if (vec) PNSFM_LAUNCH((gn_bwd_reduce_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   else PNSFM_LAUNCH((gn_bwd_reduce_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   e = check_launch("gn_bwd_reduce");
   if (e) return e;
-  const bool one_group_block = B * G <= 256;      // then the group kernel finishes dgamma / dbeta itself
-  PNSFM_LAUNCH(gn_bwd_group_kernel, dim3(ceil_div(B * G, 256)), dim3(256), 0, s, (const double*)red_ws, gamma, csum, gsum, B, C, G,
-               g.nchunk, (double)(C / G) * (double)HW, one_group_block ? dgamma : (float*)nullptr,
-               one_group_block ? dbeta : (float*)nullptr);
-  e = check_launch("gn_bwd_group");
-  if (e) return e;
-  if (vec) PNSFM_LAUNCH((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
-  else PNSFM_LAUNCH((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const float*)gsum, dx, BC, C, HW, G, act, g);
-  e = check_launch("gn_bwd_apply");
-  if (e || one_group_block) return e;
-  PNSFM_LAUNCH(gn_bwd_params_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const double*)csum, dgamma, dbeta, B, C);
-  return check_launch("gn_bwd_params");
+  const double n = (double)(C / G) * (double)HW;
+  if (vec) PNSFM_LAUNCH((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const double*)red_ws, dx, dgamma, dbeta, B, C, HW, G, act, n, g);
+  else PNSFM_LAUNCH((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const double*)red_ws, dx, dgamma, dbeta, B, C, HW, G, act, n, g);
+  return check_launch("gn_bwd_apply");
 }
 
 }  // extern "C"

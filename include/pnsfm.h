@@ -293,6 +293,36 @@ int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long lon
 /* per-launch table (shape, grid, ms, TFLOP/s) of everything recorded since the last reset, as CSV */
 int pnsfm_prof_dump(const char* path);
 
+/* ---- sparse tensors on the pixel grid: the depth-completion branch of PackNet-SAN (csrc/sparse.hip) ----------------------
+ * replaces the MinkowskiEngine calls of networks/layers/minkowski_encoder.py:10-131 and minkowski.py:33-83 (ME.MinkowskiConvolution
+ * stride 1 / dimension 2 / no bias, ME.MinkowskiMaxPooling(3, 2), sparsify_depth, densify_features, map_add_features) with kernels whose
+ * cost follows the number of ACTIVE sites.  A sparse tensor of a [B, h, w] grid is {sites int32 [cap] (linear cell index of row n,
+ * ascending), imap int32 [B*h*w] (row of a cell or -1), count int32 [1] ON THE DEVICE, feats fp32 [cap][C]}; rows >= count are
+ * unused and hold zeros.  Kernel offsets are numbered i = (dy + k/2) + k * (dx + k/2) (MinkowskiEngine's region iterator). */
+size_t pnsfm_sparse_compact_ws_ints(int ncell);
+/* coordinate map of the cells with src > 0 (src: a depth map or a 0/1 mask over ncell = B*h*w cells): imap, sites, count. */
+int pnsfm_sparse_compact(const float* src, int ncell, int* imap, int* sites, int cap, int* count, int* ws, void* stream);
+/* stride-2 coordinate rule: mask_out [B*(h/2)*(w/2)] = 1 where one of the 2x2 fine cells is active (feed it to _compact). */
+int pnsfm_sparse_pool_cells(const int* imap, int B, int h, int w, float* mask_out, void* stream);
+/* nbr [cap][ks*ks]: row of the neighbour of site n at offset i, or -1 (outside the grid / inactive / n >= count). */
+int pnsfm_sparse_neighbors(const int* imap, const int* sites, const int* count, int cap, int h, int w, int ks, int* nbr, void* stream);
+/* out[n][co] = sum_i sum_ci feats[nbr[n][flip ? KK-1-i : i]][ci] * kern[i][ci][co]; kern [ks*ks][Cin][Cout] (MinkowskiConvolution's
+ * layout).  Backward-data = the same call with the kernel transposed to [ks*ks][Cout][Cin], Cin/Cout swapped and flip = 1.  Exact fp32
+ * (v_mfma_f32_32x32x2_f32).  Every row < cap of `out` is written (zeros past count). */
+int pnsfm_sparse_conv(const float* feats, const float* kern, const int* nbr, const int* count, float* out, int cap, int Cin, int Cout,
+                      int ks, int flip, void* stream);
+/* dkern [ks*ks][Cin][Cout] = sum_n feats[nbr[n][i]][ci] * dout[n][co] (overwritten). */
+int pnsfm_sparse_conv_backward_weight(const float* feats, const float* dout, const int* nbr, const int* count, float* dkern, int cap,
+                                      int Cin, int Cout, int ks, void* stream);
+/* ME.MinkowskiMaxPooling(3, 2): fin rows of the fine [B, h, w] grid (imap_in) -> fout rows of the coarse sites (sites_out / count_out of
+ * the compacted pool_cells mask); arg [cap][C] = fine row each maximum came from (-1: none) for the backward scatter. */
+int pnsfm_sparse_maxpool_forward(const float* fin, const int* imap_in, const int* sites_out, const int* count_out, float* fout, int* arg,
+                                 int cap, int C, int h, int w, void* stream);
+int pnsfm_sparse_maxpool_backward(const float* dout, const int* arg, float* din, int cap_out, int cap_in, int C, void* stream);
+/* rows -> dense [B][C][hw] (zeros at inactive cells; every element written) and dense -> rows (zeros past count). */
+int pnsfm_sparse_densify(const float* feats, const int* imap, float* dense, int B, int C, int hw, void* stream);
+int pnsfm_sparse_gather(const float* dense, const int* sites, const int* count, float* rows, int cap, int C, int hw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

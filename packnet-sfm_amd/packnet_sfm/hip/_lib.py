@@ -67,6 +67,16 @@ SIGNATURES = {
     "pnsfm_jitter_totensor": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_nrs_project_forward": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "pnsfm_nrs_project_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "pnsfm_sparse_compact_ws_ints": (_sz, [_i]),
+    "pnsfm_sparse_compact": (_i, [_p, _i, _p, _p, _i, _p, _p, _p]),
+    "pnsfm_sparse_pool_cells": (_i, [_p, _i, _i, _i, _p, _p]),
+    "pnsfm_sparse_neighbors": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "pnsfm_sparse_conv": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_sparse_conv_backward_weight": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_sparse_maxpool_forward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_sparse_maxpool_backward": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_sparse_densify": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_sparse_gather": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_set_autotune": (_i, [_i]),
     "pnsfm_set_conv_variant": (_i, [_i]),
     "pnsfm_tune_shipped_entries": (_i, []),

@@ -744,6 +744,98 @@ def nrs_project(direction, ray, temperature):
     return NrsProjectFn.apply(direction, ray, temperature)
 
 
+class SparseConvFn(Function):
+    """out[n] = sum_i kern[i]^T . feats[nbr[n][i]] over the active sites (ME.MinkowskiConvolution, stride 1, no bias)."""
+
+    @staticmethod
+    def forward(ctx, feats, kern, nbr, count, ks):
+        feats, kern = feats.contiguous(), kern.contiguous()
+        ctx.save_for_backward(feats, kern, nbr, count)
+        ctx.ks = ks
+        return ops.sparse_conv(feats, kern.detach(), nbr, count, ks, flip=False)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        feats, kern, nbr, count = ctx.saved_tensors
+        dout = dout.contiguous()
+        dfeats = dkern = None
+        if ctx.needs_input_grad[0]:
+            dfeats = ops.sparse_conv(dout, kern.detach().transpose(1, 2).contiguous(), nbr, count, ctx.ks, flip=True)
+        if ctx.needs_input_grad[1]:
+            dkern = ops.sparse_conv_backward_weight(feats, dout, nbr, count, ctx.ks)
+        return dfeats, dkern, None, None, None
+
+
+def sparse_conv(feats, kern, nbr, count, ks):
+    return SparseConvFn.apply(feats, kern, nbr, count, ks)
+
+
+class SparseMaxPoolFn(Function):
+    """ME.MinkowskiMaxPooling(3, 2) on feature rows: fine rows (imap_in of the [B, h, w] grid) -> coarse rows (sites_out / count_out)."""
+
+    @staticmethod
+    def forward(ctx, fin, imap_in, sites_out, count_out, cap_out, h, w):
+        fin = fin.contiguous()
+        fout, arg = ops.sparse_maxpool_forward(fin, imap_in, sites_out, count_out, cap_out, h, w)
+        ctx.save_for_backward(arg)
+        ctx.cap_in = fin.shape[0]
+        return fout
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        return ops.sparse_maxpool_backward(dout.contiguous(), arg, ctx.cap_in), None, None, None, None, None, None
+
+
+def sparse_maxpool(fin, imap_in, sites_out, count_out, cap_out, h, w):
+    return SparseMaxPoolFn.apply(fin, imap_in, sites_out, count_out, cap_out, h, w)
+
+
+class SparseDensifyFn(Function):
+    """feature rows -> dense [B, C, h, w], zeros at inactive cells (densify_features, reference minkowski.py:60-83)."""
+
+    @staticmethod
+    def forward(ctx, feats, imap, sites, count, B, h, w):
+        ctx.save_for_backward(sites, count)
+        ctx.cap = feats.shape[0]
+        return ops.sparse_densify(feats.contiguous(), imap, B, h * w).view(B, feats.shape[1], h, w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        sites, count = ctx.saved_tensors
+        B, C, h, w = g.shape
+        return ops.sparse_gather(g.contiguous().view(B, C, h * w), sites, count, ctx.cap), None, None, None, None, None, None
+
+
+def sparse_densify(feats, imap, sites, count, B, h, w):
+    return SparseDensifyFn.apply(feats, imap, sites, count, B, h, w)
+
+
+class SparseGatherFn(Function):
+    """dense [B, C, h, w] -> feature rows at the active sites (the dense half of map_add_features, reference minkowski.py:116-136)."""
+
+    @staticmethod
+    def forward(ctx, dense, imap, sites, count, cap):
+        B, C, h, w = dense.shape
+        ctx.save_for_backward(imap)
+        ctx.shape = (B, C, h, w)
+        return ops.sparse_gather(dense.contiguous().view(B, C, h * w), sites, count, cap)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (imap,) = ctx.saved_tensors
+        B, C, h, w = ctx.shape
+        return ops.sparse_densify(g.contiguous(), imap, B, h * w).view(B, C, h, w), None, None, None, None
+
+
+def sparse_gather(dense, imap, sites, count, cap):
+    return SparseGatherFn.apply(dense, imap, sites, count, cap)
+
+
 REDUCE_MIN, REDUCE_MEAN = 0, 1
 
 

@@ -449,6 +449,104 @@ def jitter_totensor(img, ops_records, want_original=True):
     return out, orig
 
 
+# -------------------------------------------------------------------------------------- sparse tensors (PackNet-SAN)
+def _i32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.int32:
+            raise RuntimeError("packnet_sfm HIP op needs int32 index tensors, got %s" % t.dtype)
+
+
+def sparse_compact(src, cap=None):
+    """src: fp32 tensor over the cells of a [B, h, w] grid (a depth map or a 0/1 mask); active = src > 0.
+    -> (imap int32 [ncell], sites int32 [cap or ncell], count int32 [1] on the device).  cap=None sizes `sites` for every cell (the
+    caller trims it once it knows the count); otherwise rows past `cap` are dropped."""
+    _chk(src); _f32(src)
+    ncell = src.numel()
+    dev = src.device
+    imap = torch.empty((ncell,), dtype=torch.int32, device=dev)
+    sites = torch.empty((ncell if cap is None else max(cap, 1),), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(_lib.get().pnsfm_sparse_compact_ws_ints(ncell)),), dtype=torch.int32, device=dev)
+    _lib.check(_lib.get().pnsfm_sparse_compact(_ptr(src), ncell, _ptr(imap), _ptr(sites), sites.numel() if cap is None else cap,
+                                               _ptr(count), _ptr(ws), _stream(src)), "sparse_compact")
+    return imap, sites, count
+
+
+def sparse_pool_cells(imap, B, h, w):
+    _chk(imap); _i32(imap)
+    mask = torch.empty((B * (h // 2) * (w // 2),), dtype=torch.float32, device=imap.device)
+    _lib.check(_lib.get().pnsfm_sparse_pool_cells(_ptr(imap), B, h, w, _ptr(mask), _stream(imap)), "sparse_pool_cells")
+    return mask
+
+
+def sparse_neighbors(imap, sites, count, cap, h, w, ks):
+    _chk(imap, sites, count); _i32(imap, sites, count)
+    nbr = torch.empty((max(cap, 1), ks * ks), dtype=torch.int32, device=imap.device)
+    _lib.check(_lib.get().pnsfm_sparse_neighbors(_ptr(imap), _ptr(sites), _ptr(count), cap, h, w, ks, _ptr(nbr), _stream(imap)),
+               "sparse_neighbors")
+    return nbr
+
+
+def sparse_conv(feats, kern, nbr, count, ks, flip=False):
+    """feats [cap, Cin], kern [ks*ks, Cin, Cout] -> [cap, Cout] (rows past count are zero)."""
+    _chk(feats, kern, nbr, count); _f32(feats, kern); _i32(nbr, count)
+    cap, Cin = feats.shape
+    KK, Cin2, Cout = kern.shape
+    if KK != ks * ks or Cin2 != Cin:
+        raise RuntimeError("sparse_conv: kernel %s does not match %d input channels / k=%d" % (tuple(kern.shape), Cin, ks))
+    out = torch.empty((cap, Cout), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.get().pnsfm_sparse_conv(_ptr(feats), _ptr(kern), _ptr(nbr), _ptr(count), _ptr(out), cap, Cin, Cout, ks,
+                                            1 if flip else 0, _stream(feats)), "sparse_conv")
+    return out
+
+
+def sparse_conv_backward_weight(feats, dout, nbr, count, ks):
+    _chk(feats, dout, nbr, count); _f32(feats, dout); _i32(nbr, count)
+    cap, Cin = feats.shape
+    Cout = dout.shape[1]
+    dk = torch.empty((ks * ks, Cin, Cout), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.get().pnsfm_sparse_conv_backward_weight(_ptr(feats), _ptr(dout), _ptr(nbr), _ptr(count), _ptr(dk), cap, Cin, Cout,
+                                                            ks, _stream(feats)), "sparse_conv_backward_weight")
+    return dk
+
+
+def sparse_maxpool_forward(fin, imap_in, sites_out, count_out, cap_out, h, w):
+    _chk(fin, imap_in, sites_out, count_out); _f32(fin); _i32(imap_in, sites_out, count_out)
+    C = fin.shape[1]
+    fout = torch.empty((cap_out, C), dtype=torch.float32, device=fin.device)
+    arg = torch.empty((cap_out, C), dtype=torch.int32, device=fin.device)
+    _lib.check(_lib.get().pnsfm_sparse_maxpool_forward(_ptr(fin), _ptr(imap_in), _ptr(sites_out), _ptr(count_out), _ptr(fout), _ptr(arg),
+                                                       cap_out, C, h, w, _stream(fin)), "sparse_maxpool_forward")
+    return fout, arg
+
+
+def sparse_maxpool_backward(dout, arg, cap_in):
+    _chk(dout, arg); _f32(dout); _i32(arg)
+    cap_out, C = dout.shape
+    din = torch.empty((cap_in, C), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.get().pnsfm_sparse_maxpool_backward(_ptr(dout), _ptr(arg), _ptr(din), cap_out, cap_in, C, _stream(dout)),
+               "sparse_maxpool_backward")
+    return din
+
+
+def sparse_densify(feats, imap, B, hw):
+    _chk(feats, imap); _f32(feats); _i32(imap)
+    C = feats.shape[1]
+    dense = torch.empty((B, C, hw), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.get().pnsfm_sparse_densify(_ptr(feats), _ptr(imap), _ptr(dense), B, C, hw, _stream(feats)), "sparse_densify")
+    return dense
+
+
+def sparse_gather(dense, sites, count, cap):
+    """dense [B, C, hw] -> rows [cap, C] at the active sites (zeros past count)."""
+    _chk(dense, sites, count); _f32(dense); _i32(sites, count)
+    B, C, hw = dense.shape
+    rows = torch.empty((cap, C), dtype=torch.float32, device=dense.device)
+    _lib.check(_lib.get().pnsfm_sparse_gather(_ptr(dense), _ptr(sites), _ptr(count), _ptr(rows), cap, C, hw, _stream(dense)),
+               "sparse_gather")
+    return rows
+
+
 # ---------------------------------------------------------------------------------------------- adam
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     _chk(param, grad, exp_avg, exp_avg_sq); _f32(param, grad, exp_avg, exp_avg_sq)

@@ -6,27 +6,29 @@ constructor arguments, same `prep(depth)` / `forward(x)` protocol, same paramete
 
 The reference runs this branch on MinkowskiEngine (third-party, NOT vendored in the reference and not installed here; the
 Dockerfile builds it from git master, i.e. un-versioned).  Its operations are restated from the MinkowskiEngine 0.5
-documentation on the dense-plus-mask representation of minkowski.py:
-  ME.MinkowskiConvolution(k, stride 1, dimension 2, no bias): out[p] = sum_o W[o] . in[p + o*ts] over the ACTIVE neighbours, for
-      active p only                         == mask * conv2d(features with zeros at inactive sites): the MFMA conv kernel;
+documentation on the active-site lists of minkowski.py (`SparseGrid`), each one a kernel of csrc/sparse.hip:
+  ME.MinkowskiConvolution(k, stride 1, dimension 2, no bias): out[p] = sum_o W[o]^T . in[p + o*ts] over the ACTIVE neighbours, for
+      active p only  -> gather-based implicit GEMM on the matrix cores (exact fp32), its backward-data and weight gradient;
   ME.MinkowskiMaxPooling(3, stride 2): output cell active iff one of its 2x2 input cells is; value = max over the active
       inputs of the 3x3 window centred on the cell's origin;
-  ME.MinkowskiBatchNorm: BatchNorm1d over the active sites of the whole batch (running statistics, affine);
-  ME.MinkowskiReLU, sparse + sparse on identical coordinates: elementwise.
+  ME.MinkowskiBatchNorm: BatchNorm1d over the feature rows of the active sites of the whole batch (running statistics, affine);
+  ME.MinkowskiReLU, sparse + sparse on identical coordinates: elementwise on the rows.
 Kernel offset order assumed for `kernel[i]`: ME's hyper-cube region iterator, first coordinate fastest:
-i = (dy + k//2) + k * (dx + k//2).  PARITY OF THIS BRANCH IS UNPINNED (no MinkowskiEngine to run, the reference has no test
-or golden vector for it): tests check it against an independent gather-based restatement of the same rules (oracle/).
+i = (dy + k//2) + k * (dx + k//2).  PARITY AGAINST MinkowskiEngine ITSELF IS UNPINNED (it cannot be run here and the reference has no
+test or golden vector for the branch); the rules above are pinned by hand-computed vectors (tests/test_sparse.py) on
+oracle/minkowski_oracle.py, an independent coordinate-dictionary restatement, and the kernels are checked against that oracle.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from packnet_sfm.hip import functional as HF
-from packnet_sfm.networks.layers.minkowski import GridSparse, densify_features, map_add_features, sparsify_depth
+from packnet_sfm.networks.layers.minkowski import (SparseGrid, densify_features, map_add_features, pool_coordinates,
+                                                    sparsify_depth)
 
 
 class MinkowskiConvolution(nn.Module):
-    """Parameter container + masked MFMA conv: `kernel` [k*k, in, out] (MinkowskiEngine's layout), no bias."""
+    """`kernel` [k*k, in, out] (MinkowskiEngine's layout), no bias; the sparse convolution kernel of csrc/sparse.hip."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, dimension=2):
         super().__init__()
@@ -36,31 +38,24 @@ class MinkowskiConvolution(nn.Module):
         self.kernel = nn.Parameter(torch.empty(kernel_size * kernel_size, in_channels, out_channels))
         with torch.no_grad():               # ME default: ME.utils.kaiming_normal_(kernel, mode='fan_out', nonlinearity='relu')
             self.kernel.normal_(0, (2.0 / (out_channels * kernel_size * kernel_size)) ** 0.5)
-        self._packed = HF.PackedConvWeight(volatile=True)
-
-    def dense_weight(self):
-        k = self.kernel_size
-        # kernel[i], i = ky + k*kx  ->  [out, in, ky, kx]
-        return self.kernel.view(k, k, self.in_channels, self.out_channels).permute(3, 2, 1, 0).contiguous()
 
     def forward(self, x):
-        y = HF.conv2d(x.F, self.dense_weight(), None, self._packed)
-        return GridSparse(y * x.mask, x.mask, x.tensor_stride)
+        return x.with_features(HF.sparse_conv(x.F, self.kernel, x.neighbors(self.kernel_size), x.count, self.kernel_size))
 
 
 class MinkowskiBatchNorm(nn.Module):
-    """BatchNorm over the ACTIVE sites of the batch; parameters under `.bn` like ME.MinkowskiBatchNorm."""
+    """BatchNorm over the feature rows of the ACTIVE sites of the batch; parameters under `.bn` like ME.MinkowskiBatchNorm."""
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
 
     def forward(self, x):
-        bn, m, f = self.bn, x.mask, x.F
+        bn, f, rows = self.bn, x.F, x.row_mask
         if self.training or not bn.track_running_stats:
-            n = m.sum().clamp(min=1.0)
-            mean = (f * m).sum((0, 2, 3)) / n
-            var = (((f - mean.view(1, -1, 1, 1)) ** 2) * m).sum((0, 2, 3)) / n
+            n = x.count.to(torch.float32).clamp(min=1.0)            # device scalar: no host round trip
+            mean = f.sum(0) / n                                      # rows past count are zero
+            var = (((f - mean) ** 2) * rows).sum(0) / n
             if bn.track_running_stats:
                 with torch.no_grad():
                     mom = bn.momentum
@@ -69,9 +64,8 @@ class MinkowskiBatchNorm(nn.Module):
                     bn.num_batches_tracked += 1
         else:
             mean, var = bn.running_mean, bn.running_var
-        y = (f - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + bn.eps)
-        y = y * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
-        return GridSparse(y * m, m, x.tensor_stride)
+        y = ((f - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias) * rows
+        return x.with_features(y)
 
 
 class MinkowskiReLU(nn.Module):
@@ -79,7 +73,7 @@ class MinkowskiReLU(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        return GridSparse(F.relu(x.F), x.mask, x.tensor_stride)
+        return x.with_features(F.relu(x.F))
 
 
 class MinkowskiMaxPooling(nn.Module):
@@ -89,11 +83,9 @@ class MinkowskiMaxPooling(nn.Module):
             raise NotImplementedError('MaxPooling(3, 2, dimension=2) (all the SAN branch uses)')
 
     def forward(self, x):
-        neg = torch.finfo(x.F.dtype).min
-        f = torch.where(x.mask > 0, x.F, torch.full_like(x.F, neg))
-        pooled = F.max_pool2d(f, kernel_size=3, stride=2, padding=1)
-        mask = F.max_pool2d(x.mask, kernel_size=2, stride=2)
-        return GridSparse(torch.where(mask > 0, pooled, torch.zeros_like(pooled)), mask, x.tensor_stride * 2)
+        out = pool_coordinates(x)
+        out.F = HF.sparse_maxpool(x.F, x.imap, out.sites, out.count, out.cap, x.h, x.w)
+        return out
 
 
 class MinkConv2D(nn.Module):
@@ -118,7 +110,7 @@ class MinkConv2D(nn.Module):
         if self.pool is not None:
             x = self.pool(x)
         x1, x2, x3 = self.layer1(x), self.layer2(x), self.layer3(x)
-        return None, self.layer_final(GridSparse(x1.F + x2.F + x3.F, x.mask, x.tensor_stride))
+        return None, self.layer_final(x.with_features(x1.F + x2.F + x3.F))
 
 
 class MinkowskiEncoder(nn.Module):

@@ -35,14 +35,15 @@ def test_packed_weight_sizes(lib_path):
     """Host-side geometry helpers (no kernel launch): padded packed-weight sizes."""
     from packnet_sfm.hip import _lib
     lib = _lib.bind(ctypes.CDLL(lib_path))
-    # shapes the split-bf16 kernels take (>= 16 K-channels, k >= 3) are packed as three bf16 pieces: 6 bytes per element
+    # shapes the split-bf16 kernels take (>= 16 K-channels; 1x1 layers too since round 3) are packed as three bf16 pieces: 6 bytes per element
     assert lib.pnsfm_conv2d_packed_elems_fwd(64, 64, 3) == 9 * 64 * 64 * 3 // 2
     assert lib.pnsfm_conv2d_packed_elems_fwd(3, 64, 5) == 25 * 16 * 64         # K rows padded to whole 16-channel chunks
     assert lib.pnsfm_conv2d_packed_elems_bwd(3, 64, 5) == 25 * 64 * 32 * 3 // 2   # backward-data: K = 64 output channels
     assert lib.pnsfm_conv2d_packed_elems_fwd(129, 64, 3) == 9 * 144 * 64 * 3 // 2
     assert lib.pnsfm_conv2d_packed_elems_bwd(129, 64, 3) == 9 * 64 * 160 * 3 // 2   # M = 129 -> 5 tiles of 32
     assert lib.pnsfm_conv2d_packed_elems_fwd(256, 1, 3) == 9 * 256 * 32 * 3 // 2
-    assert lib.pnsfm_conv2d_packed_elems_fwd(256, 64, 1) == 256 * 64           # 1x1: f32 kernels only
+    assert lib.pnsfm_conv2d_packed_elems_fwd(256, 64, 1) == 256 * 64 * 3 // 2   # 1x1: split-bf16 since round 3
+    assert lib.pnsfm_conv2d_packed_elems_fwd(8, 64, 1) == 16 * 64              # < 16 K-channels: f32 kernels
 
 
 def test_product_loader_refuses_cpu_tensors(lib_path):

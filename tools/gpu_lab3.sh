@@ -33,6 +33,11 @@ alltests)
   echo "== pytest -m gpu (all)"
   timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $O/pytest_all_$TAG.log 2>&1
   tail -12 $O/pytest_all_$TAG.log | cut -c1-300 ;;
+sparse)
+  echo "== sparse branch: tests + next-rows bench"
+  timeout 900 python -m pytest tests/test_sparse.py tests/test_packnet_san.py -m gpu -q -p no:cacheprovider --timeout 600 > $O/pytest_sparse_$TAG.log 2>&1
+  tail -5 $O/pytest_sparse_$TAG.log | cut -c1-300
+  timeout 600 python tools/next_rows_bench.py > $O/next_rows_$TAG.json 2> $O/next_rows_$TAG.err; tail -1 $O/next_rows_$TAG.json | cut -c1-1500 ;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_$TAG.log 2>&1; tail -3 $O/smoke_$TAG.log ;;
 bench)

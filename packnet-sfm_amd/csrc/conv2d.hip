@@ -64,9 +64,15 @@ static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a 
 static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
+// tm (split-bf16 kernels only): 0 = the classic tilings (32-wide 2-D tiles when W % 32 == 0, else linear runs whose patch spans
+// whole rows), 1 = 16-wide rectangles (16 x 8*NT), 2 = row bands (W x floor(128*NT / W)).  On maps whose width is not a multiple
+// of 32 (80, 40, 20) the linear runs drag (W + k - 1)-wide patch rows along: 410 staged pixels for 128 outputs at W = 80, too many
+// for the register prefetch with NT = 2 -- the rectangles bring that to 180 / 324 and make NT = 2 usable there.
 static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0,
-                            int S = 1, int forceMT = 0) {
+                            int S = 1, int forceMT = 0, int tm = 0) {
   g.DMA = DMA;
+  g.TW = g.TH = 0;
+  if (tm != 0 && DMA < 3) return false;
   const int HW = H * W;
   g.MT = conv_pick_MT(Cout);
   // 32-row M tiles instead of 64 double the block count of a low-resolution layer WITHOUT split-K atomics; the packed
@@ -78,7 +84,21 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   g.CI = Cin <= 8 ? 8 : 16;    // K-chunk: multiple of 8 channels = whole batches of 4 MFMA k-steps
   g.mode = (W % 32 == 0) ? 0 : 1;
   g.NT = NT;
-  if (g.mode == 0) {
+  if (tm == 1 || tm == 2) {
+    if (W % 32 == 0) return false;                       // the 32-wide tiles already are rectangles there
+    g.TW = tm == 1 ? 16 : W;
+    g.TH = tm == 1 ? 8 * NT : (128 * NT) / W;
+    if (g.TH < 1 || (tm == 1 && W < 16)) return false;
+    if (g.TH > H) g.TH = H;
+    // useful share of the tile grid: slots that hold a pixel of the image (a bad quantisation loses to the linear runs)
+    const double fill = (double)H * W / ((double)ceil_div(H, g.TH) * ceil_div(W, g.TW) * 128.0 * NT);
+    if (fill < 0.6) return false;
+    g.mode = 2;
+    g.tiles_x = ceil_div(W, g.TW);
+    g.tiles_per_img = g.tiles_x * ceil_div(H, g.TH);
+    g.PH = (g.TH - 1) * S + ks;
+    g.PW = (g.TW - 1) * S + ks;
+  } else if (g.mode == 0) {
     g.tiles_x = W / 32;
     g.tiles_per_img = g.tiles_x * ceil_div(H, 4 * NT);
     g.PH = (4 * NT - 1) * S + ks;
@@ -314,6 +334,7 @@ struct ConvArgs {
   int B, Cin, Cout, H, W, KS;   // H, W: OUTPUT size
   int S, Hi, Wi;                // stride (1 | 2) and INPUT size (Hi = H, Wi = W when S == 1)
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
+  int TW, TH;         // mode 2 (split-bf16 kernels): tile width / height in output pixels
   int pstride;        // DMA variants: floats between the two patch buffers
   int G;              // pipelined / bx3 variants: taps per weight stage
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
@@ -820,6 +841,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.S = S; a.Hi = Hi; a.Wi = Wi;
   a.CI = g.CI; a.mode = g.mode; a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img;
+  a.TW = g.TW; a.TH = g.TH;
   a.PH = g.PH; a.PW = g.PW; a.KP = g.KP; a.MP = g.MP; a.nchunks = g.nchunks;
   a.chunks_per_split = ceil_div(g.nchunks, g.splitK); a.splitK = g.splitK;
   a.invPW = 1.0f / (float)g.PW;
@@ -940,19 +962,21 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
-      for (int cfg = 0; cfg < 6 * nMT; ++cfg) {
+      const int nTM = (bx3 && W % 32 != 0) ? 3 : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
+      for (int cfgt = 0; cfgt < 6 * nMT * nTM; ++cfgt) {
+        const int cfg = cfgt % (6 * nMT), tm = cfgt / (6 * nMT);
         const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % 3 + (bx3 ? 3 : 0), fMT = cfg / 6;
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
-          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA, S, fMT)) break;
+          if (!conv_geom_fixed(B, Cin, Cout, H, W, ks, NT, want, c, DA, S, fMT, tm)) break;
           if (c.splitK == last_split) continue;
           last_split = c.splitK;
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
           const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi); });
-          tune_log(0, key, NT | (DA << 4) | (fMT << 8), c.splitK, ms);
-          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8), c.splitK}; }
+          tune_log(0, key, NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK, ms);
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK}; }
         }
       }
       dec = &g_tuned.emplace(key, best).first->second;
@@ -962,7 +986,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
     if (dec) {
       ConvGeom t;
       const int DA = ((*dec)[0] >> 4) & 7;
-      if ((DA >= 3) == bx3 && conv_geom_fixed(B, Cin, Cout, H, W, ks, (*dec)[0] & 15, (*dec)[1], t, DA, S, ((*dec)[0] >> 8) & 1)) g = t;
+      if ((DA >= 3) == bx3 &&
+          conv_geom_fixed(B, Cin, Cout, H, W, ks, (*dec)[0] & 15, (*dec)[1], t, DA, S, ((*dec)[0] >> 8) & 1, ((*dec)[0] >> 9) & 3))
+        g = t;
     }
   }
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)

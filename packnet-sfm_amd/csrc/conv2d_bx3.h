@@ -90,6 +90,21 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
       pvalid[nt] = oy[nt] < H;
       boff[nt] = (row * a.PW + l32) * S;
     }
+  } else if (a.mode == 2) {
+    // TW x TH rectangle (16 x 8*NT, or a band of whole rows): slot p of the tile is pixel (p / TW, p % TW)
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int y0 = ty * a.TH, x0 = tx * a.TW;
+    py0 = y0 * S - P;
+    px0 = x0 * S - P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int p = (wave * NT + nt) * 32 + l32;
+      const int row = p / a.TW, col = p - row * a.TW;
+      pvalid[nt] = row < a.TH && y0 + row < H && x0 + col < W;
+      oy[nt] = pvalid[nt] ? y0 + row : y0;
+      ox[nt] = pvalid[nt] ? x0 + col : x0;
+      boff[nt] = pvalid[nt] ? (row * a.PW + col) * S : 0;
+    }
   } else {
     const int n0 = t * 128 * NT;
     const int r0 = n0 / W;
@@ -179,18 +194,27 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
   // ---- weight stream: stage = G taps of one chunk, MT slabs per tap; one DMA instruction moves 1 KB (one piece of one slab)
   const pnsfm_dma_buf wdesc = pnsfm_make_dma_buf(a.wp, (long)(a.MP / 32) * a.nchunks * KK * PNSFM_BX3_SLAB);
   const int mb0 = blockIdx.y * MT;
-  const int nwi = G * MT * 3;                    // wave-instructions per stage
+  // A stage's slabs sit in LDS as [m tile][tap][piece] -- for one m tile the G taps of a chunk are ONE contiguous run of the packed
+  // weight stream (G * 3 KB), so a wave's share of the stage is a contiguous range of 1-KB pieces: source and destination advance by
+  // 1024 per instruction and the loop around the DMA is a handful of scalar operations (it used to decode (slab, piece, tap, tile)
+  // per instruction: ~25 scalar instructions and 250-300 cycles per DMA, 18-24 % of a wave's time -- tools/bx3_trace.py).
+  const unsigned wbase0 = (unsigned)(mb0 * a.nchunks * KK) * PNSFM_BX3_SLAB + lane * 16;
+  const unsigned wmtstride = (unsigned)(a.nchunks * KK) * PNSFM_BX3_SLAB;
   auto issue_weights = [&](int c, int tap0, unsigned char* dst) {
-    for (int wi = wave; wi < nwi; wi += 4) {
-      const int slab = wi / 3, s = wi - slab * 3;
-      const int tl = slab / MT, mt = slab - tl * MT;
-      if (tap0 + tl < KK) {
-        const unsigned src = (unsigned)((((mb0 + mt) * a.nchunks + c) * KK + tap0 + tl) * PNSFM_BX3_SLAB + s * 1024) + lane * 16;
-        pnsfm_dma16(wdesc, src, reinterpret_cast<float*>(dst + slab * PNSFM_BX3_SLAB + s * 1024));
-      }
+    int gcn = KK - tap0;
+    if (gcn > G) gcn = G;
+    const int run = 3 * gcn, total = MT * run;
+    const int per = (total + 3) >> 2;
+    int q = wave * per;
+    int qe = q + per;
+    if (qe > total) qe = total;
+    const unsigned src0 = wbase0 + (unsigned)(c * KK + tap0) * PNSFM_BX3_SLAB;
+    for (; q < qe; ++q) {
+      const int mt = (MT == 2 && q >= run) ? 1 : 0;
+      const int r = q - mt * run;
+      pnsfm_dma16(wdesc, src0 + mt * wmtstride + (unsigned)r * 1024u, reinterpret_cast<float*>(dst + (mt * G * 3 + r) * 1024));
     }
   };
-
   // per-lane operand addresses
   unsigned baddr[NT];
 #pragma unroll
@@ -203,7 +227,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int s = 0; s < 3; ++s)
-        f.A[mt][s] = *reinterpret_cast<const pnsfm_u32x4*>(wst + (tl * MT + mt) * PNSFM_BX3_SLAB + s * 1024 + aaddr);
+        f.A[mt][s] = *reinterpret_cast<const pnsfm_u32x4*>(wst + ((mt * G + tl) * 3 + s) * 1024 + aaddr);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -220,12 +244,23 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
 #undef PNSFM_BX3_P
   };
 
+#ifdef PNSFM_PIPE_TRACE
+  // debug build (tools/bx3_trace.py): cycles of this wave in {stage wait, DMA / load issue, MFMA loop, chunk-end staging}
+  long long tr_wait = 0, tr_issue = 0, tr_mma = 0, tr_stage = 0;
+  const long long tr_start = __builtin_readcyclecounter();
+#define PNSFM_TR(acc_, expr) do { const long long t0_ = __builtin_readcyclecounter(); expr; acc_ += __builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define PNSFM_TR(acc_, expr) do { expr; } while (0)
+#endif
   // ---- prologue: first chunk's patch and first stage's weights
   const int SG = (KK + G - 1) / G;               // stages per chunk
   issue_weights(c_begin, 0, wbuf0);
   if (prefetch) { load_items(c_begin); write_items(smem); }
   else stage_sync(c_begin, smem);
 
+#ifdef PNSFM_PIPE_TRACE
+  const long long tr_loop = __builtin_readcyclecounter();
+#endif
   int pcur = 0, stage = 0;
   for (int c = c_begin; c < c_end; ++c) {
     unsigned char* const patch = smem + pcur * patchB;
@@ -234,13 +269,20 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
       const int tap0 = sg * G;
       const int gcount = (KK - tap0 < G) ? KK - tap0 : G;
       const bool last = sg + 1 == SG;
-      pnsfm_dma_wait();    // this wave's weight DMA for the stage has landed ...
-      __syncthreads();     // ... and so has everyone's; the patch is visible, the previous stage is consumed
+      PNSFM_TR(tr_wait, pnsfm_dma_wait();    // this wave's weight DMA for the stage has landed ...
+               __syncthreads());             // ... and so has everyone's; the patch is visible, the previous stage is consumed
       unsigned char* const wst = wbuf0 + (stage & 1) * stageB;
       unsigned char* const wnext = wbuf0 + ((stage & 1) ^ 1) * stageB;
-      if (!last) issue_weights(c, tap0 + G, wnext);
-      else if (more) issue_weights(c + 1, 0, wnext);
-      if (last && more && prefetch) load_items(c + 1);
+      // (handing this DMA / load burst out in slices between the taps' MFMA batches was measured and is slower: 124 vs 134 img/s --
+      // an LDS-DMA issued inside the MFMA stream stalls the wave longer than the same instruction in a burst)
+      PNSFM_TR(tr_issue, {
+        if (!last) issue_weights(c, tap0 + G, wnext);
+        else if (more) issue_weights(c + 1, 0, wnext);
+        if (last && more && prefetch) load_items(c + 1);
+      });
+#ifdef PNSFM_PIPE_TRACE
+      const long long tr_m0 = __builtin_readcyclecounter();
+#endif
 
       int ky = tap0 / a.KS, kx = tap0 - ky * a.KS;
       auto tapoff = [&]() -> int {
@@ -259,6 +301,10 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
         }
       }
 
+#ifdef PNSFM_PIPE_TRACE
+      tr_mma += __builtin_readcyclecounter() - tr_m0;
+      const long long tr_s0 = __builtin_readcyclecounter();
+#endif
       if (last && more) {
         if (a.PB == 2) {
           // the other patch buffer was last read two chunks ago: write the next chunk's patch while the other waves finish
@@ -270,11 +316,26 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
           else stage_sync(c + 1, patch);
         }
       }
+#ifdef PNSFM_PIPE_TRACE
+      tr_stage += __builtin_readcyclecounter() - tr_s0;
+#endif
     }
     if (a.PB == 2) pcur ^= 1;
   }
+#ifdef PNSFM_PIPE_TRACE
+  const long long tr_epi = __builtin_readcyclecounter();
+#endif
 
   conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+#ifdef PNSFM_PIPE_TRACE
+  if (a.trace && lane == 0) {
+    const long long tr_end = __builtin_readcyclecounter();
+    long long* tt = a.trace + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave) * 8;
+    tt[0] = tr_wait; tt[1] = tr_issue; tt[2] = tr_mma; tt[3] = tr_stage; tt[4] = tr_end - tr_start; tt[5] = tr_loop - tr_start;
+    tt[6] = tr_end - tr_epi; tt[7] = stage;
+  }
+#endif
+#undef PNSFM_TR
 }
 
 // ---- weight packer for the bx3 kernels: fp32 [Cout][Cin][k][k] -> the split LDS images described above.

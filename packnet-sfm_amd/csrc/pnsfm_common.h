@@ -175,7 +175,8 @@ struct ConvGeom {
   int MT;             // 32-row MFMA tiles per wave along M (block M tile BM = 32*MT)
   int NT;             // 32-pixel MFMA tiles per wave along N (block covers 4 waves * NT * 32 pixels)
   int CI;             // input channels staged per K-chunk (even, <= 16)
-  int mode;           // 0: 2-D pixel tile (4*NT rows x 32 cols), 1: linear run of 128*NT pixels
+  int mode;           // 0: 2-D pixel tile (4*NT rows x 32 cols), 1: linear run of 128*NT pixels, 2: TW x TH rectangle (split-bf16 kernels)
+  int TW, TH;         // mode 2: tile width / height in output pixels (TW * TH <= 128 * NT)
   int tiles_x, tiles_per_img;
   int PH, PW;         // staged input patch (rows, cols) incl. halo
   int KP, MP;         // padded K-channels / M-channels of the packed weight

@@ -142,6 +142,38 @@ def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
+@pytest.mark.parametrize('cfg', [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2)])
+@pytest.mark.parametrize('shape', [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7)])
+def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):
+    """Tile modes of the split-bf16 kernels for maps whose width is not a multiple of 32 (24x80, 12x40, 6x20 in PackNet01), pinned
+    like the autotuner does: cfg = (NT, variant, narrow-M, K-split, tile mode) with tile mode 1 = 16-wide rectangles (16 x 8*NT),
+    2 = bands of whole rows (W x floor(128*NT / W)); ragged last tiles in both directions, heights below the tile height."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    NT, variant, narrow, split, tm = cfg
+    lib.pnsfm_set_conv_math(1)
+    B, Cin, Cout, H, W, ks = shape
+    if tm == 2 and W > 128 * NT:
+        pytest.skip('a row does not fit the tile')
+    for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+        key = (ctypes.c_int * 7)(kind + 10 + 100, B, K, M, H, W, ks)
+        assert lib.pnsfm_tune_set(key, NT | (variant << 4) | (narrow << 8) | (tm << 9), split) == 0
+    g = torch.Generator().manual_seed(sum(shape) + tm)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wf, wb = ops.conv2d_pack(w)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    P.check(ops.conv2d_forward(x, wf, b, Cout, ks), yr, 1e-5, 'fwd')
+    P.check(ops.conv2d_backward_data(dy, wb, Cin, ks), xr.grad, 1e-5, 'dgrad')
+    lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
+
+
 @pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
                                    (1, 40, 64, 6, 24, 5), (3, 17, 31, 7, 40, 1), (2, 64, 64, 8, 32, 3)])
 def test_conv2d_wgrad_tap_major(emulated_kernels, shape):

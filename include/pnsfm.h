@@ -52,6 +52,19 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
                                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 
+/* The decoder's skip connections: conv(torch.cat((x0, x1[, x2]), 1)) WITHOUT the concatenated tensor (networks/depth/PackNet01.py:138-174:
+ * iconv5..iconv1 read cat(unpacked, skip[, upsampled inverse depth])).  The K loop of the split-bf16 kernels walks the three tensors in
+ * turn; x0 and x1 must end on 16-channel (forward) / 32-channel (weight gradient) boundaries, x2 (C2 >= 0 channels) may be ragged.
+ * wp_fwd is the packed weight of the [Cout][C0+C1+C2][k][k] parameter.  Backward-data is pnsfm_conv2d_backward_data on the whole
+ * parameter (its output IS the concatenated gradient; consumers take channel slices).  Non-zero return (message in
+ * pnsfm_last_error) when the shape is outside the split kernels' envelope: the caller then concatenates. */
+int pnsfm_conv2d_forward_cat(const float* x0, int C0, const float* x1, int C1, const float* x2 /*nullable*/, int C2,
+                             const float* wp_fwd, const float* bias /*nullable*/, float* y, int B, int Cout, int H, int W, int ks,
+                             void* stream);
+int pnsfm_conv2d_backward_weight_cat(const float* x0, int C0, const float* x1, int C1, const float* x2 /*nullable*/, int C2,
+                                     const float* dy, float* dw, float* dbias /*nullable*/, int B, int Cout, int H, int W, int ks,
+                                     void* stream);
+
 /* Strided variants (stride 1 or 2, zero pad k/2): PoseNet's stride-2 conv_gn blocks, networks/pose/PoseNet.py:28-34.
  * x:[B,Cin,Hin,Win] -> y / dy:[B,Cout,Ho,Wo] with Ho = (Hin + 2*(k/2) - k)/stride + 1.  Backward-data of a stride-2 conv is
  * pnsfm_conv2d_backward_data applied to dy zero-upsampled onto the input grid (dy[y][x] at (2y, 2x)). */

@@ -327,7 +327,10 @@ static const std::array<int, 2>* tune_lookup(const std::array<int, 7>& key, bool
 }
 
 struct ConvArgs {
-  const float* x;     // [B][Cin][H][W]
+  const float* x;     // [B][Cin][H][W]   (multi-source: [B][C0][H][W], followed in K by x1 [B][C1][H][W] and x2 [B][Cin-C0-C1][H][W])
+  const float* x1;
+  const float* x2;
+  int C0, C01;        // channels of x, of x + x1 (C0 = C01 = Cin for a single source)
   const float* wp;    // [KK][KP][MP]
   const float* bias;  // [Cout] or null
   float* y;           // [B][Cout][H][W]
@@ -835,9 +838,13 @@ extern "C" int pnsfm_debug_set_trace_flags(int f) { g_trace_flags = f; return 0;
 #endif
 
 static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
-                        int Cout, int H, int W, int ks, hipStream_t stream, const char* what, int S, int Hi, int Wi) {
+                        int Cout, int H, int W, int ks, hipStream_t stream, const char* what, int S, int Hi, int Wi,
+                        const ConvSrc* ms = nullptr) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.y = y;
+  a.x1 = ms ? ms->x1 : nullptr; a.x2 = ms ? ms->x2 : nullptr;
+  a.C0 = ms ? ms->C0 : Cin; a.C01 = ms ? ms->C0 + ms->C1 : Cin;
+  if (ms && g.DMA < 3) { set_error("%s: several input tensors need the split-bf16 kernels", what); return -1; }
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.S = S; a.Hi = Hi; a.Wi = Wi;
   a.CI = g.CI; a.mode = g.mode; a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img;
@@ -935,7 +942,7 @@ static float time_on_stream(hipStream_t stream, int reps, F fn) {
 
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
                        int H, int W, int ks, hipStream_t stream, const char* what, int kind_tag, int S = 1, int Hi = 0,
-                       int Wi = 0) {
+                       int Wi = 0, const ConvSrc* ms = nullptr) {
   if (S == 1) { Hi = H; Wi = W; }
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) { set_error("%s: bad shape", what); return -1; }
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("%s: unsupported kernel size %d", what, ks); return -1; }
@@ -974,9 +981,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
           last_split = c.splitK;
           const long blocks = (long)B * c.tiles_per_img * (c.MP / (32 * c.MT)) * c.splitK;
           if (c.splitK > 1 && blocks > 24L * 256 * 4) break;      // already far more blocks than the chip holds
-          const float ms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi); });
-          tune_log(0, key, NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK, ms);
-          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = {NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK}; }
+          const float tms = time_on_stream(stream, 2, [&]() { return enqueue_conv(c, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi, ms); });
+          tune_log(0, key, NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK, tms);
+          if (tms > 0.f && tms < best_ms) { best_ms = tms; best = {NT | (DA << 4) | (fMT << 8) | (tm << 9), c.splitK}; }
         }
       }
       dec = &g_tuned.emplace(key, best).first->second;
@@ -994,7 +1001,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
   prof_begin(0, flops, stream, meta);
-  const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi);
+  const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi, ms);
   prof_end(0, stream);
   return rc;
 }
@@ -1335,9 +1342,27 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx, 
   return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data", 1);
 }
 
+static bool conv_ms_ok(int C0, int C1, int C2, int granule, const char* what) {
+  if (C0 <= 0 || C1 <= 0 || C2 < 0 || C0 % granule != 0 || (C2 > 0 && (C0 + C1) % granule != 0)) {
+    set_error("%s: input tensors of %d / %d / %d channels: every tensor but the last must end on a %d-channel boundary", what, C0, C1,
+              C2, granule);
+    return false;
+  }
+  return true;
+}
+
+int pnsfm_conv2d_forward_cat(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* wp_fwd,
+                             const float* bias, float* y, int B, int Cout, int H, int W, int ks, void* stream) {
+  const int Cin = C0 + C1 + C2;
+  if (!conv_ms_ok(C0, C1, C2, 16, "conv2d_forward_cat")) return -1;
+  if (!conv_use_bx3(Cin, ks)) { set_error("conv2d_forward_cat: needs the split-bf16 arithmetic (>= 16 channels)"); return -1; }
+  const ConvSrc ms = {x1, x2, C0, C1};
+  return launch_conv(x0, wp_fwd, bias, y, B, Cin, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward_cat", 0, 1, 0, 0, &ms);
+}
+
 // H, W: size of dY (the conv OUTPUT); x is [B, Cin, Hi, Wi] with Hi = H, Wi = W when S == 1
 static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
-                      int ks, int S, int Hi, int Wi, void* stream) {
+                      int ks, int S, int Hi, int Wi, void* stream, const ConvSrc* ms = nullptr) {
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("backward_weight: unsupported kernel size %d", ks); return -1; }
   if (S != 1 && S != 2) { set_error("backward_weight: unsupported stride %d", S); return -1; }
   hipStream_t s = (hipStream_t)stream;
@@ -1449,10 +1474,14 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   int nt3 = wgrad3_nt2_ok(Cin, ks) ? 2 : 1, wm3 = 0;
   int split3 = v3_ok ? v3_default_split(nt3) : 1;
   if (v3_ok && g_wgrad_variant != 0 && g_wgrad_variant != 1) variant = 2;     // -1 (library default) or 2 (pinned)
+  if (ms) {          // several input tensors (ConvSrc): only the split-bf16 kernel reads them
+    if (!v3_ok) { set_error("backward_weight: several input tensors need the split-bf16 weight-gradient kernel"); return -1; }
+    variant = 2;
+  }
   {
     // tuned / pinned decision of this shape (autotuner, PNSFM_TUNE_DB / shipped database, pnsfm_tune_set -- the latter in
     // every build, so tests can pin kernel, split, ci tiles per wave and co tiles per workgroup on the emulator too)
-    const std::array<int, 7> key = {2 + 10 * S + (v3_ok ? 100 : 0), B, Cin, Cout, a.cstride, W, ks};
+    const std::array<int, 7> key = {2 + 10 * S + (v3_ok ? 100 : 0) + (ms ? 1000 : 0), B, Cin, Cout, a.cstride, W, ks};
     const bool tune = autotune_enabled();
     std::lock_guard<std::mutex> lk(g_tune_mu);
     const std::array<int, 2>* dec = tune_lookup(key, tune);
@@ -1462,7 +1491,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
       float best_ms = 1e30f;
       int best_split = a.splitP, prev_tps = -1;
       const long base = (long)n_tiles * m_tiles;
-      for (int want = 1; want <= a.total_tiles; want = want < 8 ? want + 1 : (want * 3 + 1) / 2) {
+      for (int want = 1; want <= a.total_tiles && !ms; want = want < 8 ? want + 1 : (want * 3 + 1) / 2) {
         const int tps = ceil_div(a.total_tiles, want);
         if (tps == prev_tps) continue;
         prev_tps = tps;
@@ -1474,7 +1503,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; }
       }
       int best_variant = 0;
-      if (v2_ok) {     // tap-major kernel: pixel splits around one workgroup per CU
+      if (v2_ok && !ms) {     // tap-major kernel: pixel splits around one workgroup per CU
         const int base2 = wgrad2_base_blocks(Cin, Cout, ks), tiles2 = wgrad2_total_tiles(B, H0, W0);
         int prev = -1;
         for (int want = 1; want <= tiles2; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
@@ -1504,9 +1533,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
               if ((long)base3 * split < 200 && split < tiles3) continue;      // cannot fill the chip
               if ((long)base3 * split > 16L * 256 && split > 1) break;
               if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
-              const float ms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, WMv, s); });
-              tune_log(2, key, 2 | (NT << 4) | (WMv << 6), split, ms);
-              if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6); }
+              if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) continue;
+              const float tms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, WMv, s, ms); });
+              tune_log(2, key, 2 | (NT << 4) | (WMv << 6), split, tms);
+              if (tms > 0.f && tms < best_ms) { best_ms = tms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6); }
             }
           }
       }
@@ -1517,7 +1547,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     if (dec) {
       const int d0 = (*dec)[0], d1 = (*dec)[1];
       variant = ((d1 & 15) == 1 && v2_ok) ? 1 : (((d1 & 15) == 2 && v3_ok) ? 2 : 0);
-      if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 7; }
+      if (ms) variant = 2;
+      if (variant == 2 && (d1 & 15) != 2) { /* a pinned decision for another kernel: keep the split-bf16 defaults */ }
+      else if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 7; }
       else if (variant == 1) split2 = d0;
       else {
         int sp = d0;
@@ -1532,7 +1564,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   if (variant == 2) {
     const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3};
     prof_begin(1, flops, s, meta);
-    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split3, nt3, wm3, s);
+    const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split3, nt3, wm3, s, ms);
     prof_end(1, s);
     return rc;
   }
@@ -1553,6 +1585,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
 int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout,
                                  int H, int W, int ks, void* stream) {
   return wgrad_impl(x, dy, dw, dbias, B, Cin, Cout, H, W, ks, 1, H, W, stream);
+}
+
+int pnsfm_conv2d_backward_weight_cat(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* dy,
+                                     float* dw, float* dbias, int B, int Cout, int H, int W, int ks, void* stream) {
+  if (!conv_ms_ok(C0, C1, C2, 32, "conv2d_backward_weight_cat")) return -1;
+  const ConvSrc ms = {x1, x2, C0, C1};
+  return wgrad_impl(x0, dy, dw, dbias, B, C0 + C1 + C2, Cout, H, W, ks, 1, H, W, stream, &ms);
 }
 
 int pnsfm_conv2d_forward_strided(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin,

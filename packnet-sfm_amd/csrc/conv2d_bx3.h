@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
   // ---- patch staging.  Item e = (pixel e>>1 of the patch, channel half e&1); its three 16-byte pieces go to byte e*16 of
   // each plane.  A thread's items sit at the same pixel for every chunk: the byte offset inside a channel image is computed
   // once; out-of-image pixels carry an out-of-range offset (the buffer load returns 0 for them, as for channels >= Cin).
-  const float* xb = a.x + (size_t)b * a.Cin * HWi;
+  // (multi-source input: the decoder's concatenations are never materialised -- chunk c reads whichever tensor holds its channels)
   const int nitems = 2 * PS;
   const int nit = (nitems + 255) >> 8;
   const bool prefetch = nit <= MAXIT;
@@ -147,10 +147,16 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) gv[it] = item_off(it * 256 + tid);
   float raw[MAXIT][8];
-  auto chunk_buf = [&](int c) -> pnsfm_buf {       // descriptor over channels [16c, Cin) of this image
-    const int ci0 = c * 16;
-    const long rem = (long)(a.Cin - ci0) * HWi * 4;
-    return pnsfm_make_buf(xb + (size_t)ci0 * HWi, (unsigned)(rem > 0 ? rem : 0));
+  auto chunk_buf = [&](int c) -> pnsfm_buf {       // descriptor over the channels from 16c to the end of THEIR source tensor, this image
+    int ci0 = c * 16;
+    const float* src = a.x;
+    int Cs = a.C0;
+    if (ci0 >= a.C0) {                             // wave-uniform
+      if (ci0 < a.C01) { src = a.x1; Cs = a.C01 - a.C0; ci0 -= a.C0; }
+      else { src = a.x2; Cs = a.Cin - a.C01; ci0 -= a.C01; }
+    }
+    const long rem = (long)(Cs - ci0) * HWi * 4;
+    return pnsfm_make_buf(src + ((size_t)b * Cs + ci0) * HWi, (unsigned)(rem > 0 ? rem : 0));
   };
   auto load_items = [&](int c) {
     const pnsfm_buf buf = chunk_buf(c);

@@ -31,7 +31,10 @@
 namespace pnsfm {
 
 struct Wgrad3Args {
-  const float* x;    // [B][Cin][H][W]
+  const float* x1;   // multi-source input (ConvSrc, pnsfm_common.h): channels [C0, C01) live in x1, [C01, Cin) in x2
+  const float* x2;
+  int C0, C01;       // C0 = C01 = Cin for a single source
+  const float* x;    // [B][Cin][H][W]  (multi-source: [B][C0][H][W])
   const float* dy;   // [B][Cout][H][W]
   float* dw;         // [Cout][Cin][KS][KS]   written directly when the launch has ONE pixel split ...
   float* dbias;      // [Cout] or null
@@ -138,7 +141,14 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     cur[1] = cur[0]; advance(cur[1]);
     cur[2] = cur[1]; advance(cur[2]);
   }
-  const pnsfm_buf xbuf = pnsfm_make_buf(a.x, (unsigned)((size_t)a.B * a.Cin * HW * 4));
+  // the tensor this workgroup's ci tile lives in (tiles never straddle two sources: the entry point checks the granule)
+  const float* xs = a.x;
+  int Cs = a.C0, lci0 = ci0;
+  if (ci0 >= a.C0) {
+    if (ci0 < a.C01) { xs = a.x1; Cs = a.C01 - a.C0; lci0 = ci0 - a.C0; }
+    else { xs = a.x2; Cs = a.Cin - a.C01; lci0 = ci0 - a.C01; }
+  }
+  const pnsfm_buf xbuf = pnsfm_make_buf(xs, (unsigned)((size_t)a.B * Cs * HW * 4));
   const pnsfm_buf dybuf = pnsfm_make_buf(a.dy, (unsigned)((size_t)a.B * a.Cout * HW * 4));
 
   // patch items of this thread: (channel, row, 8-column group); LDS slot and lane part of the global offset are fixed
@@ -152,11 +162,11 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
     it_lds[it] = (ci * CS + r * RS + 8 * g) * 2;
     it_ry[it] = r + ky - P;                       // image row = y0 + it_ry
     it_gx[it] = 8 * g - 8;                        // image column = x0 + it_gx
-    it_lane[it] = ((ci0 + ci) * HW + it_ry[it] * W + it_gx[it]) * 4;
+    it_lane[it] = ((lci0 + ci) * HW + it_ry[it] * W + it_gx[it]) * 4;
   }
   float raw[PDX][NIT][8];
   auto load_patch = [&](float (&rw)[NIT][8], const Cur& c) {
-    const int sbase = (c.b * a.Cin * HW + c.y0 * W + c.x0) * 4;
+    const int sbase = (c.b * Cs * HW + c.y0 * W + c.x0) * 4;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int yy = c.y0 + it_ry[it], xx = c.x0 + it_gx[it];
@@ -432,15 +442,22 @@ static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
 }
 
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
-                   int split, int NT, int WMwant, hipStream_t s) {
+                   int split, int NT, int WMwant, hipStream_t s, const ConvSrc* ms) {
   if (!wgrad3_supported(Cin, Cout, H, W, ks)) { set_error("conv2d_backward_weight (split-bf16): unsupported shape"); return -1; }
   if ((size_t)B * Cin * H * W * 4 >= (1ull << 31) || (size_t)B * Cout * H * W * 4 >= (1ull << 31)) {
     set_error("conv2d_backward_weight (split-bf16): tensor too large for 32-bit buffer offsets");
     return -1;
   }
   if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
+  if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) NT = 1;     // a 64-channel tile would straddle two tensors
+  if (ms && (ms->C0 % 32 != 0 || (ms->C0 + ms->C1) % 32 != 0)) {
+    set_error("conv2d_backward_weight (split-bf16): the input tensors must end on 32-channel boundaries");
+    return -1;
+  }
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
+  a.x1 = ms ? ms->x1 : nullptr; a.x2 = ms ? ms->x2 : nullptr;
+  a.C0 = ms ? ms->C0 : Cin; a.C01 = ms ? ms->C0 + ms->C1 : Cin;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   const int tc = wgrad3_tc(W);
   const bool masked = W % 8 != 0;

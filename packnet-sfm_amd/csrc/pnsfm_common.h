@@ -169,6 +169,15 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }
 
+// Multi-source input of a convolution: the K channels are the concatenation of up to three NCHW tensors (x [C0 channels], x1 [C1],
+// x2 [the rest]) -- the decoder's torch.cat((unpack, skip, upsampled disparity), 1) without the copy.  C0 and C0 + C1 must be
+// multiples of the kernels' channel granule (16 forward, 32 / 64 weight gradient) so that a K chunk never straddles two sources.
+struct ConvSrc {
+  const float* x1;
+  const float* x2;
+  int C0, C1;
+};
+
 // --- conv2d implicit-GEMM geometry (shared by forward / backward-data / packers) -----------
 // GEMM view: M = output channels, N = output pixels, K = (tap, input channel).
 struct ConvGeom {
@@ -210,7 +219,7 @@ int wgrad3_total_tiles(int B, int H, int W);
 int wgrad3_WM(int Cout, int want);          // co tiles per workgroup (want: 0 = the most the layer fills, or 1 / 2 / 4)
 int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM);
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
-                   int split, int NT, int WM, hipStream_t stream);
+                   int split, int NT, int WM, hipStream_t stream, const ConvSrc* ms = nullptr);
 
 // more than 64 KB of dynamic LDS needs hipFuncSetAttribute once per kernel AND device: `mask` (one static per kernel
 // instantiation) remembers the devices already done (api.hip).  0 on success.

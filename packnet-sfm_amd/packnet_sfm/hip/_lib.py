@@ -29,6 +29,8 @@ SIGNATURES = {
     "pnsfm_conv2d_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv2d_forward_cat": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv2d_backward_weight_cat": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_forward_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_groupnorm_ws_doubles": (_sz, [_i, _i, _i]),

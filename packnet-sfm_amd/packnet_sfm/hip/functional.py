@@ -9,6 +9,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
+from ._lib import HipError as _HipError
 
 # bumped by optimizers that update parameters through raw pointers (bypassing tensor._version)
 _WEIGHT_EPOCH = [0]
@@ -313,6 +314,64 @@ class Conv2dFn(Function):
 
 def conv2d(x, weight, bias, cache):
     return Conv2dFn.apply(x, weight, bias, cache, torch.is_grad_enabled())
+
+
+class Conv2dCatFn(Function):
+    """y = conv2d(zero_pad(cat((x0, x1[, x2]), 1)), weight) + bias with the concatenation folded into the K loop of the split-bf16
+    kernels (the decoder's skip connections, reference PackNet01.py:138-174): the concatenated tensor -- 254 MB for iconv1 at
+    192x640 batch 4 -- is neither written nor read.  Backward-data produces the gradient of the whole concatenation in one tensor;
+    the inputs receive channel slices of it (views)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, cache, recording, *xs):
+        xs = tuple(t.contiguous() for t in xs)
+        need_dx = any(ctx.needs_input_grad[4:])
+        wp_fwd, wp_bwd = cache.get(weight, need_dx)
+        Cout, Cin, ks, _ = weight.shape
+        if sum(t.shape[1] for t in xs) != Cin:
+            raise RuntimeError("conv2d_cat: inputs have %d channels, weight expects %d" % (sum(t.shape[1] for t in xs), Cin))
+        y = ops.conv2d_forward_cat(xs, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
+        ctx.save_for_backward(wp_bwd if wp_bwd is not None else xs[0].new_empty(0), *xs)
+        ctx.meta = (Cin, Cout, ks, bias is not None)
+        ctx.params = (weight, bias)
+        _WgradStream.note_use(recording, weight, bias)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        wp_bwd, *xs = ctx.saved_tensors
+        Cin, Cout, ks, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dxs = [None] * len(xs)
+        dw = db = None
+        detached = _WgradStream.side_ok(*ctx.params)
+        sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[0])
+        if any(ctx.needs_input_grad[4:]):
+            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
+            c0 = 0
+            for i, t in enumerate(xs):
+                if ctx.needs_input_grad[4 + i]:
+                    dxs[i] = dx[:, c0:c0 + t.shape[1]]
+                c0 += t.shape[1]
+        if ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1]):
+            try:
+                dw, db = ops.conv2d_backward_weight_cat(xs, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+            except _HipError:      # outside the split weight-gradient kernel's envelope: concatenate for this one kernel
+                dw, db = ops.conv2d_backward_weight(torch.cat(xs, 1), dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+        return (dw, db, None, None) + tuple(dxs)
+
+
+def conv2d_cat(xs, weight, bias, cache):
+    """xs: tuple of 2 or 3 NCHW tensors.  Falls back to torch.cat + conv2d when the shape is outside the multi-source kernels'
+    envelope (first / second tensor not ending on a 16-channel boundary, < 16 channels, f32 arithmetic mode)."""
+    import os
+    C0 = xs[0].shape[1]
+    ok = os.environ.get('PNSFM_CAT_FOLD', '1') != '0' and len(xs) in (2, 3) and C0 % 16 == 0 and (len(xs) == 2 or (C0 + xs[1].shape[1]) % 16 == 0) and get_conv_math() == 'bx3' \
+        and sum(t.shape[1] for t in xs) >= 16
+    if not ok:
+        return conv2d(torch.cat(xs, 1), weight, bias, cache)
+    return Conv2dCatFn.apply(weight, bias, cache, torch.is_grad_enabled(), *xs)
 
 
 class Conv2dStride2Fn(Function):

@@ -111,6 +111,37 @@ def conv2d_backward_weight(x, dy, ks, want_bias=True, dw_out=None, db_out=None):
     return dw, db
 
 
+def conv2d_forward_cat(xs, wp_fwd, bias, Cout, ks):
+    """conv(cat(xs, 1)) without the concatenated tensor; xs: 2 or 3 contiguous NCHW tensors of equal B, H, W.  Raises HipError when
+    the shape is outside the split kernels' envelope (the caller concatenates instead)."""
+    _chk(*xs, wp_fwd, bias); _f32(*xs, wp_fwd, bias)
+    B, _, H, W = xs[0].shape
+    C = [t.shape[1] for t in xs] + [0] * (3 - len(xs))
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xs[0].device)
+    rc = _lib.get().pnsfm_conv2d_forward_cat(_ptr(xs[0]), C[0], _ptr(xs[1]), C[1], _ptr(xs[2] if len(xs) > 2 else None), C[2],
+                                             _ptr(wp_fwd), _ptr(bias), _ptr(y), B, Cout, H, W, ks, _stream(xs[0]))
+    _lib.check(rc, "conv2d_forward_cat")
+    return y
+
+
+def conv2d_backward_weight_cat(xs, dy, ks, want_bias=True, dw_out=None, db_out=None):
+    _chk(*xs, dy); _f32(*xs, dy)
+    B, _, H, W = xs[0].shape
+    C = [t.shape[1] for t in xs] + [0] * (3 - len(xs))
+    Cin, Cout = sum(C), dy.shape[1]
+    if dw_out is not None:
+        _chk(dw_out, db_out); _f32(dw_out, db_out)
+        if tuple(dw_out.shape) != (Cout, Cin, ks, ks) or (want_bias and (db_out is None or db_out.numel() != Cout)):
+            raise RuntimeError("conv2d_backward_weight_cat: gradient slot has the wrong shape")
+        dw, db = dw_out.view(dw_out.shape), (db_out.view(db_out.shape) if want_bias else None)
+    else:
+        dw, db = _alloc_dw_db(Cout, Cin, ks, want_bias, dy.device)
+    rc = _lib.get().pnsfm_conv2d_backward_weight_cat(_ptr(xs[0]), C[0], _ptr(xs[1]), C[1], _ptr(xs[2] if len(xs) > 2 else None), C[2],
+                                                     _ptr(dy), _ptr(dw), _ptr(db), B, Cout, H, W, ks, _stream(dy))
+    _lib.check(rc, "conv2d_backward_weight_cat")
+    return dw, db
+
+
 def conv2d_forward_strided(x, wp_fwd, bias, Cout, ks, stride):
     _chk(x, wp_fwd, bias); _f32(x, wp_fwd, bias)
     B, Cin, H, W = x.shape

@@ -71,10 +71,12 @@ class PackNet01(nn.Module):
                     m.bias.data.zero_()
 
     def _merge(self, up, skip, disp=None):
-        feat = torch.cat((up, skip), 1) if self.version == 'A' else up + skip
+        """Input of an iconv block: cat(up, skip[, upsampled inverse depth]) (version 'A') or up + skip[, ...] ('B') -- returned as
+        the TUPLE of its parts: Conv2D folds the concatenation into its K loop (reference :138-174 materialises it)."""
+        parts = (up, skip) if self.version == 'A' else (up + skip,)
         if disp is not None:
-            feat = torch.cat((feat, F.interpolate(disp, scale_factor=2, mode='nearest')), 1)
-        return feat
+            parts = parts + (F.interpolate(disp, scale_factor=2, mode='nearest'),)
+        return parts if len(parts) > 1 else parts[0]
 
     def forward(self, rgb):
         """Inverse depth maps: list of 4 scales (training) or the full-resolution map (eval)."""

@@ -55,10 +55,10 @@ class Decoder(nn.Module):
             setattr(self, 'disp%d_layer' % (i + 1), InvDepth(n[i], out_channels=out_channels))
 
     def _merge(self, up, skip, disp=None):
-        feat = torch.cat((up, skip), 1) if self.version == 'A' else up + skip
+        parts = (up, skip) if self.version == 'A' else (up + skip,)        # Conv2D folds the concatenation into its K loop
         if disp is not None:
-            feat = torch.cat((feat, F.interpolate(disp, scale_factor=2, mode='nearest')), 1)
-        return feat
+            parts = parts + (F.interpolate(disp, scale_factor=2, mode='nearest'),)
+        return parts if len(parts) > 1 else parts[0]
 
     def forward(self, x5p, skips):
         skip1, skip2, skip3, skip4, skip5 = skips

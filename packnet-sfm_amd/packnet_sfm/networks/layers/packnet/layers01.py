@@ -31,11 +31,14 @@ class _HipConv2d(nn.Conv2d):
         self._packed = HF.PackedConvWeight()
 
     def forward(self, x):
+        if isinstance(x, (tuple, list)):       # channel concatenation folded into the convolution (hip.functional.conv2d_cat)
+            return HF.conv2d_cat(tuple(x), self.weight, self.bias, self._packed)
         return HF.conv2d(x, self.weight, self.bias, self._packed)
 
 
 class Conv2D(nn.Module):
-    """2D convolution (zero 'same' padding) + GroupNorm(16) + ELU."""
+    """2D convolution (zero 'same' padding) + GroupNorm(16) + ELU.  `x` may be a tuple of tensors standing for their channel
+    concatenation (the decoder's skip connections): the concatenated tensor is then never materialised."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride):
         super().__init__()

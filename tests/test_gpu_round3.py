@@ -314,3 +314,14 @@ def test_two_rank_gradient_averaging():
     assert res['ok']
     if torch.cuda.device_count() >= 2:
         assert res['backend'] == 'nccl' and res['timing'] is not None
+
+
+# ------------------------------------------------------------------------------------- (f) the decoder's concatenations
+@pytest.mark.parametrize('case', [(2, (64, 64, 1), 64, 48, 160, 3, 0), (4, (128, 128, 1), 128, 24, 80, 3, 1), (2, (512, 512), 512, 12, 40, 3, 2),
+                                  (1, (64, 64, 1), 64, 192, 640, 3, 3)])
+def test_conv2d_cat_multi_source_gpu(case):
+    """iconv1 .. iconv5 of PackNet01 read cat(unpacked, skip[, upsampled inverse depth]) (reference PackNet01.py:138-174); here the
+    concatenation is folded into the K loop of the split-bf16 forward and weight-gradient kernels.  Against F.conv2d on the
+    concatenated tensor at the real layer shapes (autotuner on: every candidate tiling reads the three tensors)."""
+    from test_kernels_emulated import _check_conv2d_cat
+    _check_conv2d_cat(DEV, *case)

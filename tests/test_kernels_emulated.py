@@ -677,3 +677,37 @@ def test_groupnorm_two_launch_form(emulated_kernels, shape, act, use_res):
         P.check(rh.grad, rr.grad, 2e-5, 'dres')
     P.check(gh.grad, gr.grad, 2e-5, 'dgamma')
     P.check(bh.grad, br.grad, 2e-5, 'dbeta')
+
+
+def _check_conv2d_cat(device, B, Cs, Cout, H, W, ks, seed):
+    """conv(cat(xs)) folded into the K loop (hip.functional.conv2d_cat) vs F.conv2d on the concatenated tensor: output, the gradient of
+    every input tensor, weight and bias gradients."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import functional as HF
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in Cs]
+    w = torch.randn(Cout, sum(Cs), ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(torch.cat(xr, 1), wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xh = [t.clone().to(device).requires_grad_(True) for t in xs]
+    wh, bh = w.clone().to(device).requires_grad_(True), b.clone().to(device).requires_grad_(True)
+    y = HF.conv2d_cat(tuple(xh), wh, bh, HF.PackedConvWeight())
+    y.backward(dy.to(device))
+    P.check(y, yr, 1e-5, 'fwd')
+    for i, (a, r) in enumerate(zip(xh, xr)):
+        P.check(a.grad, r.grad, 1e-5, 'd input %d' % i)
+    P.check(wh.grad, wr.grad, 2e-5, 'wgrad')
+    P.check(bh.grad, br.grad, 2e-5, 'dbias')
+
+
+@pytest.mark.parametrize('case', [(2, (32, 32, 1), 16, 6, 20, 3, 0), (1, (64, 32), 40, 5, 8, 3, 1), (1, (16, 5), 32, 4, 32, 5, 2),
+                                  (1, (32, 64, 3), 8, 3, 16, 3, 3), (1, (8, 8), 16, 4, 8, 3, 4)])
+def test_conv2d_cat_multi_source(emulated_kernels, case):
+    """The decoder's cat(unpacked, skip[, upsampled disparity]) as a multi-source K loop: three and two tensors, a ragged last tensor, a
+    first tensor of 16 channels (forward folds, the weight gradient falls back to one concatenation: 32-channel granule), and a shape
+    outside the envelope (8-channel tensors: plain torch.cat path)."""
+    _check_conv2d_cat('cpu', *case)

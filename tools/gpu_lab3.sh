@@ -53,6 +53,14 @@ ab_1x1)
   echo "== bench with 1x1 layers on the f32 kernels"
   PNSFM_BX3_1X1=0 PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_ab1x1_$TAG.log 2>&1
   tail -1 $O/bench_ab1x1_$TAG.log | cut -c1-400 ;;
+ab_cat)
+  echo "== A/B: concatenations folded into the conv K loop vs torch.cat (same database, A B A B)"
+  for i in 1 2; do
+    PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_catA_$TAG.log 2>&1
+    echo "fold   : $(tail -1 $O/bench_catA_$TAG.log | cut -c1-150)"
+    PNSFM_CAT_FOLD=0 PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_catB_$TAG.log 2>&1
+    echo "no fold: $(tail -1 $O/bench_catB_$TAG.log | cut -c1-150)"
+  done ;;
 bench2)
   echo "== bench again on the primed database (run-to-run spread)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench2_$TAG.log 2>&1

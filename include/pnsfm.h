@@ -94,8 +94,8 @@ int pnsfm_set_conv_variant(int lds_dma);
  *     (v_mfma_f32_32x32x16_bf16; dropped terms <= 3 * 2^-24 |a||b|) -- measured error against fp64 is BELOW that of the f32
  *     MFMA chain (tools/micro/bf16x3_check.hip; tests/test_gpu_parity.py::test_conv2d_bx3_error_vs_fp64);
  *   0 v_mfma_f32_32x32x2_f32 everywhere (env PNSFM_CONV_MATH=f32).
- * Variants 3..5 of pnsfm_set_conv_variant select the un-tuned LDS plan of the split kernels (3: one patch buffer, 4: two,
- * 5: two + a whole kernel row of weights per stage).  The packed-weight layout follows from (mode, shape):
+ * Variants 3..6 of pnsfm_set_conv_variant select the un-tuned LDS plan of the split kernels (3: one patch buffer, 4: two,
+ * 5: two + a whole kernel row of weights per stage, 6: <= 53 KB of LDS and <= 168 registers so that THREE workgroups share a CU).  The packed-weight layout follows from (mode, shape):
  * pnsfm_conv2d_packed_elems_* already return the larger of the two sizes, but weights packed under one mode must be packed
  * again after a switch.  Returns the previous mode.  Under mode 1 the weight gradient runs the same split arithmetic
  * (conv2d_wgrad3.hip: stride 1, k in {3,5,7}, W % 4 == 0, >= 16 channels; tests/test_gpu_round3.py holds its error against fp64 to

@@ -62,6 +62,7 @@ static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_s
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
 static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
 static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
+static const size_t kPipeThreeBlocks = 53 * 1024;  // variant 6 of the split-bf16 kernels: three workgroups per CU
 
 // Geometry of the forward / backward-data kernel for a FIXED choice of (NT, K-split); false if it does not fit.
 // tm (split-bf16 kernels only): 0 = the classic tilings (32-wide 2-D tiles when W % 32 == 0, else linear runs whose patch spans
@@ -122,7 +123,8 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.CI = 16;
     g.KP = round_up(Cin, 16);
     g.nchunks = g.KP / 16;
-    g.PB = DMA == 3 ? 1 : 2;
+    g.PB = (DMA == 3 || DMA == 6) ? 1 : 2;
+    if (DMA == 6 && g.MT * NT > 2) return false;           // three workgroups per CU: <= 168 VGPRs only without the (2,2) tile
     const int KK = ks * ks;
     const size_t plane = (size_t)round_up(g.PH * g.PW * 32, 1024);
     const size_t patch = (size_t)g.PB * 3 * plane;
@@ -131,6 +133,10 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.G = 0;
     if (DMA == 5) {
       if (smem_bx3(cand[0]) <= kMaxSmemPipe) g.G = cand[0];
+    } else if (DMA == 6) {
+      for (int i = 0; i < 6 && !g.G; ++i)
+        if (cand[i] <= KK && smem_bx3(cand[i]) <= kPipeThreeBlocks) g.G = cand[i];
+      if (!g.G) return false;
     } else {
       for (int i = 0; i < 6 && !g.G; ++i)
         if (cand[i] <= KK && smem_bx3(cand[i]) <= kPipeTwoBlocks) g.G = cand[i];
@@ -879,16 +885,21 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     do {                                                                                                           \
       static unsigned long long done = 0; /* one bit per device */                                                 \
       if (g.smem_bytes > 64 * 1024 &&                                                                              \
-          ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_bx3_kernel<MTv, NTv>), &done, (int)kMaxSmemPipe, what)) \
+          ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_bx3_kernel<MTv, NTv, 2>), &done, (int)kMaxSmemPipe, what)) \
         return -1;                                                                                                 \
     } while (0)
 #else
 #define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
 #endif
-    if (g.MT == 2 && g.NT == 2) { PNSFM_BX3_ATTR(2, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else if (g.MT == 2 && g.NT == 1) { PNSFM_BX3_ATTR(2, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else if (g.MT == 1 && g.NT == 2) { PNSFM_BX3_ATTR(1, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else { PNSFM_BX3_ATTR(1, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
+    if (g.DMA == 6) {         // three workgroups per CU (<= 53 KB of LDS each: no opt-in needed)
+      if (g.MT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 3>), grid, dim3(256), g.smem_bytes, stream, a);
+      else if (g.NT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 3>), grid, dim3(256), g.smem_bytes, stream, a);
+      else PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 3>), grid, dim3(256), g.smem_bytes, stream, a);
+    }
+    else if (g.MT == 2 && g.NT == 2) { PNSFM_BX3_ATTR(2, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 2 && g.NT == 1) { PNSFM_BX3_ATTR(2, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 1 && g.NT == 2) { PNSFM_BX3_ATTR(1, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else { PNSFM_BX3_ATTR(1, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
 #undef PNSFM_BX3_ATTR
   } else if (g.DMA == 2) {
 #ifndef PNSFM_EMU
@@ -970,9 +981,10 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
       const int nTM = (bx3 && W % 32 != 0) ? 3 : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
-      for (int cfgt = 0; cfgt < 6 * nMT * nTM; ++cfgt) {
-        const int cfg = cfgt % (6 * nMT), tm = cfgt / (6 * nMT);
-        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % 3 + (bx3 ? 3 : 0), fMT = cfg / 6;
+      const int nVar = bx3 ? 4 : 3;                       // LDS plans: f32 0..2, split-bf16 3..6 (6 = three workgroups per CU)
+      for (int cfgt = 0; cfgt < 2 * nVar * nMT * nTM; ++cfgt) {
+        const int cfg = cfgt % (2 * nVar * nMT), tm = cfgt / (2 * nVar * nMT);
+        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % nVar + (bx3 ? 3 : 0), fMT = cfg / (2 * nVar);
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -1629,7 +1641,7 @@ int pnsfm_set_wgrad_variant(int tap_major) {
 }
 
 int pnsfm_set_conv_variant(int lds_dma) {
-  if (lds_dma >= 3) g_default_bx3 = lds_dma > 5 ? 5 : lds_dma;     // 3..5: un-tuned default of the split-bf16 kernels
+  if (lds_dma >= 3) g_default_bx3 = lds_dma > 6 ? 6 : lds_dma;     // 3..6: un-tuned default of the split-bf16 kernels
   else g_default_dma = lds_dma < 0 ? 0 : lds_dma;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_pinned.clear();       // pins only (see pnsfm_set_wgrad_variant)

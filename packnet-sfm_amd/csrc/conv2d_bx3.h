@@ -49,10 +49,13 @@ __device__ __forceinline__ void bx3_split8(const float (&v)[8], pnsfm_u32x4& H, 
   }
 }
 
-template <int MT, int NT>
-__global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
+// OCC = workgroups the register budget is sized for (__launch_bounds__): 2 (<= 256 VGPRs) or 3 (<= 168: one fragment set instead of
+// the tap-ahead pair, three patch items in flight) -- three waves per SIMD cover each other's staging / DMA-issue / barrier phases
+// (35-50 % of a wave's cycles, tools/bx3_trace.py) where two leave the matrix pipe idle; the host gives such launches <= 53 KB of LDS.
+template <int MT, int NT, int OCC>
+__global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   PNSFM_DYN_SMEM(unsigned char, smem);
-  constexpr int BM = 32 * MT, MAXIT = (MT * NT == 4) ? PNSFM_BX3_MAXIT - 1 : PNSFM_BX3_MAXIT;   // (2,2): acc + fragments leave fewer registers
+  constexpr int BM = 32 * MT, MAXIT = (MT * NT == 4 || OCC == 3) ? PNSFM_BX3_MAXIT - 1 : PNSFM_BX3_MAXIT;   // (2,2): acc + fragments leave fewer registers
   const int PS = a.PH * a.PW;
   const int planeB = a.pstride;                  // bytes of one piece plane of the patch
   const int patchB = 3 * planeB;
@@ -296,14 +299,22 @@ __global__ void __launch_bounds__(256, 2) conv2d_bx3_kernel(ConvArgs a) {
         if (++kx == a.KS) { kx = 0; ++ky; }
         return o;
       };
-      Frag f0, f1;
-      load_frag(f0, wst, 0, patch, tapoff());
-      for (int j = 0; j < gcount; j += 2) {
-        if (j + 1 < gcount) load_frag(f1, wst, j + 1, patch, tapoff());
-        mma(f0);
-        if (j + 1 < gcount) {
-          if (j + 2 < gcount) load_frag(f0, wst, j + 2, patch, tapoff());
-          mma(f1);
+      if (OCC == 3) {          // one fragment set: the other two waves of the SIMD hide the LDS latency
+        Frag f0;
+        for (int j = 0; j < gcount; ++j) {
+          load_frag(f0, wst, j, patch, tapoff());
+          mma(f0);
+        }
+      } else {
+        Frag f0, f1;
+        load_frag(f0, wst, 0, patch, tapoff());
+        for (int j = 0; j < gcount; j += 2) {
+          if (j + 1 < gcount) load_frag(f1, wst, j + 1, patch, tapoff());
+          mma(f0);
+          if (j + 1 < gcount) {
+            if (j + 2 < gcount) load_frag(f0, wst, j + 2, patch, tapoff());
+            mma(f1);
+          }
         }
       }
 

@@ -81,14 +81,14 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
-@pytest.mark.parametrize('direct_a', [5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize('direct_a', [6, 5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
                                    (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3),
                                    (2, 32, 64, 4, 40, 1), (1, 48, 33, 12, 40, 1)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
     """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; every
     variant of the forward/backward-data kernel: f32 MFMA (0 patch through registers, 1 patch by LDS-DMA, 2 fully pipelined)
-    and the split-bf16 arithmetic (3 one patch buffer, 4 two, 5 whole kernel rows per stage; shapes with < 16 K-channels or
+    and the split-bf16 arithmetic (3 one patch buffer, 4 two, 5 whole kernel rows per stage, 6 three workgroups per CU; shapes with < 16 K-channels or
     fall through to the f32 kernels there; 1x1 layers run the split kernels since round 3, on 32-wide rows of the flattened map
     when H*W is a multiple of 32)."""
     import torch.nn.functional as F
@@ -112,7 +112,7 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     P.check(db, br.grad, 1e-5, 'dbias')
 
 
-@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1)])
+@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1), (1, 6, 0, 1), (2, 6, 1, 2)])
 @pytest.mark.parametrize('shape', [(1, 48, 64, 9, 32, 3), (1, 40, 64, 20, 24, 5), (1, 32, 40, 8, 32, 7)])
 def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     """Configurations the un-tuned heuristics never pick for small test shapes (two pixel tiles per wave, narrow M tiles,

@@ -1546,9 +1546,12 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
               if ((long)base3 * split > 16L * 256 && split > 1) break;
               if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
               if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) continue;
-              const float tms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, WMv, s, ms); });
-              tune_log(2, key, 2 | (NT << 4) | (WMv << 6), split, tms);
-              if (tms > 0.f && tms < best_ms) { best_ms = tms; best_split = split; best_variant = 2 | (NT << 4) | (WMv << 6); }
+              for (int occ = 0; occ < ((ks == 3 && NT == 1 && W3 % 8 == 0) ? 2 : 1); ++occ) {    // occ 1: the three-workgroups-per-CU build
+                const int wmv = WMv | (occ ? 8 : 0);
+                const float tms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, wmv, s, ms); });
+                tune_log(2, key, 2 | (NT << 4) | (wmv << 6), split, tms);
+                if (tms > 0.f && tms < best_ms) { best_ms = tms; best_split = split; best_variant = 2 | (NT << 4) | (wmv << 6); }
+              }
             }
           }
       }
@@ -1561,7 +1564,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
       variant = ((d1 & 15) == 1 && v2_ok) ? 1 : (((d1 & 15) == 2 && v3_ok) ? 2 : 0);
       if (ms) variant = 2;
       if (variant == 2 && (d1 & 15) != 2) { /* a pinned decision for another kernel: keep the split-bf16 defaults */ }
-      else if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 7; }
+      else if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 15; }
       else if (variant == 1) split2 = d0;
       else {
         int sp = d0;

@@ -66,7 +66,9 @@ __device__ __forceinline__ void w3_split8(const float (&v)[8], pnsfm_u32x4& H, p
   }
 }
 
-template <int KS, int NT, int WM, int TCv>
+// OCC = 3 (3x3, one ci tile per wave only): register budget of three workgroups per CU (<= 168 VGPRs: shorter dY ring, one patch tile in
+// flight) -- the third wave per SIMD covers the staging / barrier phases the other two leave the matrix pipe idle in.
+template <int KS, int NT, int WM, int TCv, int OCC = 2>
 struct Wgrad3Geom {
   static constexpr int P = KS / 2, KK = KS * KS;
   static constexpr int WK = 4 / WM;                      // pixel shares of a workgroup
@@ -83,18 +85,18 @@ struct Wgrad3Geom {
   static constexpr int KPW = KSTEPS / WK;                // k-steps of a tile per wave
   // dY fragments in flight per wave (8 registers each): a whole tile ahead where the accumulators leave room -- the loads
   // are issued RD k-steps before use, which is what hides the global-memory latency when only one workgroup fits a CU
-  static constexpr int RDW = (KS >= 7 || NT == 2) ? 2 : (KS == 5 ? 4 : 8);
+  static constexpr int RDW = (KS >= 7 || NT == 2 || (OCC == 3 && TCv == 32)) ? 2 : ((KS == 5 || OCC == 3) ? 4 : 8);
   static constexpr int RD = 2 * KPW < RDW ? 2 * KPW : RDW;      // up to TWO tiles ahead (RD divides 2 * KPW)
   // patch prefetch depth in tiles: a 3x3 tile with one ci tile per wave is only 1-2 us of MFMAs -- less than the latency of
   // the loads issued at its start -- so those kernels keep two tiles of raw patch data in flight
-  static constexpr int PDX = (KS == 3 && NT == 1 && KPW <= 4) ? 2 : 1;
+  static constexpr int PDX = (KS == 3 && NT == 1 && KPW <= 4 && OCC != 3) ? 2 : 1;
 };
 
 // MASKED: W % 8 == 4 -- the upper half of an 8-pixel group may lie past the end of an image row: the two 4-pixel halves are
 // range-checked separately (an out-of-row half gets an out-of-range buffer offset and reads as zero)
-template <int KS, int NT, int WM, int TCv, bool MASKED>
-__global__ void __launch_bounds__(256, 2) conv2d_wgrad3_kernel(Wgrad3Args a) {
-  using Gm = Wgrad3Geom<KS, NT, WM, TCv>;
+template <int KS, int NT, int WM, int TCv, bool MASKED, int OCC = 2>
+__global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
+  using Gm = Wgrad3Geom<KS, NT, WM, TCv, OCC>;
   constexpr int P = Gm::P, KK = Gm::KK, WK = Gm::WK, TR = Gm::TR, TC = Gm::TC, RS = Gm::RS, CS = Gm::CS, NCI = Gm::NCI, SEG = Gm::SEG;
   constexpr int PIECE = Gm::PIECE, NIT = Gm::NIT, KPW = Gm::KPW, RD = Gm::RD, PDX = Gm::PDX;
   PNSFM_DYN_SMEM(unsigned char, smem);
@@ -418,6 +420,7 @@ static int wgrad3_tc(int W) {
 // -- fewer co tiles = more pixel shares per workgroup (WK = 4 / WM) and more workgroups: parallelism for the low-resolution
 // layers WITHOUT a pixel split (no partial tensors, no second kernel)
 int wgrad3_WM(int Cout, int want) {
+  want &= 7;
   const int most = Cout > 96 ? 4 : (Cout > 32 ? 2 : 1);
   return (want == 1 || want == 2 || want == 4) && want < most ? want : most;
 }
@@ -427,17 +430,17 @@ int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM) {
 }
 bool wgrad3_nt2_ok(int Cin, int ks) { return ks <= 3 && Cin > 32; }
 
-template <int KS, int NT, int WM, int TC, bool MASKED>
+template <int KS, int NT, int WM, int TC, bool MASKED, int OCC = 2>
 static int launch_wgrad3(const Wgrad3Args& a, dim3 grid, hipStream_t s) {
-  using Gm = Wgrad3Geom<KS, NT, WM, TC>;
+  using Gm = Wgrad3Geom<KS, NT, WM, TC, OCC>;
 #ifndef PNSFM_EMU
   static unsigned long long raised = 0;      // one bit per device
   if (Gm::SMEM > 64 * 1024 &&
-      ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), &raised, 160 * 1024,
+      ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED, OCC>), &raised, 160 * 1024,
                        "conv2d_backward_weight"))
     return -1;
 #endif
-  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
+  PNSFM_LAUNCH((conv2d_wgrad3_kernel<KS, NT, WM, TC, MASKED, OCC>), grid, dim3(256), (size_t)Gm::SMEM, s, a);
   return check_launch("conv2d_backward_weight (split-bf16)");
 }
 
@@ -469,6 +472,8 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   a.tiles_per_split = ceil_div(a.total_tiles, split);
   const int splitP = ceil_div(a.total_tiles, a.tiles_per_split);
   a.ci_tiles = ceil_div(Cin, 32 * NT);
+  const bool occ3 = (WMwant & 8) != 0 && ks == 3 && NT == 1 && !masked;      // WM | 8: the three-workgroups-per-CU build
+  WMwant &= 7;
   const int WM = wgrad3_WM(Cout, WMwant);
   const int co_groups = ceil_div(ceil_div(Cout, 32), WM);
   a.COP = co_groups * WM * 32;
@@ -496,7 +501,11 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
     else if (WM == 2) PNSFM_W3T(KSv, NTv, 2);                             \
     else PNSFM_W3T(KSv, NTv, 1);                                          \
   } while (0)
-  if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); else PNSFM_W3(1, 1); }
+  if (occ3) {
+    if (tc == 16) { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 16, false, 3>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 16, false, 3>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 16, false, 3>(a, grid, s); }
+    else { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 32, false, 3>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 32, false, 3>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 32, false, 3>(a, grid, s); }
+  }
+  else if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); else PNSFM_W3(1, 1); }
   else if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
   else if (ks == 5) PNSFM_W3(5, 1);
   else PNSFM_W3(7, 1);

@@ -230,11 +230,12 @@ def test_conv2d_wgrad_split_bf16(emulated_kernels, shape):
     P.check(db, br.grad, 1e-5, 'dbias (split-bf16)')
 
 
-@pytest.mark.parametrize('cfg', [(1, 1, 1), (1, 1, 2), (2, 1, 1), (2, 2, 2), (3, 1, 4)])
+@pytest.mark.parametrize('cfg', [(1, 1, 1), (1, 1, 2), (2, 1, 1), (2, 2, 2), (3, 1, 4), (1, 1, 9), (2, 1, 12), (2, 1, 10)])
 @pytest.mark.parametrize('shape', [(1, 64, 128, 8, 32, 3), (2, 48, 160, 5, 40, 3), (1, 32, 100, 6, 24, 5)])
 def test_conv2d_wgrad_split_bf16_pinned(emulated_kernels, shape, cfg):
     """wgrad3 configurations the autotuner explores on the GPU, pinned through pnsfm_tune_set: cfg = (pixel split, ci tiles per
-    wave NT, co tiles per workgroup WM) -- WM below the layer's maximum turns waves into extra pixel shares (LDS reduction)."""
+    wave NT, co tiles per workgroup WM; WM | 8 = the build whose register budget lets three workgroups share a CU) -- WM below the
+    layer's maximum turns waves into extra pixel shares (LDS reduction)."""
     import ctypes
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops

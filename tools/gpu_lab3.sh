@@ -79,7 +79,9 @@ pmc)
     (cd /tmp && PNSFM_TUNE_DB=$DB timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -o bench -- \
       python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-extra > $O/pmc_${TAG}_$n.log 2>&1)
     tail -1 $O/pmc_${TAG}_$n.log | cut -c1-200
-  done ;;
+  done
+  python tools/pmc_traffic.py $(find $O/pmc_${TAG}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_${TAG}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/traffic_$TAG.json $O/layers_$TAG.csv | head -8
+  python tools/pmc_mfma_busy.py $(find $O/pmc_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1) $O/mfma_busy_$TAG.json ;;
 esac
 echo "   [$w: $(( $(date +%s) - t0 )) s]"
 done

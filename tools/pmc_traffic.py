@@ -44,7 +44,7 @@ if layer_csv:
         by = 4.0 * (B * Cin * px + B * Cout * px + Cout * Cin * ks * ks)
         # which kernel family ran the launch: the split-bf16 kernels take >= 16 K-channels and k >= 3 (the autotuner may
         # still have preferred an f32 kernel for a few weight-gradient shapes, e.g. W = 20)
-        split = Cin >= 16 and ks >= 3 and (r['kind'] == '0' or Cout >= 16)
+        split = Cin >= 16 and (r['kind'] == '0' or Cout >= 16)       # (1x1 layers joined the split kernels in round 3)
         name = {('0', True): 'pnsfm::conv2d_bx3_kernel', ('0', False): 'pnsfm::conv2d_mfma_kernel',
                 ('1', True): 'pnsfm::conv2d_wgrad3_kernel', ('1', False): 'pnsfm::conv2d_wgrad_kernel'}[(r['kind'], split)]
         a = acc.setdefault(name, [0.0, 0])
@@ -53,11 +53,13 @@ if layer_csv:
     for name, a in acc.items():
         if name in res and a[1]:
             res[name]['algorithmic_bytes_per_launch'] = a[0] / a[1]
+res['workload_shape'] = [192, 640, 4]      # H, W, batch of the bench.py run the passes were collected on (bench.py only quotes
+                                           # these numbers for that workload)
 res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` with a '
                 'primed tuning database (PNSFM_TUNE_DB: every launch is a training-step launch, no autotune candidates); '
                 'bytes = counter*1024 averaged over the launches of each kernel; FETCH_SIZE is quoted raw (4-byte/lane loads are '
                 'not a calibrated access width on gfx950). algorithmic = (input + output + weight) bytes of the layer, averaged '
                 'over the launches of bench.py --layer-table.')
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
-for k, v in sorted(((k, v) for k, v in res.items() if isinstance(v, dict)), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_in_pass'])[:12]:
+for k, v in sorted(((k, v) for k, v in res.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_in_pass'])[:12]:
     print('%-40s launches %5d  fetch %8.2f MB  write %8.2f MB per launch' % (k, v['launches_in_pass'], v['fetch_bytes_per_launch'] / 1e6, v['write_bytes_per_launch'] / 1e6))

@@ -13,8 +13,10 @@
  *   - outputs and named workspaces are caller-allocated.  The ONE exception: the two-stage reductions (pixel-split weight
  *     gradients, the loss scalars) keep their partial sums in a grow-only scratch buffer the library hipMalloc's itself, one per
  *     (device, stream), outside the caller's allocator (csrc/api.hip: a few KB .. tens of MB; a buffer that has to grow is
- *     replaced and the old one freed once the stream has passed it; under hipGraph capture the scratch is a stream-ordered
- *     allocation that becomes memory nodes of the graph);
+ *     replaced and the old one freed once the stream has passed it).  Launches captured into a hipGraph use one of four
+ *     per-device capture buffers instead, sized by the largest un-captured request so far (run one warm-up step before
+ *     capturing, as torch's recipe does) and never moved afterwards; a request they cannot serve becomes a stream-ordered
+ *     allocation, i.e. memory nodes of the graph (PNSFM_CAPTURE_SCRATCH=0 forces that);
  *   - return value: 0 on success, non-zero on error (pnsfm_last_error() has the message).
  */
 #ifndef PNSFM_H

@@ -60,19 +60,66 @@ static void scratch_reap(int dev) {      // g_scratch_mu held
 }
 #endif
 
+// Captured launches cannot grow a buffer (hipMalloc is illegal during capture) and stream-ordered allocations would turn every
+// two-stage reduction into a pair of graph memory nodes (slow to replay, and replays of such graphs were seen to return
+// transiently wrong sums on ROCm 7.0).  Instead every device keeps kCapBufs capture buffers, grown EAGERLY to the largest
+// request any un-captured call has made on that device (frameworks run a warm-up step before they capture: torch's recipe does),
+// and handed out per capturing stream -- parallel branches of one capture (a side stream) get different buffers.  A buffer that
+// was ever handed to a capture is never freed or moved: graphs hold its address.  Requests that do not fit (no warm-up, more
+// than kCapBufs capturing streams) fall back to hipMallocAsync / hipFreeAsync.  PNSFM_CAPTURE_SCRATCH=0 forces that fallback.
+struct CapBuf { int dev; hipStream_t stream; bool used; void* p; size_t cap; };
+static constexpr int kCapBufs = 4;
+static std::vector<CapBuf> g_capbuf;
+#ifndef PNSFM_EMU
+static bool capbuf_enabled() {
+  static const bool on = [] { const char* e = getenv("PNSFM_CAPTURE_SCRATCH"); return !(e && e[0] == '0'); }();
+  return on;
+}
+static void capbuf_grow(int dev, size_t cap) {      // g_scratch_mu held, not capturing
+  if (!capbuf_enabled()) return;
+  int have = 0;
+  for (auto& c : g_capbuf)
+    if (c.dev == dev) {
+      ++have;
+      if (c.cap >= cap) continue;
+      void* p = nullptr;
+      if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (!c.used && c.p) (void)hipFree(c.p);      // a buffer some graph may address stays alive
+      c.p = p; c.cap = cap; c.used = false; c.stream = nullptr;
+    }
+  for (; have < kCapBufs; ++have) {
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    g_capbuf.push_back(CapBuf{dev, nullptr, false, p, cap});
+  }
+}
+static void* capbuf_get(int dev, hipStream_t stream, size_t bytes) {      // g_scratch_mu held
+  if (!capbuf_enabled()) return nullptr;
+  for (auto& c : g_capbuf)
+    if (c.dev == dev && c.used && c.stream == stream && c.cap >= bytes) return c.p;
+  for (auto& c : g_capbuf)
+    if (c.dev == dev && !c.used && c.cap >= bytes) { c.used = true; c.stream = stream; return c.p; }
+  return nullptr;
+}
+#endif
+
 void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
   *async_owned = false;
   int dev = 0;
 #ifndef PNSFM_EMU
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("scratch: hipGetDevice failed"); return nullptr; }
   if (stream_capturing(stream)) {
-    // hipGraph capture runs on a stream of its own and may not call hipMalloc: a stream-ordered allocation becomes a pair of
-    // memory nodes of the graph instead (the caller hands it back through scratch_release)
+    {
+      std::lock_guard<std::mutex> lk(g_scratch_mu);
+      if (void* p = capbuf_get(dev, stream, bytes)) return p;
+    }
+    // no capture buffer of that size: a stream-ordered allocation becomes a pair of memory nodes of the graph (the caller hands
+    // it back through scratch_release)
     void* p = nullptr;
     if (hipMallocAsync(&p, bytes, stream) != hipSuccess || !p) { set_error("cannot allocate %zu bytes of scratch (capture)", bytes); return nullptr; }
     *async_owned = true;
     return p;
   }
-  if (hipGetDevice(&dev) != hipSuccess) { set_error("scratch: hipGetDevice failed"); return nullptr; }
 #endif
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   Scratch* sc = nullptr;
@@ -96,6 +143,7 @@ void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
       else
         (void)hipGetLastError();        // cannot track it: keep it alive (a one-off, bounded by the growth steps)
     }
+    if (p) capbuf_grow(dev, cap);
 #endif
     if (!p) { set_error("cannot allocate %zu bytes of scratch", cap); return nullptr; }
     sc->p = p;

@@ -108,12 +108,16 @@ int pnsfm_get_conv_math(void);
  * f32 MFMA (dY fragments kept in registers across the taps, LDS-DMA double buffering; conv2d_wgrad2.hip; stride 1,
  * k in {1,3,5}, W % 8 == 0, >= 16 channels), 2 = split-bf16 arithmetic (conv2d_wgrad3.hip: one kernel row per workgroup, dY
  * straight from global memory, shifted X operands built in registers; stride 1, W % 4 == 0, >= 16 channels; only under
- * pnsfm_set_conv_math(1)), -1 = library default (2 where it applies, else 0).  The autotuner times all that apply.  For tests. */
+ * pnsfm_set_conv_math(1)), -1 = library default (2 where it applies, else 0).  The autotuner times all that apply, and for 3x3
+ * layers also kernel 3 (conv2d_wgrad4.hip: all nine taps per workgroup on v_mfma_f32_16x16x32_bf16, tiles 3 / 4 / 5 pixel groups
+ * wide so that W = 20 / 40 / 80 fit; same arithmetic, same two-stage reduction), which is reachable through the tuning database /
+ * pnsfm_tune_set only.  For tests. */
 int pnsfm_set_wgrad_variant(int tap_major);
 /* Programmatic entry of the tuning database (what a PNSFM_TUNE_DB line does): key7 = {kind, B, Cin, Cout, H, W, ks} with
  * kind = 0 forward / 1 backward-data / 2 backward-weight, + 10 * stride; for kind 2 the key holds H*W in place of H and the
  * tiling width in place of W (32 for a 1x1 convolution).  forward / backward-data (+ 100 on `kind` for the split-bf16 arithmetic): v0 = NT | variant << 4 | narrow-M << 8,
- * v1 = K-split; backward-weight: v0 = pixel split, v1 = kernel (0 generic, 1 tap-major).  Used by the determinism sweep
+ * v1 = K-split; backward-weight: v0 = pixel split, v1 = kernel (0 generic, 1 tap-major, 2 | NT << 4 | WM << 6 split-bf16 one
+ * kernel row per workgroup, 3 | (WCI | TG << 4 | TR << 8) << 4 split-bf16 nine taps per workgroup).  Used by the determinism sweep
  * (tools/conv_config_sweep.py), which checks EVERY configuration the autotuner may pick against the oracle's convolution. */
 int pnsfm_tune_set(const int* key7, int v0, int v1);
 /* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and

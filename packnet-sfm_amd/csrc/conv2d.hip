@@ -1485,6 +1485,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   int split2 = v2_ok ? v2_default_split() : 1;
   int nt3 = wgrad3_nt2_ok(Cin, ks) ? 2 : 1, wm3 = 0;
   int split3 = v3_ok ? v3_default_split(nt3) : 1;
+  // nine-taps kernel (conv2d_wgrad4.hip): 3x3 only; chosen by the autotuner / a pinned decision (variant 3)
+  const bool v4_ok = v3_ok && ks == 3 && wgrad4_supported(Cin, Cout, H0, W0, ks);
+  int split4 = 1, cfg4 = 2;
   if (v3_ok && g_wgrad_variant != 0 && g_wgrad_variant != 1) variant = 2;     // -1 (library default) or 2 (pinned)
   if (ms) {          // several input tensors (ConvSrc): only the split-bf16 kernel reads them
     if (!v3_ok) { set_error("backward_weight: several input tensors need the split-bf16 weight-gradient kernel"); return -1; }
@@ -1555,14 +1558,36 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
             }
           }
       }
+      if (v4_ok) {     // nine-taps kernel: ci tiles per workgroup x tile width x pixel splits around two workgroups per CU
+        for (int WCI = 1; WCI <= 2; ++WCI)
+          for (int tgi = 0; tgi < (W0 > 24 ? 2 : 1); ++tgi) {
+            const int TG = W0 > 24 ? 4 + tgi : 3, TR = wgrad4_TR(H0, 0);
+            if (W0 > 24 && round_up(W0, 8 * TG) > round_up(W0, 8 * (9 - TG)) + 8) continue;      // clearly the more wasteful width
+            const int tiles4 = wgrad4_total_tiles(B, H0, W0, TG, TR), base4 = wgrad4_base_blocks(Cin, Cout, WCI);
+            const int cfg = WCI | (TG << 4) | (TR << 8);
+            int prev = -1;
+            for (int want = 1; want <= tiles4; want = want < 4 ? want + 1 : (want * 3 + 1) / 2) {
+              const int tps = ceil_div(tiles4, want);
+              const int split = ceil_div(tiles4, tps);
+              if (split == prev) continue;
+              prev = split;
+              if ((long)base4 * split < 200 && split < tiles4) continue;      // cannot fill the chip
+              if ((long)base4 * split > 16L * 256 && split > 1) break;
+              const float tms = time_on_stream(s, 2, [&]() { return enqueue_wgrad4(x, dy, dw, dbias, B, Cin, Cout, H0, W0, split, cfg, s, ms); });
+              tune_log(2, key, 3 | (cfg << 4), split, tms);
+              if (tms > 0.f && tms < best_ms) { best_ms = tms; best_split = split; best_variant = 3 | (cfg << 4); }
+            }
+          }
+      }
       dec = &g_tuned.emplace(key, std::array<int, 2>{best_split, best_variant}).first->second;
       tune_db_append(key, *dec);
     }
 #endif
     if (dec) {
       const int d0 = (*dec)[0], d1 = (*dec)[1];
-      variant = ((d1 & 15) == 1 && v2_ok) ? 1 : (((d1 & 15) == 2 && v3_ok) ? 2 : 0);
-      if (ms) variant = 2;
+      variant = ((d1 & 15) == 1 && v2_ok) ? 1 : (((d1 & 15) == 2 && v3_ok) ? 2 : (((d1 & 15) == 3 && v4_ok) ? 3 : 0));
+      if (ms && variant != 3) variant = 2;
+      if (variant == 3) { split4 = d0; cfg4 = d1 >> 4; }
       if (variant == 2 && (d1 & 15) != 2) { /* a pinned decision for another kernel: keep the split-bf16 defaults */ }
       else if (variant == 2) { split3 = d0; nt3 = ((d1 >> 4) & 3) == 2 ? 2 : 1; wm3 = (d1 >> 6) & 15; }
       else if (variant == 1) split2 = d0;
@@ -1576,6 +1601,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     }
   }
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
+  if (variant == 3) {
+    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split4, wgrad4_base_blocks(Cin, Cout, (cfg4 & 15) == 1 ? 1 : 2) * split4};
+    prof_begin(1, flops, s, meta);
+    const int rc = enqueue_wgrad4(x, dy, dw, dbias, B, Cin, Cout, H0, W0, split4, cfg4, s, ms);
+    prof_end(1, s);
+    return rc;
+  }
   if (variant == 2) {
     const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3};
     prof_begin(1, flops, s, meta);

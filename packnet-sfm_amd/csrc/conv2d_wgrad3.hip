@@ -404,6 +404,14 @@ __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restr
   }
 }
 
+// the second stage on its own (conv2d_wgrad4.hip writes the same partial-tensor layout)
+int launch_wgrad3_reduce(const float* ws, const float* ws_bias, float* dw, float* dbias, int Z, int KS, int COP, int CIP, int Cin,
+                         int Cout, hipStream_t s) {
+  PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 128)), dim3(256), 0, s, ws, ws_bias, dw, dbias, Z, KS, COP, CIP, Cin,
+               Cout);
+  return check_launch("conv2d_backward_weight (split-bf16, reduction)");
+}
+
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks) {
   if (ks != 1 && ks != 3 && ks != 5 && ks != 7) return false;
   return W % 4 == 0 && Cin >= 16 && Cout >= 16 && H >= 1;      // rows of 4-pixel groups (16-byte aligned)
@@ -512,11 +520,7 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
 #undef PNSFM_W3T
 #undef PNSFM_W3
   if (a.ws) {
-    if (!rc) {
-      PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 128)), dim3(256), 0, s, (const float*)a.ws, (const float*)a.ws_bias,
-                   dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout);
-      rc = check_launch("conv2d_backward_weight (split-bf16, reduction)");
-    }
+    if (!rc) rc = launch_wgrad3_reduce(a.ws, a.ws_bias, dw, dbias, splitP, ks, a.COP, a.CIP, Cin, Cout, s);
   }
   return rc;
 }

@@ -15,6 +15,8 @@ typedef hipemu::f32x16 f32x16;
 static inline f32x16 pnsfm_mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
 typedef hipemu::u32x4 pnsfm_u32x4;
 static inline f32x16 pnsfm_mfma_bf16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x16 c) { return hipemu::mfma_f32_32x32x16_bf16(a, b, c); }
+typedef hipemu::f32x4 f32x4;
+static inline f32x4 pnsfm_mfma_bf16_16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x4 c) { return hipemu::mfma_f32_16x16x32_bf16(a, b, c); }
 static inline unsigned pnsfm_f2u(float v) { unsigned u; memcpy(&u, &v, 4); return u; }
 static inline float pnsfm_u2f(unsigned u) { float v; memcpy(&v, &u, 4); return v; }
 // v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even), `lo` in bits [0,16), `hi` in bits [16,32)
@@ -73,6 +75,12 @@ typedef unsigned pnsfm_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 pnsfm_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 pnsfm_mfma_bf16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pnsfm_bf16x8, a), __builtin_bit_cast(pnsfm_bf16x8, b), c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_bf16: D(16x16) += A(16x32) * B(32x16): lane l holds A[m = l&15][k = 8*(l>>4) + i], B[k = 8*(l>>4) + i][n = l&15]
+// and D[row = 4*(l>>4) + r][col = l&15]; 16 cycles/SIMD (4 passes): the same MAC rate with a quarter of the accumulator registers.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pnsfm_mfma_bf16_16(pnsfm_u32x4 a, pnsfm_u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pnsfm_bf16x8, a), __builtin_bit_cast(pnsfm_bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ unsigned pnsfm_f2u(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ float pnsfm_u2f(unsigned u) { return __uint_as_float(u); }
@@ -220,6 +228,16 @@ int wgrad3_WM(int Cout, int want);          // co tiles per workgroup (want: 0 =
 int wgrad3_base_blocks(int Cin, int Cout, int ks, int NT, int WM);
 int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
                    int split, int NT, int WM, hipStream_t stream, const ConvSrc* ms = nullptr);
+
+// nine-taps-per-workgroup 3x3 weight gradient on the 16x16x32 MFMA (conv2d_wgrad4.hip).  cfg = WCI (ci tiles of 16 channels per
+// workgroup: 1 | 2) | TG << 4 (tile width in 8-pixel groups, 0 = library choice) | TR << 8 (tile rows, 0 = library choice)
+bool wgrad4_supported(int Cin, int Cout, int H, int W, int ks);
+int wgrad4_TG(int W, int want);
+int wgrad4_TR(int H, int want);
+int wgrad4_total_tiles(int B, int H, int W, int TG, int TR);
+int wgrad4_base_blocks(int Cin, int Cout, int WCI);
+int enqueue_wgrad4(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int split,
+                   int cfg, hipStream_t stream, const ConvSrc* ms = nullptr);
 
 // more than 64 KB of dynamic LDS needs hipFuncSetAttribute once per kernel AND device: `mask` (one static per kernel
 // instantiation) remembers the devices already done (api.hip).  0 on success.

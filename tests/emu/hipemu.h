@@ -154,6 +154,31 @@ inline f32x16 mfma_f32_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[m = l&15][k = 8*(l>>4) + i] and B[k = 8*(l>>4) + i][n = l&15], i = 0..7 (packed as
+// above); lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3.  Summed in double and rounded once, like the 32x32 model.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+inline f32x4 mfma_f32_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  WaveState& W = my_wave();
+  int l = my_lane();
+  for (int i = 0; i < 8; ++i) {
+    unsigned ua = (i & 1) ? (a[i >> 1] & 0xffff0000u) : (a[i >> 1] << 16);
+    unsigned ub = (i & 1) ? (b[i >> 1] & 0xffff0000u) : (b[i >> 1] << 16);
+    memcpy(&W.a8[l][i], &ua, 4);
+    memcpy(&W.b8[l][i], &ub, 4);
+  }
+  wave_barrier(W);
+  int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = 4 * (l >> 4) + r;
+    double acc = c[r];
+    for (int h = 0; h < 4; ++h)
+      for (int i = 0; i < 8; ++i) acc += (double)W.a8[row + 16 * h][i] * (double)W.b8[col + 16 * h][i];
+    c[r] = (float)acc;
+  }
+  wave_barrier(W);
+  return c;
+}
+
 template <class T>
 inline T shfl_generic(T v, int src_lane) {
   WaveState& W = my_wave();

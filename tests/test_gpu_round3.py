@@ -88,6 +88,48 @@ def test_conv2d_wgrad3_error_vs_fp64_real_K(shape):
     assert err['bx3'][1] <= max(2.0 * err['f32'][1], 1.5e-7), err
 
 
+@pytest.mark.parametrize('cfg', [(0, 1), (0, 2), (5, 2)])
+@pytest.mark.parametrize('shape', [sh for sh in WGRAD_REAL_SHAPES if sh[5] == 3] + [(4, 512, 512, 12, 40, 3), (4, 64, 64, 96, 320, 3)])
+def test_conv2d_wgrad_nine_taps_error_vs_fp64_real_K(shape, cfg):
+    """The nine-taps 3x3 weight gradient (csrc/conv2d_wgrad4.hip, 16x16x32 MFMA) at the training step's reduction lengths: same
+    fp64 error bound as the one-row kernel, and the two kernels agree to fp32 round-off.  cfg = (tile width in groups, ci tiles
+    per workgroup); the pixel split is the one two workgroups per CU ask for."""
+    import ctypes
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    TG, WCI = cfg
+    if W <= 24:
+        TG = 0
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = (torch.randn(B, Cin, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, Cin, 1, 1, generator=g))).to(DEV)
+    dy = (torch.randn(B, Cout, H, W, generator=g) * torch.exp(0.5 * torch.randn(B, Cout, 1, 1, generator=g))).to(DEV)
+    dw64, mag = _wgrad_fp64(x, dy, ks)
+    db64 = dy.double().sum((0, 2, 3))
+    dbmag = dy.double().abs().sum((0, 2, 3))
+    HF.set_conv_math('bx3')
+    base = -(-Cin // (16 * WCI)) * -(-Cout // (32 * (4 // WCI)))
+    split = max(1, 512 // base)
+    key = (ctypes.c_int * 7)(2 + 10 + 100, B, Cin, Cout, H * W, W, ks)
+    lib.pnsfm_set_autotune(0)
+    try:
+        lib.pnsfm_set_wgrad_variant(2)
+        dw3, db3 = ops.conv2d_backward_weight(x, dy, ks)
+        lib.pnsfm_set_wgrad_variant(-1)
+        assert lib.pnsfm_tune_set(key, split, 3 | ((WCI | (TG << 4)) << 4)) == 0
+        dw, db = ops.conv2d_backward_weight(x, dy, ks)
+    finally:
+        lib.pnsfm_set_wgrad_variant(-1)
+        lib.pnsfm_set_autotune(1)
+    e9 = float(((dw.double() - dw64).abs() / mag).max())
+    e3 = float(((dw3.double() - dw64).abs() / mag).max())
+    eb = float(((db.double() - db64).abs() / dbmag).max())
+    print('wgrad %s cfg %s split %d  max|err|/sum|dy||x|: nine taps %.2e (dbias %.2e)  one row %.2e' % (shape, cfg, split, e9, eb, e3))
+    assert e9 <= max(2.0 * e3, 1.5e-7) and e9 <= 16 * 2.0 ** -24
+    assert eb <= 1.5e-7
+    assert float(((dw - dw3).abs() / mag.float()).max()) <= max(e9 + e3, 3e-7) * 1.05      # each within its own error of fp64
+
+
 # ------------------------------------------------------------------------ (b) FlatAdam, gradients produced inside the arena
 class _BlockStack(torch.nn.Module):
     """Conv2D -> ResidualConv -> PackLayerConv3d (collapsed form) -> UnpackLayerConv3d -> Conv2D: every kind of conv weight the

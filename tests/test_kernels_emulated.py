@@ -259,6 +259,42 @@ def test_conv2d_wgrad_split_bf16_pinned(emulated_kernels, shape, cfg):
     lib.pnsfm_set_wgrad_variant(-1)      # clears the pinned entry
 
 
+@pytest.mark.parametrize('cfg', [(1, 1, 0, 0), (1, 2, 0, 0), (2, 2, 4, 0), (3, 1, 5, 0), (2, 2, 5, 0), (2, 1, 0, 6), (5, 2, 0, 4)])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 8, 32, 3), (2, 48, 70, 5, 40, 3), (2, 40, 24, 6, 20, 3), (1, 33, 129, 7, 80, 3),
+                                   (1, 16, 32, 9, 4, 3), (1, 130, 20, 9, 8, 3)])
+def test_conv2d_wgrad_nine_taps(emulated_kernels, shape, cfg):
+    """The nine-taps-per-workgroup 3x3 weight gradient on the 16x16x32 MFMA (csrc/conv2d_wgrad4.hip) vs torch, pinned through
+    pnsfm_tune_set (variant 3): cfg = (pixel split, ci tiles per workgroup, tile width in 8-pixel groups, tile rows; 0 = the
+    library's choice).  Widths of 3 / 4 / 5 groups incl. ragged last tiles (W = 80 with 32-column tiles), W % 8 == 4 (masked half
+    groups: 20, 4), one-group images, 6-row tiles whose last k-step is partly empty, heights that do not fill the tile rows,
+    odd channel counts, direct stores (one split) and the two-stage reduction."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_conv_math(1)
+    split, WCI, TG, TR = cfg
+    B, Cin, Cout, H, W, ks = shape
+    if W <= 24:
+        TG = 0                      # narrow images have one legal width (3 groups)
+    elif TR == 6:
+        TR = 0                      # 6-row tiles exist for 3-group tiles only
+    key = (ctypes.c_int * 7)(2 + 10 + 100, B, Cin, Cout, H * W, W, ks)
+    assert lib.pnsfm_tune_set(key, split, 3 | ((WCI | (TG << 4) | (TR << 8)) << 4)) == 0
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dw, db = ops.conv2d_backward_weight(x, dy, ks)
+    P.check(dw, wr.grad, 1e-5, 'wgrad (nine taps)')
+    P.check(db, br.grad, 1e-5, 'dbias (nine taps)')
+    lib.pnsfm_set_wgrad_variant(-1)      # clears the pinned entry
+
+
 @pytest.mark.parametrize('nf', [8, 4])
 @pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3)])
 def test_conv3d_raw(emulated_kernels, shape, nf):

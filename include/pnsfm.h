@@ -44,6 +44,18 @@ size_t pnsfm_conv2d_packed_elems_fwd(int Cin, int Cout, int ks);
 size_t pnsfm_conv2d_packed_elems_bwd(int Cin, int Cout, int ks);
 int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd /*nullable*/, float* wp_bwd /*nullable*/,
                               int Cin, int Cout, int ks, void* stream);
+/* Many weights in ONE launch (a model's conv layers right after the optimizer step; replaces ~100 per-layer launches of ~10 us
+ * each).  The caller keeps a table of pnsfm_conv2d_pack_item_bytes()-sized items in DEVICE memory: each item is written on the
+ * host by pnsfm_conv2d_pack_item_fill (w: [Cout][Cin][k][k]; wp_fwd / wp_bwd sized by pnsfm_conv2d_packed_elems_*; first_block =
+ * sum of the block counts of the items before it), which returns the item's block count -- 0 if the shape does not take the
+ * split-bf16 layout in both directions (leave it to pnsfm_conv2d_pack_weights; nothing is written), < 0 on error -- and then
+ * copied to the device by the caller.  pnsfm_conv2d_pack_table packs all of them; pointers must stay valid while the table is
+ * in use.  Mirrors nothing in the reference (cuDNN keeps its own filter layouts); replaces packnet_sfm/hip/functional.py's
+ * lazy per-layer repack for optimizers that update parameters in place. */
+size_t pnsfm_conv2d_pack_item_bytes(void);
+int pnsfm_conv2d_pack_item_fill(void* item_host, const float* w, float* wp_fwd, float* wp_bwd, int Cin, int Cout, int ks,
+                                int first_block);
+int pnsfm_conv2d_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream);
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias /*nullable*/, float* y,
                          int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,

@@ -17,6 +17,7 @@
 //     count cannot fill 256 CUs (pack4/pack5: 480 pixels, K = 147456); partial sums meet with fp32 atomics.
 // Roofline: MFMA-bound. 2*Cout*Cin*k*k*B*H*W flop per launch against the 157.3 TFLOP/s fp32 matrix peak.
 #include "pnsfm_common.h"
+#include <cstring>
 #include "../../include/pnsfm.h"
 
 #include <array>
@@ -1341,6 +1342,36 @@ int pnsfm_conv2d_pack_weights(const float* w, float* wp_fwd, float* wp_bwd, int 
     else PNSFM_LAUNCH((pack_bx3_kernel<7>), dim3(nf + nb), dim3(256), 0, s, w, pf, pb, Cin, Cout, nchF, nchB, nf);
   }
   return check_launch("pack_weights");
+}
+
+size_t pnsfm_conv2d_pack_item_bytes(void) { return sizeof(PackItem); }
+
+int pnsfm_conv2d_pack_item_fill(void* item_host, const float* w, float* wp_fwd, float* wp_bwd, int Cin, int Cout, int ks,
+                                int first_block) {
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("pack_item_fill: unsupported kernel size %d", ks); return -1; }
+  if (!item_host || !w || !wp_fwd || !wp_bwd) { set_error("pack_item_fill: null pointer"); return -1; }
+  // only weights whose BOTH directions run the split-bf16 kernels go through the table (the others keep the per-layer call)
+  if (!conv_use_bx3(Cin, ks) || !conv_use_bx3(Cout, ks)) return 0;
+  const int KPf = conv_pack_KP(Cin), MPf = conv_pack_MP(Cout), KPb = conv_pack_KP(Cout), MPb = conv_pack_MP(Cin);
+  PackItem it;
+  it.w = w;
+  it.pf = reinterpret_cast<unsigned char*>(wp_fwd);
+  it.pb = reinterpret_cast<unsigned char*>(wp_bwd);
+  it.Cin = Cin; it.Cout = Cout; it.ks = ks;
+  it.nchF = KPf / 16; it.nchB = KPb / 16;
+  it.nf = (MPf / 32) * it.nchF;
+  it.blk0 = first_block;
+  it.nblk = it.nf + (MPb / 32) * it.nchB;
+  memcpy(item_host, &it, sizeof(it));
+  return it.nblk;
+}
+
+int pnsfm_conv2d_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream) {
+  if (n_items <= 0 || total_blocks <= 0) return 0;
+  if (!table_dev) { set_error("pack_table: null table"); return -1; }
+  PNSFM_LAUNCH(pack_bx3_table_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const PackItem*>(table_dev), n_items);
+  return check_launch("pack_table");
 }
 
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin, int Cout,

@@ -362,12 +362,10 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 // 5x5 / 7x7 -- so that global reads are runs of (channel, tap) and every output tap is written as one contiguous 3072-byte
 // slab.  KS is a template parameter: the index arithmetic of the copy loops divides by compile-time constants only.
 template <int KS>
-__global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
-                                                       unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int nchF,
-                                                       int nchB, int nf) {
+__device__ __forceinline__ void pack_bx3_block(float (*tile)[16][33], const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
+                                               unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int nchF, int nchB, int nf,
+                                               int blk) {
   constexpr int KK = KS * KS, TSEG = (KS == 3) ? 9 : KS;
-  __shared__ float tile[TSEG][16][33];
-  int blk = blockIdx.x;
   const bool fwd = blk < nf;
   if (!fwd) blk -= nf;
   const int nch = fwd ? nchF : nchB;
@@ -408,4 +406,37 @@ __global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__
     }
     __syncthreads();
   }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) pack_bx3_kernel(const float* __restrict__ w, unsigned char* __restrict__ wp_fwd,
+                                                       unsigned char* __restrict__ wp_bwd, int Cin, int Cout, int nchF,
+                                                       int nchB, int nf) {
+  __shared__ float tile[(KS == 3) ? 9 : KS][16][33];
+  pack_bx3_block<KS>(tile, w, wp_fwd, wp_bwd, Cin, Cout, nchF, nchB, nf, (int)blockIdx.x);
+}
+
+// One launch for MANY weights (every conv layer of a model right after the optimizer step): a device-resident table of
+// {weight, packed buffers, geometry, first block}, a binary search per workgroup.  The ~100 per-layer launches this replaces cost
+// ~10 us each whatever their size (two dependent memory round trips behind a launch).
+struct PackItem {
+  const float* w;
+  unsigned char* pf;
+  unsigned char* pb;
+  int Cin, Cout, ks, nchF, nchB, nf, blk0, nblk;
+};
+__global__ void __launch_bounds__(256) pack_bx3_table_kernel(const PackItem* __restrict__ tab, int n) {
+  __shared__ float tile[9][16][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackItem it = tab[lo];
+  const int blk = (int)blockIdx.x - it.blk0;
+  if (blk >= it.nblk) return;
+  if (it.ks == 3) pack_bx3_block<3>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
+  else if (it.ks == 1) pack_bx3_block<1>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
+  else if (it.ks == 5) pack_bx3_block<5>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
+  else pack_bx3_block<7>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
 }

@@ -49,6 +49,46 @@ __global__ void __launch_bounds__(256) d2s_kernel(const float* __restrict__ x, f
   }
 }
 
+// 16-byte forms of the two shuffles (W % 8 == 0 / 4, 16-byte aligned tensors): 126 MB each way at full resolution, so they are
+// written as streaming copies -- one thread moves a 2 x 8 input block (s2d) / four 4-wide channel rows (d2s) with float4
+// accesses and 32-bit index arithmetic (the per-element forms above spend their time in 64-bit divisions: 2.9 TB/s).
+__global__ void __launch_bounds__(256) s2d_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                                                      unsigned total_q, size_t x_batch_stride) {
+  const unsigned h2 = H >> 1, wqn = W >> 3;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total_q) return;
+  const unsigned wq = idx % wqn, r = idx / wqn;
+  const unsigned h = r % h2, bc = r / h2;
+  const unsigned c = bc % (unsigned)C, b = bc / (unsigned)C;
+  const float* src = x + (size_t)b * x_batch_stride + ((size_t)c * H + 2 * h) * W + 8 * wq;
+  const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(src + W), b1 = *reinterpret_cast<const float4*>(src + W + 4);
+  const size_t plane = (size_t)h2 * (W >> 1);
+  float* dst = y + (((size_t)b * 4 * C + 4 * c) * h2 + h) * (W >> 1) + 4 * wq;
+  *reinterpret_cast<float4*>(dst) = make_float4(a0.x, a0.z, a1.x, a1.z);                 // i = 0, j = 0
+  *reinterpret_cast<float4*>(dst + plane) = make_float4(a0.y, a0.w, a1.y, a1.w);         // i = 0, j = 1
+  *reinterpret_cast<float4*>(dst + 2 * plane) = make_float4(b0.x, b0.z, b1.x, b1.z);     // i = 1, j = 0
+  *reinterpret_cast<float4*>(dst + 3 * plane) = make_float4(b0.y, b0.w, b1.y, b1.w);     // i = 1, j = 1
+}
+
+__global__ void __launch_bounds__(256) d2s_v4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                                                      unsigned total_q) {
+  const unsigned wqn = W >> 2;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total_q) return;
+  const unsigned wq = idx % wqn, r = idx / wqn;
+  const unsigned h = r % (unsigned)H, bc = r / (unsigned)H;       // bc = b * C + c
+  const size_t plane = (size_t)H * W;
+  const float* src = x + ((size_t)bc * 4 * H + h) * W + 4 * wq;
+  const float4 p00 = *reinterpret_cast<const float4*>(src), p01 = *reinterpret_cast<const float4*>(src + plane);
+  const float4 p10 = *reinterpret_cast<const float4*>(src + 2 * plane), p11 = *reinterpret_cast<const float4*>(src + 3 * plane);
+  float* dst = y + ((size_t)bc * 2 * H + 2 * h) * (2 * W) + 8 * wq;
+  *reinterpret_cast<float4*>(dst) = make_float4(p00.x, p01.x, p00.y, p01.y);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(p00.z, p01.z, p00.w, p01.w);
+  *reinterpret_cast<float4*>(dst + 2 * W) = make_float4(p10.x, p11.x, p10.y, p11.y);
+  *reinterpret_cast<float4*>(dst + 2 * W + 4) = make_float4(p10.z, p11.z, p10.w, p11.w);
+}
+
 // out[b][f*D+d][y][x] = b3[f] + sum_{dz,dy,dx} w3[f][dz][dy][dx] * p[b][d+dz-1][y+dy-1][x+dx-1]
 // grid: (ceil(D*HW/256), 1, B): one thread per voxel (d, y, x) -- flattened so that small planes (the 7x7 / 5x5 weight
 // volumes of the kernel composition, or 6x20 feature maps) still fill every lane -- produces all 8 features;
@@ -294,7 +334,13 @@ int pnsfm_space_to_depth_strided(const float* x, float* y, int B, int C, int H, 
   if ((H & 1) || (W & 1)) { set_error("space_to_depth: H, W must be even (got %d x %d)", H, W); return -1; }
   if (x_batch_stride < (size_t)C * H * W) { set_error("space_to_depth: batch stride smaller than one image"); return -1; }
   const size_t total = (size_t)B * C * H * W;
-  PNSFM_LAUNCH(s2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total, x_batch_stride);
+  const bool al16 = (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && x_batch_stride % 4 == 0;
+  if (W % 8 == 0 && al16 && total / 16 < (1ull << 31)) {
+    const unsigned total_q = (unsigned)(total / 16);      // one thread per 2 x 8 input block
+    PNSFM_LAUNCH(s2d_v4_kernel, dim3((total_q + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total_q, x_batch_stride);
+  } else {
+    PNSFM_LAUNCH(s2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total, x_batch_stride);
+  }
   return check_launch("space_to_depth");
 }
 
@@ -304,7 +350,12 @@ int pnsfm_space_to_depth(const float* x, float* y, int B, int C, int H, int W, v
 
 int pnsfm_depth_to_space(const float* x, float* y, int B, int C, int H, int W, void* stream) {
   const size_t total = (size_t)B * C * 4 * H * W;
-  PNSFM_LAUNCH(d2s_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total);
+  if (W % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && total / 16 < (1ull << 31)) {
+    const unsigned total_q = (unsigned)(total / 16);      // one thread per four 4-wide channel rows
+    PNSFM_LAUNCH(d2s_v4_kernel, dim3((total_q + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total_q);
+  } else {
+    PNSFM_LAUNCH(d2s_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, total);
+  }
   return check_launch("depth_to_space");
 }
 

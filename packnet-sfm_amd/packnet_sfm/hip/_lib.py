@@ -26,6 +26,9 @@ SIGNATURES = {
     "pnsfm_conv2d_packed_elems_fwd": (_sz, [_i, _i, _i]),
     "pnsfm_conv2d_packed_elems_bwd": (_sz, [_i, _i, _i]),
     "pnsfm_conv2d_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_conv2d_pack_item_bytes": (_sz, []),
+    "pnsfm_conv2d_pack_item_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
+    "pnsfm_conv2d_pack_table": (_i, [_p, _i, _i, _p]),
     "pnsfm_conv2d_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

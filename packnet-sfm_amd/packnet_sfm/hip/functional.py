@@ -63,6 +63,7 @@ class PackedConvWeight:
         self.key_bwd = None
         self.volatile = volatile      # weight is a freshly computed tensor every call (e.g. a composed kernel): always repack
         self._serial = 0
+        self._weight_ref = None       # the parameter this cache last packed (repack_all re-packs it in the batched launch)
 
     def get(self, weight, need_bwd):
         if self.volatile:
@@ -84,7 +85,71 @@ class PackedConvWeight:
                 self.wp_fwd, self.key_fwd = f, key
             if do_b:
                 self.wp_bwd, self.key_bwd = b, key
+            if not self.volatile and weight.is_leaf and weight.requires_grad:
+                _register_packed(self, weight)
         return self.wp_fwd, (self.wp_bwd if need_bwd else None)
+
+    @staticmethod
+    def key_of(weight):
+        return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
+
+
+# ---- batched re-pack: every conv weight of the model in ONE launch, right after the optimizer step ----------------------------
+# The lazy re-pack in front of each conv is ~100 launches of ~10 us per step (profiles/r03_*: 0.55 ms of the 0.83 ms the packers
+# take are per-launch floor, not bytes).  Caches register the LEAF parameter they pack; repack_all() -- called by FlatAdam.step
+# -- rebuilds the device table when the set of (parameter, buffers) changed, runs pnsfm_conv2d_pack_table and stamps the caches
+# with the new key, so the next forward finds them fresh.  PNSFM_PACK_BATCH=0 keeps the lazy path only.
+_PACK_REG = {}          # id(cache) -> (weakref(cache), weakref(parameter))
+_PACK_TABLES = {}       # device -> [signature, table tensor, n items, blocks, [(cache ref, parameter ref)] covered]
+
+
+def _register_packed(cache, weight):
+    import weakref
+    ent = _PACK_REG.get(id(cache))
+    if ent is not None and ent[0]() is cache and ent[1]() is weight:
+        return
+    cid = id(cache)
+    _PACK_REG[cid] = (weakref.ref(cache, lambda r, cid=cid: _PACK_REG.pop(cid, None)), weakref.ref(weight))
+    cache._weight_ref = _PACK_REG[cid][1]
+
+
+def repack_all():
+    """Re-pack every registered conv weight whose forward AND backward-data buffers exist, one launch per device.  Returns the
+    number of weights packed.  No-op under PNSFM_PACK_BATCH=0 and while a stream is being captured."""
+    import os
+    if os.environ.get('PNSFM_PACK_BATCH', '1') == '0' or not _PACK_REG:
+        return 0
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return 0
+    by_dev = {}
+    for cref, wref in list(_PACK_REG.values()):
+        c, w = cref(), wref()
+        if c is None or w is None or c.wp_fwd is None or c.wp_bwd is None or c.wp_fwd.device != w.device:
+            continue
+        by_dev.setdefault(w.device, []).append((c, w))
+    done = 0
+    for dev, pairs in by_dev.items():
+        sig = tuple((w.data_ptr(), tuple(w.shape), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
+        tab = _PACK_TABLES.get(dev)
+        if tab is None or tab[0] != sig:
+            table, n, blocks, covered = ops.conv2d_pack_table_build([(w.detach(), c.wp_fwd, c.wp_bwd) for c, w in pairs], dev)
+            tab = _PACK_TABLES[dev] = [sig, table, n, blocks, [pairs[i] for i in covered]]
+        if not tab[2]:
+            continue
+        with torch.cuda.device(dev) if dev.type == 'cuda' else _nullctx():
+            ops.conv2d_pack_table_run(tab[1], tab[2], tab[3])
+        for c, w in tab[4]:
+            c.key_fwd = c.key_bwd = PackedConvWeight.key_of(w)
+        done += len(tab[4])
+    return done
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class _WgradStream:

@@ -66,6 +66,34 @@ def conv2d_pack(w, wp_fwd=None, wp_bwd=None, want_fwd=True, want_bwd=True):
     return wp_fwd, wp_bwd
 
 
+def conv2d_pack_table_build(entries, device):
+    """entries: [(w, wp_fwd, wp_bwd)] with w [Cout, Cin, k, k] and packed buffers of conv2d_packed_sizes().  Returns
+    (table tensor on `device`, number of items, total blocks, indices of the entries the table covers) -- entries whose shape
+    does not take the split-bf16 layout in both directions are left out (pack them with conv2d_pack)."""
+    import ctypes
+    lib = _lib.get()
+    isz = int(lib.pnsfm_conv2d_pack_item_bytes())
+    host = (ctypes.c_ubyte * (isz * max(1, len(entries))))()
+    n, blocks, covered = 0, 0, []
+    for i, (w, pf, pb) in enumerate(entries):
+        _chk(w, pf, pb); _f32(w, pf, pb)
+        Cout, Cin, ks, _ = w.shape
+        rc = lib.pnsfm_conv2d_pack_item_fill(ctypes.addressof(host) + n * isz, _ptr(w), _ptr(pf), _ptr(pb), Cin, Cout, ks, blocks)
+        if rc < 0:
+            _lib.check(rc, "conv2d_pack_item_fill")
+        if rc > 0:
+            n += 1
+            blocks += rc
+            covered.append(i)
+    table = torch.frombuffer(bytearray(bytes(host)[:max(1, n) * isz]), dtype=torch.uint8).to(device)
+    return table, n, blocks, covered
+
+
+def conv2d_pack_table_run(table, n, blocks):
+    if n:
+        _lib.check(_lib.get().pnsfm_conv2d_pack_table(_ptr(table), n, blocks, _stream(table)), "conv2d_pack_table")
+
+
 def conv2d_forward(x, wp_fwd, bias, Cout, ks):
     _chk(x, wp_fwd, bias); _f32(x, wp_fwd, bias)
     B, Cin, H, W = x.shape

@@ -159,7 +159,8 @@ class FlatAdam:
             ops.adam_flat_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['_hp'])
             if keep is not None:
                 torch._foreach_copy_(keep[0], keep[1])
-        HF.bump_weight_epoch()      # parameters changed through raw pointers: invalidate packed conv weights
+        HF.bump_weight_epoch()      # parameters changed through raw pointers: invalidate packed conv weights ...
+        HF.repack_all()             # ... and re-pack all of them in one launch (hip/functional.py; the lazy path covers the rest)
         return loss
 
     # ---- checkpoints in torch.optim.Adam's layout ----------------------------------------------------------------------

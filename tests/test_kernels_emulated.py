@@ -34,6 +34,26 @@ def test_space_to_depth_channel_slice(emulated_kernels):
     assert torch.equal(ops.space_to_depth(tr), F.pixel_unshuffle(tr, 2))
 
 
+@pytest.mark.parametrize('shape', [(2, 3, 4, 16), (1, 5, 6, 8), (2, 4, 2, 24), (1, 2, 4, 12), (3, 1, 2, 4)])
+def test_space_to_depth_depth_to_space_16_byte_forms(emulated_kernels, shape):
+    """The float4 forms of the two shuffles (csrc/pack3d.hip: W % 8 == 0 for space_to_depth, W % 4 == 0 for depth_to_space, 16-byte
+    aligned tensors) and the per-element fallbacks (W = 12 / 4, a channel slice at an odd offset) vs torch's pixel_unshuffle /
+    pixel_shuffle -- bit-exact, data movement only."""
+    import torch.nn.functional as F
+    from packnet_sfm.hip import ops
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(sum(shape)))
+    y = ops.space_to_depth(x)
+    assert torch.equal(y, F.pixel_unshuffle(x, 2))
+    assert torch.equal(ops.depth_to_space(y), x)
+    z = torch.randn(B, 4 * C, H, W, generator=torch.Generator().manual_seed(1 + sum(shape)))
+    assert torch.equal(ops.depth_to_space(z), F.pixel_shuffle(z, 2))
+    wide = torch.randn(B, C + 3, H, W, generator=torch.Generator().manual_seed(2 + sum(shape)))
+    for lo in (1, 2):                   # a slice that starts 1 / 2 planes in: aligned or not depending on H * W
+        sl = wide[:, lo:lo + C]
+        assert torch.equal(ops.space_to_depth(sl), F.pixel_unshuffle(sl, 2))
+
+
 def test_unpack(emulated_kernels):
     P.case_unpack('cpu')
 
@@ -599,6 +619,59 @@ def test_conv2d_stride2(emulated_kernels, shape, variant):
     P.check(wh.grad, wr.grad, 1e-5, 'wgrad')
     P.check(bh.grad, br.grad, 1e-5, 'dbias')
     _lib.get().pnsfm_set_conv_variant(0)
+
+
+def test_batched_repack_after_the_optimizer_step(emulated_kernels):
+    """hip.functional.repack_all (one pnsfm_conv2d_pack_table launch for every registered conv weight, called by
+    FlatAdam.step): after the step the caches are FRESH (the next forward does not re-pack), the packed buffers are
+    bit-identical to what the per-layer packer writes for the updated weights (3x3, 5x5, 7x7 and 1x1 layers, ragged channel
+    counts), a layer whose input needs no gradient (no backward-data buffer) or that has fewer than 16 channels stays on the
+    lazy path, and PNSFM_PACK_BATCH=0 switches the batched launch off."""
+    import os
+    from packnet_sfm.hip import _lib, functional as HF, ops
+    from packnet_sfm.networks.layers.packnet.layers01 import _HipConv2d
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    _lib.get().pnsfm_set_conv_math(1)
+    torch.manual_seed(4)
+    stem = _HipConv2d(3, 16, 5)                      # Cin = 3: f32 layout, never in the table
+    layers = [_HipConv2d(16, 40, 3), _HipConv2d(40, 32, 5), _HipConv2d(32, 48, 7), _HipConv2d(48, 17, 1)]
+    net = torch.nn.Sequential(stem, *layers)
+    opt = FlatAdam([{'params': list(net.parameters()), 'lr': 1e-2}])
+    x = torch.randn(1, 3, 6, 8)
+
+    def fwd_bwd():
+        opt.zero_grad()
+        net(x).pow(2).mean().backward()
+
+    fwd_bwd()
+    caches = [l._packed for l in layers]
+    assert all(c.wp_fwd is not None and c.wp_bwd is not None for c in caches)
+    opt.step()
+    n_lazy = [0]
+    real_pack = ops.conv2d_pack
+
+    def counting_pack(*a, **k):
+        n_lazy[0] += 1
+        return real_pack(*a, **k)
+
+    ops.conv2d_pack = counting_pack
+    try:
+        for l, c in zip(layers, caches):
+            w = l.weight
+            assert c.key_fwd == HF.PackedConvWeight.key_of(w) and c.key_bwd == c.key_fwd, 'cache not stamped by repack_all'
+            f, b = real_pack(w.detach().contiguous())
+            assert torch.equal(f, c.wp_fwd) and torch.equal(b, c.wp_bwd), 'batched pack differs from the per-layer packer'
+        fwd_bwd()
+        assert n_lazy[0] == 1, 'only the stem (f32 layout, no backward-data buffer) may re-pack lazily, saw %d' % n_lazy[0]
+        os.environ['PNSFM_PACK_BATCH'] = '0'
+        opt.step()
+        n_lazy[0] = 0
+        fwd_bwd()
+        assert n_lazy[0] == 1 + len(layers)
+    finally:
+        ops.conv2d_pack = real_pack
+        os.environ.pop('PNSFM_PACK_BATCH', None)
+        opt._slots.remove()
 
 
 def test_flat_adam_skips_parameters_without_gradient(emulated_kernels):

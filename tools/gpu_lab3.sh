@@ -61,6 +61,18 @@ ab_cat)
     PNSFM_CAT_FOLD=0 PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_catB_$TAG.log 2>&1
     echo "no fold: $(tail -1 $O/bench_catB_$TAG.log | cut -c1-150)"
   done ;;
+ab_pack)
+  echo "== A/B: all conv weights re-packed in one launch after the optimizer step vs lazily per layer (same database, A B A B)"
+  for i in 1 2; do
+    PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_packA_$TAG.log 2>&1
+    echo "batched: $(tail -1 $O/bench_packA_$TAG.log | cut -c1-150)"
+    PNSFM_PACK_BATCH=0 PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_packB_$TAG.log 2>&1
+    echo "lazy   : $(tail -1 $O/bench_packB_$TAG.log | cut -c1-150)"
+  done ;;
+bench_graph)
+  echo "== bench, whole step replayed as a hipGraph (same database)"
+  PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --graph on --no-cpu-baseline --no-extra --no-prof > $O/bench_graph_$TAG.log 2>&1
+  tail -1 $O/bench_graph_$TAG.log | cut -c1-200 ;;
 bench2)
   echo "== bench again on the primed database (run-to-run spread)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench2_$TAG.log 2>&1

@@ -138,12 +138,77 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
   }
 }
 
+// Four voxels per thread along x (W % 4 == 0, 16-byte aligned tensors): the 9 rows of the stencil are read as one 16-byte load
+// plus the two edge values each (27 load instructions per 4 voxels instead of 108), the weights as [tap][feature] float4
+// broadcasts from LDS, the NF outputs leave as float4 stores.  The kernel writes NF x its input: HBM-write-bound.
+template <int NF>
+__global__ void __launch_bounds__(256) conv3d_fwd_x4_kernel(const float* __restrict__ p, const float* __restrict__ w3,
+                                                             const float* __restrict__ b3, float* __restrict__ out,
+                                                             int D, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float wt[28][NF];      // [tap][feature]; row 27 = bias
+  for (int i = threadIdx.x; i < 28 * NF; i += 256) {
+    const int tap = i / NF, f = i - tap * NF;
+    wt[tap][f] = tap < 27 ? w3[f * 27 + tap] : b3[f];
+  }
+  __syncthreads();
+  const int HW = H * W, DHW = D * HW, Wq = W >> 2, HWq = H * Wq;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= D * HWq) return;
+  const int d = idx / HWq;
+  const int pq = idx - d * HWq;
+  const int y = pq / Wq, x0 = 4 * (pq - y * Wq);
+  const float* pb = p + (size_t)blockIdx.z * DHW;
+  const float* zero = pnsfm_zero_page3;
+  float acc[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[f][i] = wt[27][f];
+#pragma unroll
+  for (int dz = 0; dz < 3; ++dz) {
+    const int dd = d + dz - 1;
+    float v[3][6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      const bool ok = dd >= 0 && dd < D && yy >= 0 && yy < H;
+      const float* row = pb + (size_t)(ok ? dd : 0) * HW + (ok ? yy : 0) * W + x0;
+      const float4 c = *reinterpret_cast<const float4*>(ok ? row : zero);
+      v[dy][0] = *((ok && x0 > 0) ? row - 1 : zero);
+      v[dy][1] = c.x; v[dy][2] = c.y; v[dy][3] = c.z; v[dy][4] = c.w;
+      v[dy][5] = *((ok && x0 + 4 < W) ? row + 4 : zero);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        float wv[NF];
+#pragma unroll
+        for (int q = 0; q < NF / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(&wt[dz * 9 + dy * 3 + dx][4 * q]);
+          wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[f][i] = fmaf(wv[f], v[dy][i + dx], acc[f][i]);      // p[.][y + dy - 1][x0 + i + dx - 1]
+      }
+  }
+  float* ob = out + (size_t)blockIdx.z * NF * DHW + (size_t)d * HW + y * W + x0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+    *reinterpret_cast<float4*>(ob + (size_t)f * DHW) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+}
+
 // dp[b][d][y][x] = sum_{f,dz,dy,dx} w3[f][dz][dy][dx] * dout[b][f*D + d-dz+1][y-dy+1][x-dx+1]
 // The per-voxel form of this stencil issues 216 loads per output and is bound by the L1/TA path (measured: 166 us for
 // unpack1, 5x its HBM time).  Here one thread owns a column of `len` consecutive d at a fixed (y, x) and slides along d:
 // each dout plane (8 features x 9 in-plane neighbours = 72 raw buffer loads; zero padding by the hardware range check)
 // is loaded once and feeds the three outputs d = dd-1, dd, dd+1 (three rolling accumulators) -> 72*(len+2)/len loads
-// per output, ~80 for the run lengths the launcher picks.
+// per output, ~80 for the run lengths the launcher picks.  (Round 3 tried four outputs per thread along x -- one 16-byte
+// load + two edge values per row, 18 loads per output -- with 2 / 4 / 8 features per unrolled step: 123 / 140 / 542 us on
+// unpack1 against this kernel's 94, and weights re-read from LDS instead of the ~240 spilled scalar registers: the compiler
+// then keeps all 216 in VGPRs.  Dropped.)
 // Lanes still run along x (coalesced); the flattened (chunk, pixel) index keeps tiny planes (6x20 maps, 5x5 / 7x7 weight
 // volumes of the kernel composition) on full waves.  Weights are uniform global reads (scalar loads -> SGPR operands).
 template <int NF>
@@ -368,6 +433,12 @@ static bool nf_ok(int NF, const char* what) {
 int pnsfm_conv3d_forward(const float* p, const float* w3, const float* b3, float* out, int B, int D, int H, int W, int NF,
                          void* stream) {
   if (!nf_ok(NF, "conv3d_forward")) return -1;
+  if (W % 4 == 0 && (((uintptr_t)p | (uintptr_t)out) & 15) == 0) {      // four voxels per thread
+    const dim3 gq(ceil_div(D * H * (W / 4), 256), 1, B);
+    if (NF == 8) PNSFM_LAUNCH((conv3d_fwd_x4_kernel<8>), gq, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
+    else PNSFM_LAUNCH((conv3d_fwd_x4_kernel<4>), gq, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
+    return check_launch("conv3d_forward");
+  }
   const dim3 grid(ceil_div(D * H * W, 256), 1, B);
   if (NF == 8) PNSFM_LAUNCH((conv3d_fwd_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);
   else PNSFM_LAUNCH((conv3d_fwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p, w3, b3, out, D, H, W);

@@ -316,10 +316,11 @@ def test_conv2d_wgrad_nine_taps(emulated_kernels, shape, cfg):
 
 
 @pytest.mark.parametrize('nf', [8, 4])
-@pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3)])
+@pytest.mark.parametrize('shape', [(1, 5, 4, 6), (2, 13, 3, 5), (1, 40, 2, 3), (1, 5, 4, 8), (2, 13, 3, 4), (1, 9, 5, 12)])
 def test_conv3d_raw(emulated_kernels, shape, nf):
-    """3x3x3 1->8 stencil: forward, data gradient (column-sliding kernel, ragged run lengths along d) and weight/bias
-    gradient (register accumulation + LDS block reduction) vs the oracle on small odd volumes."""
+    """3x3x3 1->8 stencil: forward, data gradient (column-sliding kernel, ragged run lengths along d; W % 4 == 0 runs the
+    four-outputs-per-thread form) and weight/bias gradient (register accumulation + LDS block reduction) vs the oracle on small
+    odd volumes."""
     from oracle import packnet_oracle as O
     from packnet_sfm.hip import functional as HF
     B, D, H, W = shape

@@ -29,7 +29,7 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     for _ in range(N):
         step()
     torch.cuda.synchronize()
@@ -45,3 +45,25 @@ tot = sum(r[0] for r in rows)
 print('aten device time per step: %.1f us in %d (op, shape) groups' % (tot, len(rows)))
 for t, c, k, s in rows[:70]:
     print('%8.1f us %5.1f x  %-28s %s' % (t, c, k, s))
+
+# ---- by call site: the innermost frame inside this repository's package
+import collections
+sites = collections.defaultdict(lambda: [0.0, 0])
+for e in prof.events():
+    t = getattr(e, 'self_device_time_total', None)
+    if t is None:
+        t = getattr(e, 'self_cuda_time_total', 0)
+    if t <= 0 or not e.name.startswith('aten::'):
+        continue
+    where = '?'
+    for fr in (e.stack or []):
+        if 'packnet' in fr and 'site-packages' not in fr and 'dist-packages' not in fr:
+            where = fr.split('packnet-sfm_amd/')[-1]
+            break
+    a = sites[(where, e.name)]
+    a[0] += t / N
+    a[1] += 1.0 / N
+print()
+print('by call site (innermost frame of this package):')
+for (where, name), (t, c) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:60]:
+    print('%8.1f us %5.1f x  %-34s %s' % (t, c, name, where[:110]))

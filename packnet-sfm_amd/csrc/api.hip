@@ -160,6 +160,11 @@ void scratch_release(void* p, hipStream_t stream, bool async_owned) {
 #endif
 }
 
+int block_map_mode() {
+  static const int mode = [] { const char* e = getenv("PNSFM_BLOCK_MAP"); const int m = e ? atoi(e) : 2; return m < 0 || m > 2 ? 2 : m; }();
+  return mode;
+}
+
 int ensure_lds_limit(const void* kernel, unsigned long long* mask, int bytes, const char* what) {
 #ifndef PNSFM_EMU
   int dev = 0;

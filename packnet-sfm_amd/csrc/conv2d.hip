@@ -348,6 +348,7 @@ struct ConvArgs {
   int pstride;        // DMA variants: floats between the two patch buffers
   int G;              // pipelined / bx3 variants: taps per weight stage
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
+  int gx, gy, bmap;   // bx3 variants (1-D launch): pixel tiles, output-channel tiles, block order (pnsfm_common.h: block_map_mode)
   float invPW, invPS;
 #ifdef PNSFM_PIPE_TRACE
   long long* trace;   // debug build only (tools/pipe_trace.py): per wave {barrier wait, stage compute, prologue, epilogue} cycles
@@ -366,10 +367,10 @@ __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 // paths are separate loops so the compiler can stream the stores.
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int co0, int half,
-                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT]) {
+                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], bool first_split) {
   const int HW = a.H * a.W;
   float* yb = a.y + (size_t)b * a.Cout * HW;
-  const bool add_bias = a.bias != nullptr && blockIdx.z == 0;
+  const bool add_bias = a.bias != nullptr && first_split;      // one K split adds the bias
   if (add_bias) {
     float bval[MT][16];
 #pragma unroll
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if constexpr (DMA) dma_cur ^= 1;
   }
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, blockIdx.z == 0);
 }
 
 
@@ -827,7 +828,7 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, blockIdx.z == 0);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();
@@ -873,6 +874,8 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     if (e) { set_error("%s: memset failed", what); return e; }
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
+  a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
+  const dim3 grid1(grid.x * grid.y * grid.z);      // split-bf16 kernels: 1-D launch, block order decoded in the kernel
 #define PNSFM_CONV_DISPATCH(DMAv)                                                                                 \
   do {                                                                                                             \
     if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_mfma_kernel<2, 2, DMAv>), grid, dim3(256), g.smem_bytes, stream, a);      \
@@ -893,14 +896,14 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
 #define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
 #endif
     if (g.DMA == 6) {         // three workgroups per CU (<= 53 KB of LDS each: no opt-in needed)
-      if (g.MT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 3>), grid, dim3(256), g.smem_bytes, stream, a);
-      else if (g.NT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 3>), grid, dim3(256), g.smem_bytes, stream, a);
-      else PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 3>), grid, dim3(256), g.smem_bytes, stream, a);
+      if (g.MT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
+      else if (g.NT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
+      else PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
     }
-    else if (g.MT == 2 && g.NT == 2) { PNSFM_BX3_ATTR(2, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else if (g.MT == 2 && g.NT == 1) { PNSFM_BX3_ATTR(2, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else if (g.MT == 1 && g.NT == 2) { PNSFM_BX3_ATTR(1, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
-    else { PNSFM_BX3_ATTR(1, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 2>), grid, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 2 && g.NT == 2) { PNSFM_BX3_ATTR(2, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 2, 2>), grid1, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 2 && g.NT == 1) { PNSFM_BX3_ATTR(2, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 2>), grid1, dim3(256), g.smem_bytes, stream, a); }
+    else if (g.MT == 1 && g.NT == 2) { PNSFM_BX3_ATTR(1, 2); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 2>), grid1, dim3(256), g.smem_bytes, stream, a); }
+    else { PNSFM_BX3_ATTR(1, 1); PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 2>), grid1, dim3(256), g.smem_bytes, stream, a); }
 #undef PNSFM_BX3_ATTR
   } else if (g.DMA == 2) {
 #ifndef PNSFM_EMU

@@ -69,10 +69,18 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const int H = a.H, W = a.W, HW = H * W;
   const int S = a.S, Hi = a.Hi, Wi = a.Wi, HWi = Hi * Wi;
 
-  const int b = blockIdx.x / a.tiles_per_img;
-  const int t = blockIdx.x - b * a.tiles_per_img;
-  const int co0 = blockIdx.y * BM;
-  const int c_begin = blockIdx.z * a.chunks_per_split;
+  // logical block (pixel tile, output-channel tile, K split) of this workgroup: 1-D launch, output-channel tile fastest -- the
+  // tiles that read the same input patch are neighbours -- and a contiguous range of that order per XCD (pnsfm_common.h)
+  unsigned bx, by, bz;
+  {
+    const unsigned Lb = a.bmap == 2 ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (a.bmap == 0) { bx = Lb % (unsigned)a.gx; const unsigned q = Lb / (unsigned)a.gx; by = q % (unsigned)a.gy; bz = q / (unsigned)a.gy; }
+    else { by = Lb % (unsigned)a.gy; const unsigned q = Lb / (unsigned)a.gy; bx = q % (unsigned)a.gx; bz = q / (unsigned)a.gx; }
+  }
+  const int b = (int)bx / a.tiles_per_img;
+  const int t = (int)bx - b * a.tiles_per_img;
+  const int co0 = (int)by * BM;
+  const int c_begin = (int)bz * a.chunks_per_split;
   int c_end = c_begin + a.chunks_per_split;
   if (c_end > a.nchunks) c_end = a.nchunks;
 
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 
   // ---- weight stream: stage = G taps of one chunk, MT slabs per tap; one DMA instruction moves 1 KB (one piece of one slab)
   const pnsfm_dma_buf wdesc = pnsfm_make_dma_buf(a.wp, (long)(a.MP / 32) * a.nchunks * KK * PNSFM_BX3_SLAB);
-  const int mb0 = blockIdx.y * MT;
+  const int mb0 = (int)by * MT;
   // A stage's slabs sit in LDS as [m tile][tap][piece] -- for one m tile the G taps of a chunk are ONE contiguous run of the packed
   // weight stream (G * 3 KB), so a wave's share of the stage is a contiguous range of 1-KB pieces: source and destination advance by
   // 1024 per instruction and the loop around the DMA is a handful of scalar operations (it used to decode (slab, piece, tap, tile)
@@ -343,11 +351,11 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, bz == 0);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();
-    long long* tt = a.trace + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave) * 8;
+    long long* tt = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
     tt[0] = tr_wait; tt[1] = tr_issue; tt[2] = tr_mma; tt[3] = tr_stage; tt[4] = tr_end - tr_start; tt[5] = tr_loop - tr_start;
     tt[6] = tr_end - tr_epi; tt[7] = stage;
   }

@@ -8,7 +8,7 @@
 // error at 16/6 the MAC rate of v_mfma_f32_32x32x2_f32.
 //
 // GEMM view PER TAP: M = co, N = ci, K = pixels; one MFMA k-step = 16 consecutive pixels of an image row.
-//   * a workgroup owns ONE KERNEL ROW ky (blockIdx.x = (ci tile, ky)): its waves accumulate the KS taps of that row for a
+//   * a workgroup owns ONE KERNEL ROW ky (logical block x = (ci tile, ky)): its waves accumulate the KS taps of that row for a
 //     32(co) x 32*NT(ci) tile each, KS*NT accumulator tiles;  4 waves = WM co tiles x WK pixel shares (WM = 4, 2, 1 for
 //     Cout >= 97, >= 33, smaller): all waves share one X patch in LDS;
 //   * A operand (dY): lane (co = l&31, half = l>>5) needs 8 consecutive pixels -- 32 contiguous bytes of the NCHW tensor: read
@@ -19,7 +19,7 @@
 //     MFMAs) -> 3 bf16 pieces -> LDS [piece][ci][row][col] (channel stride 8 * odd elements: conflict-free ds_read_b128).
 //     A lane reads the aligned 8-pixel block and its two neighbours (3 ds_read_b128 per piece) and builds the KS shifted
 //     operands in registers: an even shift is a register renaming, an odd shift one v_alignbit_b32 per dword;
-//   * the WK pixel shares of a workgroup are summed through LDS; pixel tiles are split over blockIdx.z and the partial
+//   * the WK pixel shares of a workgroup are summed through LDS; pixel tiles are split over the third logical block index and the partial
 //     tensors of a split launch go to a scratch buffer ([split][ky][co][kx][ci]: coalesced stores) that a second kernel sums
 //     in a fixed order -- no atomics anywhere: the gradient is bit-reproducible run to run.
 // Widths that are a multiple of 4 but not of 8 (20, 4: the upper half of an 8-pixel group may lie past the row end) run a
@@ -43,7 +43,8 @@ struct Wgrad3Args {
   int COP, CIP;      // padded channel extents of the workspace (whole workgroup tiles)
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
-  int ci_tiles;      // gridDim.x = ci_tiles * KS
+  int ci_tiles;      // logical grid x = ci_tiles * KS
+  int gx, gy, bmap;  // 1-D launch: ci tiles * KS, co groups, block order (pnsfm_common.h: block_map_mode)
 };
 
 #ifdef PNSFM_EMU
@@ -105,10 +106,14 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
   const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
   const int wm = wave % WM, wk = wave / WM;
   const int H = a.H, W = a.W, HW = H * W;
-  const int cit = blockIdx.x / KS, ky = blockIdx.x - cit * KS;
+  // logical block ((ci tile, kernel row), co group, pixel split): first index fastest -- the workgroups of one pixel split read the
+  // same dY and X -- and a contiguous range of that order per XCD (pnsfm_common.h)
+  const unsigned Lb = a.bmap == 2 ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bx = (int)(Lb % (unsigned)a.gx), by = (int)((Lb / (unsigned)a.gx) % (unsigned)a.gy), bz = (int)(Lb / (unsigned)(a.gx * a.gy));
+  const int cit = bx / KS, ky = bx - cit * KS;
   const int ci0 = cit * NCI;
-  const int co0 = (blockIdx.y * WM + wm) * 32;
-  const int t_begin = blockIdx.z * a.tiles_per_split;
+  const int co0 = (by * WM + wm) * 32;
+  const int t_begin = bz * a.tiles_per_split;
   int t_end = t_begin + a.tiles_per_split;
   if (t_end > a.total_tiles) t_end = a.total_tiles;
 
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][k][r] = 0.f;
   float bsum = 0.f;
-  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0;      // ci tile 0, kernel row 0
+  const bool do_bias = a.dbias != nullptr && bx == 0;      // ci tile 0, kernel row 0
 
   // ---- tile cursors.  Index arithmetic is kept out of the loop: a tile's origin (image, first row, first column) is advanced
   // incrementally in scalar registers for the current tile and the two behind it (the prefetch targets), and every per-lane
@@ -337,7 +342,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
       }
       if (do_bias && half == 0 && co0 + l32 < a.Cout) a.dbias[co0 + l32] = bsum;
     } else {                    // partial sums, ci fastest: 128 contiguous bytes per half-wave
-      float* w = a.ws + ((size_t)blockIdx.z * KS + ky) * a.COP * KS * a.CIP;
+      float* w = a.ws + ((size_t)bz * KS + ky) * a.COP * KS * a.CIP;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int ci = ci0 + nt * 32 + l32;
@@ -349,7 +354,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
             w[((size_t)co * KS + kx) * a.CIP + ci] = acc[nt][kx][r];
           }
       }
-      if (do_bias && half == 0) a.ws_bias[(size_t)blockIdx.z * a.COP + co0 + l32] = bsum;
+      if (do_bias && half == 0) a.ws_bias[(size_t)bz * a.COP + co0 + l32] = bsum;
     }
   }
 }
@@ -495,7 +500,8 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
     a.ws = lease.as<float>();
     a.ws_bias = a.ws + (size_t)splitP * part;
   }
-  dim3 grid(a.ci_tiles * ks, co_groups, splitP);
+  a.gx = a.ci_tiles * ks; a.gy = co_groups; a.bmap = block_map_mode();
+  dim3 grid(a.ci_tiles * ks * co_groups * splitP);
   int rc = 0;
 #define PNSFM_W3T(KSv, NTv, WMv)                                                    \
   do {                                                                              \

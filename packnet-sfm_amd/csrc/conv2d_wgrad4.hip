@@ -20,7 +20,7 @@
 //     reads its aligned 8-pixel block once per (kernel row, piece) plus the two neighbouring dwords and builds the three
 //     shifted operands with one v_alignbit_b32 per dword;
 //   * the 4 waves of a workgroup are WCO co tiles x WCI ci tiles (no pixel shares: nothing to reduce inside a workgroup);
-//     pixel tiles are split over blockIdx.z and the partial tensors of a split launch go to the stream's scratch buffer in
+//     pixel tiles are split over the launch's third logical dimension and the partial tensors of a split launch go to the stream's scratch buffer in
 //     wgrad3's layout ([split][ky][co][kx][ci]) for wgrad3_reduce_kernel: no atomics, bit-reproducible.
 // Roofline: MFMA-bound: 2*Cout*Cin*9*B*H*W algorithmic flop against 2500/6 TFLOP/s (bf16 dense peak / 6 products).
 #include "pnsfm_common.h"
@@ -41,6 +41,7 @@ struct Wgrad4Args {
   int COP, CIP;      // padded channel extents of the workspace (whole workgroup tiles)
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
+  int gx, gy, bmap;  // 1-D launch: ci tiles, co groups, block order (pnsfm_common.h: block_map_mode)
 };
 
 #ifdef PNSFM_EMU
@@ -98,9 +99,13 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
   const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), l16 = lane & 15, j = lane >> 4;
   const int wci = wave % WCI, wco = wave / WCI;
   const int H = a.H, W = a.W, HW = H * W;
-  const int ci0 = blockIdx.x * NCI;
-  const int co0 = (blockIdx.y * WCO + wco) * 32;
-  const int t_begin = blockIdx.z * a.tiles_per_split;
+  // logical block (ci tile, co group, pixel split): ci tile fastest -- the workgroups of one pixel split read the same dY and X
+  // -- and a contiguous range of that order per XCD (pnsfm_common.h)
+  const unsigned Lb = a.bmap == 2 ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bx = (int)(Lb % (unsigned)a.gx), by = (int)((Lb / (unsigned)a.gx) % (unsigned)a.gy), bz = (int)(Lb / (unsigned)(a.gx * a.gy));
+  const int ci0 = bx * NCI;
+  const int co0 = (by * WCO + wco) * 32;
+  const int t_begin = bz * a.tiles_per_split;
   int t_end = t_begin + a.tiles_per_split;
   if (t_end > a.total_tiles) t_end = a.total_tiles;
 
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[s][ky][kx][r] = 0.f;
   float bsum0 = 0.f, bsum1 = 0.f;
-  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0 && wci == 0;
+  const bool do_bias = a.dbias != nullptr && bx == 0 && wci == 0;
 
   // ---- tile cursors (as wgrad3): origin of the current tile and the two behind it, advanced in scalar registers
   struct Cur { int b, y0, x0; };
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
   // ---- epilogue: D row = 4 * j + r -> co, column = l16 -> ci; every output element has exactly ONE writer in this launch
   const int ci = ci0 + wci * 16 + l16;
   if (a.ws) {
-    float* ws = a.ws + (size_t)blockIdx.z * 9 * a.COP * a.CIP;
+    float* ws = a.ws + (size_t)bz * 9 * a.COP * a.CIP;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -306,7 +311,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
       for (int s = 0; s < 2; ++s) {
         const int co = co0 + 16 * s + l16;
         const float v = s ? bsum1 : bsum0;
-        if (a.ws_bias) a.ws_bias[(size_t)blockIdx.z * a.COP + co] = v;
+        if (a.ws_bias) a.ws_bias[(size_t)bz * a.COP + co] = v;
         else if (co < a.Cout) a.dbias[co] = v;
       }
     }
@@ -382,7 +387,8 @@ int enqueue_wgrad4(const float* x, const float* dy, float* dw, float* dbias, int
     a.ws = lease.as<float>();
     a.ws_bias = a.ws + (size_t)splitP * part;
   }
-  dim3 grid(ci_tiles, co_groups, splitP);
+  a.gx = ci_tiles; a.gy = co_groups; a.bmap = block_map_mode();
+  dim3 grid(ci_tiles * co_groups * splitP);
   int rc = 0;
 #define PNSFM_W4(WCIv, TGv, TRv)                                                  \
   do {                                                                            \

@@ -173,6 +173,20 @@ struct ScratchLease {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Block order of the conv kernels.  Workgroup p of a 1-D grid runs on XCD p % 8 (observed on MI355X; relied on for speed only) and
+// every XCD has its own 4 MB L2, so round-robin neighbours share nothing: each XCD is handed a CONTIGUOUS range of the logical
+// block order instead, and the kernels order their logical blocks so that neighbours share operands (all output-channel tiles of
+// one pixel tile; all channel tiles of one pixel split).  mode 0: logical = physical (round 2's order).
+#ifdef PNSFM_EMU
+static inline unsigned pnsfm_xcd_logical_block(unsigned p, unsigned n) {
+#else
+__device__ __forceinline__ unsigned pnsfm_xcd_logical_block(unsigned p, unsigned n) {
+#endif
+  const unsigned xcd = p & 7u, slot = p >> 3, full = n >> 3, rem = n & 7u;
+  return xcd * full + (xcd < rem ? xcd : rem) + slot;
+}
+int block_map_mode();      // api.hip: PNSFM_BLOCK_MAP = 0 (x fastest, round robin) | 1 (operand-sharing order) | 2 (+ XCD ranges, default)
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -69,6 +69,12 @@ ab_pack)
     PNSFM_PACK_BATCH=0 PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench_packB_$TAG.log 2>&1
     echo "lazy   : $(tail -1 $O/bench_packB_$TAG.log | cut -c1-150)"
   done ;;
+ab_map)
+  echo "== A/B: block order of the conv kernels (0 round robin as round 2, 1 operand-sharing order, 2 + contiguous range per XCD), same database"
+  for i in 1 2; do for m in 2 0 1; do
+    PNSFM_BLOCK_MAP=$m PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra > $O/bench_map${m}_$TAG.log 2>&1
+    echo "map $m: $(tail -1 $O/bench_map${m}_$TAG.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'img/s  fwd+dgrad', r['achieved'], 'TF  wgrad', r['wgrad_kernel']['achieved'], 'TF')")"
+  done; done ;;
 bench_graph)
   echo "== bench, whole step replayed as a hipGraph (same database)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --graph on --no-cpu-baseline --no-extra --no-prof > $O/bench_graph_$TAG.log 2>&1

@@ -212,46 +212,83 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 
   const unsigned char* const bbase = smem + (size_t)(l32 * CS + 8 + 8 * half) * 2;   // + nt*32*CS*2 + piece + row/col of the k-step
 
+  // one k-step.  7x7 (and the two-ci-tile / three-workgroups-per-CU builds): the B pieces are walked l, m, h -- one 24-element window (prev, cur, next 8-pixel blocks: 12 dwords) in
+  // registers at a time instead of all three (the 112 accumulator registers of 7 taps leave no room for 36 + 12: that form
+  // spilled) -- and each shifted operand feeds the A pieces it pairs with, so every accumulator still sees its smallest products
+  // first: (h,l) | (m,m) (h,m) | (l,h) (m,h) (h,h) [A piece, B piece]; +4.5 % on the two 7x7 layers.  3x3 / 5x5 keep all three
+  // windows and finish one tap (6 MFMAs on one accumulator) at a time: the piece-major form measured 4-8 % slower on 5x5.
   auto kstep = [&](const pnsfm_u32x4 (&A)[3], int q) {
     const int koff = ((q / SEG) * RS + 16 * (q % SEG)) * 2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
-      unsigned Wd[3][12];
+      if (KS >= 7 || NT == 2 || OCC == 3) {      // the register-tight instantiations
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE) * 2 + koff;
-        const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
+        for (int s = 2; s >= 0; --s) {
+          unsigned Wd[12];
+          const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE) * 2 + koff;
+          const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
-        if (KS > 1) {
-          const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
-          const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
+          for (int d = 0; d < 4; ++d) Wd[4 + d] = c[d];
+          if (KS > 1) {
+            const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
+            const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
-        }
-      }
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const int sh = kx - P;                         // element shift of this tap
-        pnsfm_u32x4 Bv[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
-            else {
-              const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
-              Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
-            }
+            for (int d = 0; d < 4; ++d) { Wd[d] = pv[d]; Wd[8 + d] = nx[d]; }
           }
-        // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-        acc[nt][kx] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][kx]);
-        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][kx]);
-        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[1], acc[nt][kx]);
-        acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[0], acc[nt][kx]);
-        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[1], acc[nt][kx]);
-        acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[0], acc[nt][kx]);
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const int sh = kx - P;                         // element shift of this tap
+            pnsfm_u32x4 Bv;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              if ((sh & 1) == 0) Bv[d] = Wd[4 + d + sh / 2];
+              else {
+                const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
+                Bv[d] = w3_alignbit16(Wd[lo + 1], Wd[lo]);
+              }
+            }
+#pragma unroll
+            for (int sa = 2 - s; sa >= 0; --sa) acc[nt][kx] = pnsfm_mfma_bf16(A[sa], Bv, acc[nt][kx]);
+          }
+        }
+      } else {
+        // window of 24 elements (prev, cur, next 8-pixel blocks) of each piece: 12 dwords
+        unsigned Wd[3][12];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const unsigned char* p = bbase + (size_t)(nt * 32 * CS + s * PIECE) * 2 + koff;
+          const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
+          if (KS > 1) {
+            const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
+            const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int sh = kx - P;                         // element shift of this tap
+          pnsfm_u32x4 Bv[3];
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
+              else {
+                const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
+                Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
+              }
+            }
+          // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+          acc[nt][kx] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][kx]);
+          acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][kx]);
+          acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[1], acc[nt][kx]);
+          acc[nt][kx] = pnsfm_mfma_bf16(A[1], Bv[0], acc[nt][kx]);
+          acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[1], acc[nt][kx]);
+          acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[0], acc[nt][kx]);
+        }
       }
     }
   };
@@ -466,6 +503,10 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   }
   if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
   if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) NT = 1;     // a 64-channel tile would straddle two tensors
+  // two instantiations do not fit their register budget without spilling (3x3, four co tiles per workgroup, 32-column tiles: two
+  // ci tiles per wave, and the three-workgroups-per-CU build): those requests run the one-ci-tile / two-workgroup build instead
+  const bool tight = ks == 3 && wgrad3_WM(Cout, WMwant & 7) == 4 && wgrad3_tc(W) == 32 && W % 8 == 0;
+  if (tight) { NT = 1; WMwant &= 7; }
   if (ms && (ms->C0 % 32 != 0 || (ms->C0 + ms->C1) % 32 != 0)) {
     set_error("conv2d_backward_weight (split-bf16): the input tensors must end on 32-channel boundaries");
     return -1;
@@ -517,10 +558,15 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
   } while (0)
   if (occ3) {
     if (tc == 16) { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 16, false, 3>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 16, false, 3>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 16, false, 3>(a, grid, s); }
-    else { if (WM == 4) rc = launch_wgrad3<3, 1, 4, 32, false, 3>(a, grid, s); else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 32, false, 3>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 32, false, 3>(a, grid, s); }
+    else { if (WM == 4) { set_error("conv2d_backward_weight (split-bf16): unreachable build"); rc = -1; } else if (WM == 2) rc = launch_wgrad3<3, 1, 2, 32, false, 3>(a, grid, s); else rc = launch_wgrad3<3, 1, 1, 32, false, 3>(a, grid, s); }
   }
   else if (ks == 1) { if (NT == 2) PNSFM_W3(1, 2); else PNSFM_W3(1, 1); }
-  else if (ks == 3) { if (NT == 2) PNSFM_W3(3, 2); else PNSFM_W3(3, 1); }
+  else if (ks == 3 && NT == 2 && WM == 4) {      // (the 32-column tile of this shape was re-routed above)
+    if (masked) rc = launch_wgrad3<3, 2, 4, 16, true>(a, grid, s);
+    else if (tc == 16) rc = launch_wgrad3<3, 2, 4, 16, false>(a, grid, s);
+    else { set_error("conv2d_backward_weight (split-bf16): unreachable build"); rc = -1; }
+  }
+  else if (ks == 3) { if (NT == 2) { if (WM == 2) PNSFM_W3T(3, 2, 2); else PNSFM_W3T(3, 2, 1); } else PNSFM_W3(3, 1); }
   else if (ks == 5) PNSFM_W3(5, 1);
   else PNSFM_W3(7, 1);
 #undef PNSFM_W3T

@@ -447,7 +447,7 @@ def main():
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(m['loss'], 6),
                        # fp32 tensors and accumulators; the conv GEMMs as 6 bf16 MFMA products of exact 3-way operand splits
                        'arithmetic': ('fp32 via 6xbf16 MFMA (exact 3-way bf16 operand split, fp32 accumulate; csrc/conv2d_bx3.h, '
-                                      'conv2d_wgrad3.hip; 1x1 / Cin<16 layers on v_mfma_f32_32x32x2_f32)') if bx3 else
+                                      'conv2d_wgrad3.hip, conv2d_wgrad4.hip; Cin<16 / stride-2 layers on v_mfma_f32_32x32x2_f32)') if bx3 else
                                      'fp32 on v_mfma_f32_32x32x2_f32',
                        'optimizer': ('FlatAdam (flat arenas = all-reduce buckets, conv weight gradients written in place)'
                                      if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)'),

@@ -348,6 +348,7 @@ struct ConvArgs {
   int pstride;        // DMA variants: floats between the two patch buffers
   int G;              // pipelined / bx3 variants: taps per weight stage
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
+  int playout;        // bx3 variants: patch layout in LDS (1: half planes, conflict-free B fragments; 0: round 2's)
   int gx, gy, bmap;   // bx3 variants (1-D launch): pixel tiles, output-channel tiles, block order (pnsfm_common.h: block_map_mode)
   float invPW, invPS;
 #ifdef PNSFM_PIPE_TRACE
@@ -875,6 +876,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
+  { static const int pl = [] { const char* e = getenv("PNSFM_PATCH_LAYOUT"); return (e && e[0] == '0') ? 0 : 1; }(); a.playout = pl; }
   const dim3 grid1(grid.x * grid.y * grid.z);      // split-bf16 kernels: 1-D launch, block order decoded in the kernel
 #define PNSFM_CONV_DISPATCH(DMAv)                                                                                 \
   do {                                                                                                             \

@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   constexpr int BM = 32 * MT, MAXIT = (MT * NT == 4 || OCC == 3) ? PNSFM_BX3_MAXIT - 1 : PNSFM_BX3_MAXIT;   // (2,2): acc + fragments leave fewer registers
   const int PS = a.PH * a.PW;
   const int planeB = a.pstride;                  // bytes of one piece plane of the patch
+  const int halfB = planeB >> 1;                 // ... which is two half planes: channels 0-7 and 8-15 of the chunk, [pixel][8 ch]
+  const bool hp = a.playout != 0;                // (0: round 2's [pixel][half][8 ch] layout, kept selectable for the A/B: PNSFM_PATCH_LAYOUT)
+  const int tapB = hp ? 16 : 32;                 // bytes between horizontally adjacent pixels of a plane
   const int patchB = 3 * planeB;
   const int G = a.G;
   const int stageB = G * MT * PNSFM_BX3_SLAB;
@@ -140,20 +143,23 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // ---- patch staging.  Item e = (pixel e>>1 of the patch, channel half e&1); its three 16-byte pieces go to byte e*16 of
-  // each plane.  A thread's items sit at the same pixel for every chunk: the byte offset inside a channel image is computed
+  // ---- patch staging.  Item e = (channel half e / PS, pixel e % PS of the patch); its three 16-byte pieces go to the half plane
+  // of each piece plane, 16 bytes per pixel: the B operand of 16 consecutive lanes (consecutive pixels) is then 256 contiguous
+  // bytes -- every LDS bank once.  (Round 2's [pixel][half] layout put them 32 bytes apart: a 2-way bank conflict on every B
+  // fragment, the 33 % "conflict cycles" of profiles/r02_sq_waits.json.)  A thread's items sit at the same pixel for every chunk: the byte offset inside a channel image is computed
   // once; out-of-image pixels carry an out-of-range offset (the buffer load returns 0 for them, as for channels >= Cin).
   // (multi-source input: the decoder's concatenations are never materialised -- chunk c reads whichever tensor holds its channels)
   const int nitems = 2 * PS;
   const int nit = (nitems + 255) >> 8;
   const bool prefetch = nit <= MAXIT;
   auto item_off = [&](int e) -> unsigned {
-    const int pix = e >> 1;
+    const int hi = hp ? (e >= PS ? 1 : 0) : (e & 1), pix = hp ? e - hi * PS : e >> 1;
     const int r = pix / a.PW, cc = pix - r * a.PW;
     const int yy = py0 + r, xx = px0 + cc;
     const bool ok = e < nitems && yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
-    return ok ? (unsigned)(((e & 1) * 8 * HWi + yy * Wi + xx) * 4) : PNSFM_DMA_INVALID;
+    return ok ? (unsigned)((hi * 8 * HWi + yy * Wi + xx) * 4) : PNSFM_DMA_INVALID;
   };
+  auto item_lds = [&](int e) -> int { return (hp && e >= PS) ? halfB + (e - PS) * 16 : e * 16; };
   unsigned gv[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) gv[it] = item_off(it * 256 + tid);
@@ -186,9 +192,10 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
         pnsfm_u32x4 Hh, Mm, Ll;
         bx3_split8(raw[it], Hh, Mm, Ll);
         if (e < nitems) {
-          *reinterpret_cast<pnsfm_u32x4*>(patch + e * 16) = Hh;
-          *reinterpret_cast<pnsfm_u32x4*>(patch + planeB + e * 16) = Mm;
-          *reinterpret_cast<pnsfm_u32x4*>(patch + 2 * planeB + e * 16) = Ll;
+          unsigned char* d = patch + item_lds(e);
+          *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
+          *reinterpret_cast<pnsfm_u32x4*>(d + planeB) = Mm;
+          *reinterpret_cast<pnsfm_u32x4*>(d + 2 * planeB) = Ll;
         }
       }
   };
@@ -202,9 +209,10 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
       for (int u = 0; u < 8; ++u) v[u] = pnsfm_buf_load(buf, off + (unsigned)(u * HWi * 4), 0);
       pnsfm_u32x4 Hh, Mm, Ll;
       bx3_split8(v, Hh, Mm, Ll);
-      *reinterpret_cast<pnsfm_u32x4*>(patch + e0 * 16) = Hh;
-      *reinterpret_cast<pnsfm_u32x4*>(patch + planeB + e0 * 16) = Mm;
-      *reinterpret_cast<pnsfm_u32x4*>(patch + 2 * planeB + e0 * 16) = Ll;
+      unsigned char* d = patch + item_lds(e0);
+      *reinterpret_cast<pnsfm_u32x4*>(d) = Hh;
+      *reinterpret_cast<pnsfm_u32x4*>(d + planeB) = Mm;
+      *reinterpret_cast<pnsfm_u32x4*>(d + 2 * planeB) = Ll;
     }
   };
 
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   // per-lane operand addresses
   unsigned baddr[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) baddr[nt] = (unsigned)boff[nt] * 32u + half * 16u;
+  for (int nt = 0; nt < NT; ++nt) baddr[nt] = hp ? (unsigned)boff[nt] * 16u + (unsigned)(half * halfB) : (unsigned)boff[nt] * 32u + half * 16u;
   const unsigned aaddr = half * 512u + l32 * 16u;
 
   struct Frag { pnsfm_u32x4 A[MT][3], B[NT][3]; };
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 
       int ky = tap0 / a.KS, kx = tap0 - ky * a.KS;
       auto tapoff = [&]() -> int {
-        const int o = (ky * a.PW + kx) * 32;
+        const int o = (ky * a.PW + kx) * tapB;
         if (++kx == a.KS) { kx = 0; ++ky; }
         return o;
       };

@@ -75,6 +75,12 @@ ab_map)
     PNSFM_BLOCK_MAP=$m PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra > $O/bench_map${m}_$TAG.log 2>&1
     echo "map $m: $(tail -1 $O/bench_map${m}_$TAG.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'img/s  fwd+dgrad', r['achieved'], 'TF  wgrad', r['wgrad_kernel']['achieved'], 'TF')")"
   done; done ;;
+ab_layout)
+  echo "== A/B: LDS layout of the conv patch (1 half planes: conflict-free B fragments, 0 round 2: [pixel][half]), same database"
+  for i in 1 2; do for m in 1 0; do
+    PNSFM_PATCH_LAYOUT=$m PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra > $O/bench_layout${m}_$TAG.log 2>&1
+    echo "layout $m: $(tail -1 $O/bench_layout${m}_$TAG.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'img/s  fwd+dgrad', r['achieved'], 'TF  wgrad', r['wgrad_kernel']['achieved'], 'TF')")"
+  done; done ;;
 bench_graph)
   echo "== bench, whole step replayed as a hipGraph (same database)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --graph on --no-cpu-baseline --no-extra --no-prof > $O/bench_graph_$TAG.log 2>&1

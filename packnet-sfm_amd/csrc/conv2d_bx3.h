@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 
 #ifdef PNSFM_PIPE_TRACE
   // debug build (tools/bx3_trace.py): cycles of this wave in {stage wait, DMA / load issue, MFMA loop, chunk-end staging}
-  long long tr_wait = 0, tr_issue = 0, tr_mma = 0, tr_stage = 0;
+  long long tr_wait = 0, tr_issue = 0, tr_mma = 0, tr_stage = 0, tr_load = 0;
   const long long tr_start = __builtin_readcyclecounter();
 #define PNSFM_TR(acc_, expr) do { const long long t0_ = __builtin_readcyclecounter(); expr; acc_ += __builtin_readcyclecounter() - t0_; } while (0)
 #else
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
       PNSFM_TR(tr_issue, {
         if (!last) issue_weights(c, tap0 + G, wnext);
         else if (more) issue_weights(c + 1, 0, wnext);
-        if (last && more && prefetch) load_items(c + 1);
+        if (last && more && prefetch) PNSFM_TR(tr_load, load_items(c + 1));      // (inside the issue bracket: also counted there)
       });
 #ifdef PNSFM_PIPE_TRACE
       const long long tr_m0 = __builtin_readcyclecounter();
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
     const long long tr_end = __builtin_readcyclecounter();
     long long* tt = a.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
     tt[0] = tr_wait; tt[1] = tr_issue; tt[2] = tr_mma; tt[3] = tr_stage; tt[4] = tr_end - tr_start; tt[5] = tr_loop - tr_start;
-    tt[6] = tr_end - tr_epi; tt[7] = stage;
+    tt[6] = tr_end - tr_epi; tt[7] = stage + 4096 * tr_load;
   }
 #endif
 #undef PNSFM_TR

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, 'packnet-sfm_amd'))
 import torch
 CS = os.path.join(ROOT, 'packnet-sfm_amd', 'csrc')
 LIB = os.path.join(ROOT, 'gpurun_out', 'libpnsfm_bx3trace.so')
-srcs = [os.path.join(CS, f) for f in ('api.hip', 'conv2d.hip', 'conv2d_wgrad2.hip', 'conv2d_wgrad3.hip')]
+srcs = [os.path.join(CS, f) for f in ('api.hip', 'conv2d.hip', 'conv2d_wgrad2.hip', 'conv2d_wgrad3.hip', 'conv2d_wgrad4.hip')]
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-munsafe-fp-atomics',
                        '-DPNSFM_PIPE_TRACE', '-w', '-o', LIB] + srcs)
 lib = ctypes.CDLL(LIB)
@@ -35,10 +35,14 @@ for i in range(0, len(args), 11):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     t = trace.cpu().view(-1, 8)
-    t = t[t[:, 4] > 0].double()
+    t = t[t[:, 4] > 0]
+    tload = (t[:, 7] // 4096).double().mean()
+    t[:, 7] = t[:, 7] % 4096
+    t = t.double()
     m = t.mean(0)
     fl = 2.0 * B * Cin * Cout * ks * ks * H * W
     print('%s NT%d var%d narrow%d tm%d split%d: %.1f us %.0f TF | waves %d, per wave cycles: total %.0f = prologue %.0f + wait %.0f + issue %.0f + '
           'mma %.0f + chunk-end %.0f + epilogue %.0f (+ rest %.0f); %d stages -> per stage wait %.0f issue %.0f mma %.0f end %.0f'
           % ((B, Cin, Cout, H, W, ks), NT, variant, narrow, tm, split, ms * 1e3, fl / ms / 1e9, len(t), m[4], m[5], m[0], m[1], m[2], m[3], m[6],
              m[4] - m[5] - m[0] - m[1] - m[2] - m[3] - m[6], int(m[7]), m[0] / m[7], m[1] / m[7], m[2] / m[7], m[3] / m[7]), flush=True)
+    print('      of the issue phase, patch loads of the next chunk: %.0f cycles per wave (%.1f %% of the wave)' % (tload, 100.0 * tload / m[4]), flush=True)

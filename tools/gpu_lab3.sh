@@ -81,6 +81,18 @@ ab_layout)
     PNSFM_PATCH_LAYOUT=$m PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-extra > $O/bench_layout${m}_$TAG.log 2>&1
     echo "layout $m: $(tail -1 $O/bench_layout${m}_$TAG.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'], 'img/s  fwd+dgrad', r['achieved'], 'TF  wgrad', r['wgrad_kernel']['achieved'], 'TF')")"
   done; done ;;
+c3)
+  echo "== 384x1280 batch 2 (BASELINE configs[2] shape): bench + layer table, rocprofv3 kernel summary, PMC traffic passes"
+  C3="--height 384 --width 1280 --batch 2"
+  PNSFM_TUNE_DB=$DB timeout 900 python bench.py $C3 --steps 8 --warmup 2 --no-cpu-baseline --no-extra --layer-table $O/layers_c3_$TAG.csv > $O/bench_c3_$TAG.log 2>&1
+  tail -1 $O/bench_c3_$TAG.log | cut -c1-300
+  (cd /tmp && PNSFM_TUNE_DB=$DB timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3_$TAG -o bench -- \
+      python $R/bench.py $C3 --steps 4 --warmup 2 --no-cpu-baseline --no-extra > $O/rocprof_c3_$TAG.log 2>&1)
+  for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    (cd /tmp && PNSFM_TUNE_DB=$DB timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_c3_${TAG}_$c -o bench -- \
+      python $R/bench.py $C3 --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-extra > $O/pmc_c3_${TAG}_$c.log 2>&1)
+  done
+  python tools/pmc_traffic.py $(find $O/pmc_c3_${TAG}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_c3_${TAG}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/traffic_c3_$TAG.json $O/layers_c3_$TAG.csv 384,1280,2 | head -6 ;;
 bench_graph)
   echo "== bench, whole step replayed as a hipGraph (same database)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --graph on --no-cpu-baseline --no-extra --no-prof > $O/bench_graph_$TAG.log 2>&1

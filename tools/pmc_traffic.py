@@ -53,7 +53,7 @@ if layer_csv:
     for name, a in acc.items():
         if name in res and a[1]:
             res[name]['algorithmic_bytes_per_launch'] = a[0] / a[1]
-res['workload_shape'] = [192, 640, 4]      # H, W, batch of the bench.py run the passes were collected on (bench.py only quotes
+res['workload_shape'] = [int(v) for v in sys.argv[5].split(',')] if len(sys.argv) > 5 else [192, 640, 4]      # H, W, batch of the bench.py run the passes were collected on (bench.py only quotes
                                            # these numbers for that workload)
 res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` with a '
                 'primed tuning database (PNSFM_TUNE_DB: every launch is a training-step launch, no autotune candidates); '

@@ -198,19 +198,17 @@ def measured_traffic(H, W, B):
     counters cannot be collected from inside this process).  Only returned for the workload the passes were collected on
     (192x640 batch 4 unless the file says otherwise): None for any other shape, and None if no profile has been committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        shape = tuple(d.get('workload_shape', (192, 640, 4)))
-        if shape != (H, W, B):
-            return None
-        d = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
-        return {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
-                round(d.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic*.json')), reverse=True):      # latest round first
+        try:
+            d = json.load(open(f))
+            if tuple(d.get('workload_shape', (192, 640, 4))) != (H, W, B):
+                continue
+            k = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
+            return {'hbm_bytes_per_launch': round(k['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
+                    round(k.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def _self_launch(args):

@@ -100,7 +100,7 @@ class PackedConvWeight:
 # -- rebuilds the device table when the set of (parameter, buffers) changed, runs pnsfm_conv2d_pack_table and stamps the caches
 # with the new key, so the next forward finds them fresh.  PNSFM_PACK_BATCH=0 keeps the lazy path only.
 _PACK_REG = {}          # id(cache) -> (weakref(cache), weakref(parameter))
-_PACK_TABLES = {}       # device -> [signature, table tensor, n items, blocks, [(cache ref, parameter ref)] covered]
+_PACK_TABLES = {}       # device -> [signature, table tensor, n items, blocks, indices of the covered (cache, parameter) pairs]
 
 
 def _register_packed(cache, weight):
@@ -133,12 +133,13 @@ def repack_all():
         tab = _PACK_TABLES.get(dev)
         if tab is None or tab[0] != sig:
             table, n, blocks, covered = ops.conv2d_pack_table_build([(w.detach(), c.wp_fwd, c.wp_bwd) for c, w in pairs], dev)
-            tab = _PACK_TABLES[dev] = [sig, table, n, blocks, [pairs[i] for i in covered]]
+            tab = _PACK_TABLES[dev] = [sig, table, n, blocks, covered]      # (indices into `pairs`: no strong references kept)
         if not tab[2]:
             continue
         with torch.cuda.device(dev) if dev.type == 'cuda' else _nullctx():
             ops.conv2d_pack_table_run(tab[1], tab[2], tab[3])
-        for c, w in tab[4]:
+        for i in tab[4]:
+            c, w = pairs[i]
             c.key_fwd = c.key_bwd = PackedConvWeight.key_of(w)
         done += len(tab[4])
     return done

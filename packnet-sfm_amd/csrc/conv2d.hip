@@ -87,7 +87,9 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   g.mode = (W % 32 == 0) ? 0 : 1;
   g.NT = NT;
   if (tm == 1 || tm == 2) {
-    if (W % 32 == 0) return false;                       // the 32-wide tiles already are rectangles there
+    // (on 32-multiple widths the default tiles already are 32 x 4*NT rectangles; the 16 x 8*NT ones are offered there for the 5x5 /
+    // 7x7 layers only: 22 x 22 staged pixels instead of 14 x 38 for 256 outputs of a 7x7, which also fits the register prefetch)
+    if (W % 32 == 0 && (tm == 2 || ks < 5)) return false;
     g.TW = tm == 1 ? 16 : W;
     g.TH = tm == 1 ? 8 * NT : (128 * NT) / W;
     if (g.TH < 1 || (tm == 1 && W < 16)) return false;
@@ -986,7 +988,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       float best_ms = 1e30f;
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
-      const int nTM = (bx3 && W % 32 != 0) ? 3 : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
+      const int nTM = (bx3 && (W % 32 != 0 || ks >= 5)) ? (W % 32 != 0 ? 3 : 2) : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
       const int nVar = bx3 ? 4 : 3;                       // LDS plans: f32 0..2, split-bf16 3..6 (6 = three workgroups per CU)
       for (int cfgt = 0; cfgt < 2 * nVar * nMT * nTM; ++cfgt) {
         const int cfg = cfgt % (2 * nVar * nMT), tm = cfgt / (2 * nVar * nMT);

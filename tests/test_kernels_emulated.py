@@ -163,11 +163,13 @@ def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
 
 
 @pytest.mark.parametrize('cfg', [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2)])
-@pytest.mark.parametrize('shape', [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7)])
+@pytest.mark.parametrize('shape', [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7),
+                                   (1, 16, 32, 18, 64, 7), (1, 32, 16, 10, 32, 5)])
 def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):
     """Tile modes of the split-bf16 kernels for maps whose width is not a multiple of 32 (24x80, 12x40, 6x20 in PackNet01), pinned
     like the autotuner does: cfg = (NT, variant, narrow-M, K-split, tile mode) with tile mode 1 = 16-wide rectangles (16 x 8*NT),
-    2 = bands of whole rows (W x floor(128*NT / W)); ragged last tiles in both directions, heights below the tile height."""
+    2 = bands of whole rows (W x floor(128*NT / W)); ragged last tiles in both directions, heights below the tile height.  The last
+    two shapes are 32-multiple widths, where the 16-wide rectangles are offered to 5x5 / 7x7 layers only (a pinned band falls back)."""
     import ctypes
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops

@@ -1599,7 +1599,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
       if (v4_ok) {     // nine-taps kernel: ci tiles per workgroup x tile width x pixel splits around two workgroups per CU
         for (int WCI = 1; WCI <= 2; ++WCI)
           for (int tgi = 0; tgi < (W0 > 24 ? 2 : 1); ++tgi) {
-            const int TG = W0 > 24 ? 4 + tgi : 3, TR = wgrad4_TR(H0, 0);
+            const int TG = W0 > 24 ? 4 + tgi : 3, TR = TG == 3 ? wgrad4_TR(H0, 0) : 4;
             if (W0 > 24 && round_up(W0, 8 * TG) > round_up(W0, 8 * (9 - TG)) + 8) continue;      // clearly the more wasteful width
             const int tiles4 = wgrad4_total_tiles(B, H0, W0, TG, TR), base4 = wgrad4_base_blocks(Cin, Cout, WCI);
             const int cfg = WCI | (TG << 4) | (TR << 8);

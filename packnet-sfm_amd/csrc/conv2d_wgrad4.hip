@@ -362,7 +362,8 @@ int enqueue_wgrad4(const float* x, const float* dy, float* dw, float* dbias, int
     return -1;
   }
   const int WCI = (cfg & 15) == 1 ? 1 : 2;
-  const int TG = wgrad4_TG(W, (cfg >> 4) & 15), TR = wgrad4_TR(H, (cfg >> 8) & 15);
+  const int TG = wgrad4_TG(W, (cfg >> 4) & 15);
+  const int TR = TG == 3 ? wgrad4_TR(H, (cfg >> 8) & 15) : 4;      // 6-row tiles exist for the 3-group (W <= 24) tiles only
   const bool masked = W % 8 != 0;
   Wgrad4Args a;
   a.x = x; a.dy = dy; a.dw = dw; a.dbias = dbias;
@@ -402,7 +403,6 @@ int enqueue_wgrad4(const float* x, const float* dy, float* dw, float* dbias, int
     else if (TG == 5) PNSFM_W4(WCIv, 5, 4);                                       \
     else PNSFM_W4(WCIv, 4, 4);                                                    \
   } while (0)
-  if (TR == 6 && TG != 3) { set_error("conv2d_backward_weight (nine taps): 6-row tiles exist for 3-group tiles only"); return -1; }
   if (WCI == 1) PNSFM_W4G(1); else PNSFM_W4G(2);
 #undef PNSFM_W4G
 #undef PNSFM_W4

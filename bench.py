@@ -227,7 +227,7 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def roofline_of(timed, iso, value, H, W, B, world, ms_per_step, use_graph, nprof):
+def roofline_of(timed, iso, value, H, W, B, world, ms_per_step, nprof):
     """`roofline` object of one workload from the library's per-launch event timing (pnsfm_prof_*: hipEvents recorded on the
     launch stream around every conv launch of `nprof` eager steps)."""
     from packnet_sfm.hip import functional as HF
@@ -256,8 +256,7 @@ def roofline_of(timed, iso, value, H, W, B, world, ms_per_step, use_graph, nprof
                         'sustains 1838 TFLOP/s bf16 = 306 fp32-equivalent on this part (tools/micro/bf16x3_check.hip)'
                         % (6 * ach)) if bx3 else 'v_mfma_f32_32x32x2_f32 dense peak',
         'vs_f32_mfma_peak': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-        'measured_in': ('%d eager steps right after the timed region (same kernels and shapes; events cannot bracket nodes of a '
-                        'replayed hipGraph)' if use_graph else '%d eager steps after the timed region') % nprof,
+        'measured_in': '%d steps right after the timed region (same launches; events on the launch stream around each one)' % nprof,
         # HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/rNN_traffic.json) or null
         'traffic': (traffic or {}).get('hbm_bytes_per_launch'), 'traffic_detail': traffic,
         'launches': int(n0), 'avg_launch_ms': round(ms0 / n0, 4), 'flop_per_launch_avg': round(fl0 / n0, 1),
@@ -277,7 +276,7 @@ def roofline_of(timed, iso, value, H, W, B, world, ms_per_step, use_graph, nprof
     }
 
 
-def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, layer_table='', graph=False):
+def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, layer_table=''):
     """W untimed warm-up steps, then exactly K timed steps between barrier + synchronize fences; max over ranks.  Returns the
     measurement (elapsed seconds, final loss, conv-launch timing of a few extra eager steps)."""
     from packnet_sfm.hip import functional as HF
@@ -297,16 +296,12 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The library autotunes every layer shape on first use (timing synchronises, so it cannot happen inside a capture) and
-    # the caching allocator settles over the first steps: two untimed EAGER steps always run first, whatever --warmup says.
+    # The library autotunes every layer shape on first use (timing synchronises) and the caching allocator settles over the
+    # first steps: two untimed steps always run first, whatever --warmup says.
     for _ in range(2):
         eager_step()
     fence()
     step = eager_step
-    if graph:
-        from packnet_sfm.hip.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, optimizer, batch, progress=0.0)
-        step = lambda: graphed(batch)      # noqa: E731  (copies the batch into the static inputs, draws the flip, replays)
     for _ in range(warmup):
         loss = step()
     fence()
@@ -329,9 +324,9 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
            'exposed_allreduce_ms_per_step': (round(exposed / steps, 4) if exposed is not None else None)}
 
     # ---- roofline of the dominant kernel: per-launch hipEvent timing inside the library (pnsfm_prof_*), on the stream
-    # each kernel is launched on.  Events cannot bracket the nodes of a replayed graph, so the SAME step is run eagerly
-    # for a few extra steps right after the timed region: (a) as trained and (b), when weight gradients run on a side stream,
-    # with that stream off, i.e. each kernel alone (kernel quality).  rocprofv3 of this command shows the same kernels.
+    # each kernel is launched on, over a few extra steps right after the timed region: (a) as trained and (b), when weight
+    # gradients run on a side stream, with that stream off, i.e. each kernel alone (kernel quality).  rocprofv3 of this command
+    # shows the same kernels.
     if want_prof:
         def profiled(nsteps):
             eager_step()
@@ -372,11 +367,6 @@ def main():
                          'single-GPU run appends to its JSON line as `extra`')
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
-    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='replay the whole step as a hipGraph (packnet_sfm/hip/graph.py).  auto = off: measured on MI355X the replay is '
-                         '3-5 %% SLOWER than eager launches (84-85 vs 88-90 img/s; the step is GPU-bound, eager already hides '
-                         'launch latency behind kernels, and the graph serialises the weight-gradient side stream) -- kept as '
-                         'an option and parity-tested; never available for N>1 (RCCL all-reduces start from autograd hooks)')
     ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps here')
     args = ap.parse_args()
 
@@ -400,26 +390,23 @@ def main():
     model = build_model(device, args.depth_net)
     force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
     ddp = world > 1 or force_ddp
-    use_graph = args.graph == 'on'
-    if use_graph and ddp:
-        raise SystemExit('--graph on is for 1 GPU (collectives are launched from autograd hooks, outside any capture)')
     groups = [{'name': 'Depth', 'params': list(model.depth_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0},
               {'name': 'Pose', 'params': list(model.pose_net.parameters()), 'lr': 2e-4, 'weight_decay': 0.0}]
     if args.optimizer == 'flat':
         from packnet_sfm.rccl.flat_adam import FlatAdam
         optimizer = FlatAdam(groups)
     else:
-        optimizer = torch.optim.Adam(groups, fused=True, capturable=use_graph)
+        optimizer = torch.optim.Adam(groups, fused=True)
     if ddp:
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                              compression=hvd.Compression.none, force_collectives=force_ddp)
     ctx = {'rank': rank, 'world': world, 'device': device, 'ddp': ddp}
 
     m = run_workload(model, optimizer, H, W, B, args.steps, args.warmup, ctx, want_prof=not args.no_prof,
-                     layer_table=args.layer_table, graph=use_graph)
+                     layer_table=args.layer_table)
     # configs[2] shape on the same model and optimizer, right behind the headline measurement (single GPU, default shape only)
     extra = None
-    if world == 1 and not ddp and (H, W, B) == (192, 640, 4) and not args.no_extra and not use_graph and args.depth_net == 'PackNet01':
+    if world == 1 and not ddp and (H, W, B) == (192, 640, 4) and not args.no_extra and args.depth_net == 'PackNet01':
         extra = run_workload(model, optimizer, 384, 1280, 2, 6, 1, ctx, want_prof=not args.no_prof)
 
     if rank == 0:
@@ -428,7 +415,7 @@ def main():
             ms_step = 1e3 * meas['elapsed'] / steps
             roof = None
             if meas['timed'] is not None:
-                roof = roofline_of(meas['timed'], meas['iso'], value, H, W, B, world, ms_step, use_graph, meas['nprof'])
+                roof = roofline_of(meas['timed'], meas['iso'], value, H, W, B, world, ms_step, meas['nprof'])
             return value, ms_step, roof
 
         value, ms_step, roofline = line_of(m, H, W, B, args.steps, args.warmup)
@@ -453,7 +440,7 @@ def main():
                        'tuning': ('user database %s' % os.environ['PNSFM_TUNE_DB']) if os.environ.get('PNSFM_TUNE_DB') else
                                  ('shipped database (%d decisions) + autotune for unlisted shapes' % ops.tune_shipped_entries()
                                   if ops.tune_shipped_entries() else 'autotune during warm-up'),
-                       'step_launch': 'hipGraph replay (one graph per flip state)' if use_graph else 'eager',
+                       'step_launch': 'eager',
                        'collective_backend': backend, 'devices_visible': ndev,
                        # ranks of the RCCL communicator the gradient all-reduce ran on (null: single process, no collective)
                        'rccl_ranks': dist.get_world_size() if (dist.is_initialized() and backend == 'nccl') else None},

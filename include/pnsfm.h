@@ -13,10 +13,8 @@
  *   - outputs and named workspaces are caller-allocated.  The ONE exception: the two-stage reductions (pixel-split weight
  *     gradients, the loss scalars) keep their partial sums in a grow-only scratch buffer the library hipMalloc's itself, one per
  *     (device, stream), outside the caller's allocator (csrc/api.hip: a few KB .. tens of MB; a buffer that has to grow is
- *     replaced and the old one freed once the stream has passed it).  Launches captured into a hipGraph use one of four
- *     per-device capture buffers instead, sized by the largest un-captured request so far (run one warm-up step before
- *     capturing, as torch's recipe does) and never moved afterwards; a request they cannot serve becomes a stream-ordered
- *     allocation, i.e. memory nodes of the graph (PNSFM_CAPTURE_SCRATCH=0 forces that);
+ *     replaced and the old one freed once the stream has passed it).  Entry points that need this scratch fail with an
+ *     error while `stream` is being captured into a hipGraph (no capture path since round 4);
  *   - return value: 0 on success, non-zero on error (pnsfm_last_error() has the message).
  */
 #ifndef PNSFM_H

@@ -34,7 +34,7 @@ int check_launch(const char* what) {
 // the next ON THE SAME STREAM.  The library keeps one grow-only device buffer per (device, stream) -- the null stream's handle is
 // the same on every device, so the device is part of the key: stream order already serialises its users, so nothing is
 // allocated, freed or synchronised in steady state (hipMallocAsync / hipFreeAsync per call measured -3.3 % on the training
-// step: 126.2 -> 121.8 img/s), and the pointers are stable under hipGraph capture.  This is the ONE place the library owns
+// step: 126.2 -> 121.8 img/s).  This is the ONE place the library owns
 // device memory (include/pnsfm.h): a buffer that has to grow is replaced, and the old one -- kernels already enqueued may
 // still use it -- is retired behind an event recorded on its stream and freed by a later call once that event has completed
 // (growth only happens while the first steps discover the sizes).
@@ -60,65 +60,15 @@ static void scratch_reap(int dev) {      // g_scratch_mu held
 }
 #endif
 
-// Captured launches cannot grow a buffer (hipMalloc is illegal during capture) and stream-ordered allocations would turn every
-// two-stage reduction into a pair of graph memory nodes (slow to replay, and replays of such graphs were seen to return
-// transiently wrong sums on ROCm 7.0).  Instead every device keeps kCapBufs capture buffers, grown EAGERLY to the largest
-// request any un-captured call has made on that device (frameworks run a warm-up step before they capture: torch's recipe does),
-// and handed out per capturing stream -- parallel branches of one capture (a side stream) get different buffers.  A buffer that
-// was ever handed to a capture is never freed or moved: graphs hold its address.  Requests that do not fit (no warm-up, more
-// than kCapBufs capturing streams) fall back to hipMallocAsync / hipFreeAsync.  PNSFM_CAPTURE_SCRATCH=0 forces that fallback.
-struct CapBuf { int dev; hipStream_t stream; bool used; void* p; size_t cap; };
-static constexpr int kCapBufs = 4;
-static std::vector<CapBuf> g_capbuf;
-#ifndef PNSFM_EMU
-static bool capbuf_enabled() {
-  static const bool on = [] { const char* e = getenv("PNSFM_CAPTURE_SCRATCH"); return !(e && e[0] == '0'); }();
-  return on;
-}
-static void capbuf_grow(int dev, size_t cap) {      // g_scratch_mu held, not capturing
-  if (!capbuf_enabled()) return;
-  int have = 0;
-  for (auto& c : g_capbuf)
-    if (c.dev == dev) {
-      ++have;
-      if (c.cap >= cap) continue;
-      void* p = nullptr;
-      if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); continue; }
-      if (!c.used && c.p) (void)hipFree(c.p);      // a buffer some graph may address stays alive
-      c.p = p; c.cap = cap; c.used = false; c.stream = nullptr;
-    }
-  for (; have < kCapBufs; ++have) {
-    void* p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return; }
-    g_capbuf.push_back(CapBuf{dev, nullptr, false, p, cap});
-  }
-}
-static void* capbuf_get(int dev, hipStream_t stream, size_t bytes) {      // g_scratch_mu held
-  if (!capbuf_enabled()) return nullptr;
-  for (auto& c : g_capbuf)
-    if (c.dev == dev && c.used && c.stream == stream && c.cap >= bytes) return c.p;
-  for (auto& c : g_capbuf)
-    if (c.dev == dev && !c.used && c.cap >= bytes) { c.used = true; c.stream = stream; return c.p; }
-  return nullptr;
-}
-#endif
-
-void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
-  *async_owned = false;
+void* scratch_get(hipStream_t stream, size_t bytes) {
   int dev = 0;
 #ifndef PNSFM_EMU
   if (hipGetDevice(&dev) != hipSuccess) { set_error("scratch: hipGetDevice failed"); return nullptr; }
   if (stream_capturing(stream)) {
-    {
-      std::lock_guard<std::mutex> lk(g_scratch_mu);
-      if (void* p = capbuf_get(dev, stream, bytes)) return p;
-    }
-    // no capture buffer of that size: a stream-ordered allocation becomes a pair of memory nodes of the graph (the caller hands
-    // it back through scratch_release)
-    void* p = nullptr;
-    if (hipMallocAsync(&p, bytes, stream) != hipSuccess || !p) { set_error("cannot allocate %zu bytes of scratch (capture)", bytes); return nullptr; }
-    *async_owned = true;
-    return p;
+    // Round 4 removed the hipGraph path (whole-step replay measured no faster than eager launches and its capture buffers were the
+    // library's only state a graph could dangle on): a two-stage reduction cannot take scratch inside a capture.
+    set_error("scratch: the stream is being captured into a hipGraph -- launches that need reduction scratch are not capturable");
+    return nullptr;
   }
 #endif
   std::lock_guard<std::mutex> lk(g_scratch_mu);
@@ -143,21 +93,12 @@ void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned) {
       else
         (void)hipGetLastError();        // cannot track it: keep it alive (a one-off, bounded by the growth steps)
     }
-    if (p) capbuf_grow(dev, cap);
 #endif
     if (!p) { set_error("cannot allocate %zu bytes of scratch", cap); return nullptr; }
     sc->p = p;
     sc->cap = cap;
   }
   return sc->p;
-}
-
-void scratch_release(void* p, hipStream_t stream, bool async_owned) {
-#ifndef PNSFM_EMU
-  if (async_owned && p) (void)hipFreeAsync(p, stream);
-#else
-  (void)p; (void)stream; (void)async_owned;
-#endif
 }
 
 int block_map_mode() {

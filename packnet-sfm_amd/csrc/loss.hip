@@ -603,8 +603,7 @@ __global__ void photometric_clip_finish_kernel(const double* __restrict__ stats,
   }
 }
 
-// per-workgroup partial sums of a two-stage reduction live in the stream's scratch buffer (api.hip; ScratchLease hands a
-// capture-time allocation back on every return path)
+// per-workgroup partial sums of a two-stage reduction live in the stream's scratch buffer (api.hip: ScratchLease)
 
 int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const float* target, double* loss_sum,
                                    uint8_t* argmin, int J, int B, int H, int W, float ssim_weight, float C1, float C2,

@@ -158,16 +158,11 @@ namespace pnsfm {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 // grow-only device scratch of the given (device, stream) (api.hip): valid until the next scratch_get on the same stream; null on
-// failure.  Under hipGraph capture it is a stream-ordered allocation instead (*async_owned): always pair with scratch_release --
-// ScratchLease does (every return path of an entry point hands a captured allocation back).
-void* scratch_get(hipStream_t stream, size_t bytes, bool* async_owned);
-void scratch_release(void* p, hipStream_t stream, bool async_owned);
+// failure (also when the stream is being captured into a hipGraph: the library's two-stage reductions are not capturable).
+void* scratch_get(hipStream_t stream, size_t bytes);
 struct ScratchLease {
   void* p;
-  hipStream_t stream;
-  bool async_owned;
-  ScratchLease(hipStream_t s, size_t bytes) : p(nullptr), stream(s), async_owned(false) { if (bytes) p = scratch_get(s, bytes, &async_owned); }
-  ~ScratchLease() { if (p) scratch_release(p, stream, async_owned); }
+  ScratchLease(hipStream_t s, size_t bytes) : p(nullptr) { if (bytes) p = scratch_get(s, bytes); }
   ScratchLease(const ScratchLease&) = delete;
   ScratchLease& operator=(const ScratchLease&) = delete;
   template <class T> T* as() const { return static_cast<T*>(p); }

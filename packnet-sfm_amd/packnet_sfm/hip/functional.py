@@ -33,6 +33,7 @@ def set_conv_math(mode):
     m = {'bx3': 1, 'f32': 0, 1: 1, 0: 0}[mode]
     prev = _lib.get().pnsfm_set_conv_math(m)
     bump_weight_epoch()
+    _PACK_TABLES.clear()      # the batched packer's device table records which weights the mode covers (and their layout)
     return 'bx3' if prev else 'f32'
 
 
@@ -129,7 +130,9 @@ def repack_all():
         by_dev.setdefault(w.device, []).append((c, w))
     done = 0
     for dev, pairs in by_dev.items():
-        sig = tuple((w.data_ptr(), tuple(w.shape), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
+        # the table's coverage and layout follow from the arithmetic mode too (a table built under 'bx3' replayed after
+        # set_conv_math('f32') wrote split-bf16 bytes into f32-layout buffers and stamped them fresh)
+        sig = (get_conv_math(),) + tuple((w.data_ptr(), tuple(w.shape), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
         tab = _PACK_TABLES.get(dev)
         if tab is None or tab[0] != sig:
             table, n, blocks, covered = ops.conv2d_pack_table_build([(w.detach(), c.wp_fwd, c.wp_bwd) for c, w in pairs], dev)

@@ -39,8 +39,8 @@ class SfmModel(BaseModel):
             return flip_output(self.depth_net(**flip_batch_input(net_input)))
         return self.depth_net(**net_input)
 
-    # set by hip/graph.py while it captures one hipGraph per flip state (the flip is Python control flow, so it cannot be
-    # decided inside a captured step) and by tests; None = draw it here as the reference does (SfmModel.py:84)
+    # set by tests that need an explicit flip state (Python's global RNG is shared with the rest of the process);
+    # None = draw it here as the reference does (SfmModel.py:84)
     _flip_override = None
 
     def _draw_flip(self, force_flip):

@@ -16,8 +16,9 @@ LIB = os.path.join(HERE, "libpnsfm_emu.so")
 
 def build_emu(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.abspath(__file__), os.path.join(CSRC, "pnsfm_common.h"), os.path.join(HERE, "hipemu.h"),
-                   os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))      # conv2d_bx3.h holds the dominant kernel
+    deps = srcs + headers + [os.path.abspath(__file__), os.path.join(HERE, "hipemu.h"),
+                             os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")

@@ -677,6 +677,51 @@ def test_batched_repack_after_the_optimizer_step(emulated_kernels):
         opt._slots.remove()
 
 
+def test_batched_repack_follows_the_arithmetic_mode(emulated_kernels):
+    """the device pack table is built for ONE arithmetic mode (which weights it covers, and the split-bf16 layout it
+    writes).  Switching hip.functional.set_conv_math between two FlatAdam steps must rebuild it: after the switch every packed
+    buffer equals the per-layer packer's output for the mode in force, both directions of the switch."""
+    from packnet_sfm.hip import _lib, functional as HF, ops
+    from packnet_sfm.networks.layers.packnet.layers01 import _HipConv2d
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    torch.manual_seed(6)
+    layers = [_HipConv2d(16, 32, 3), _HipConv2d(32, 24, 3)]
+    net = torch.nn.Sequential(*layers)
+    opt = FlatAdam([{'params': list(net.parameters()), 'lr': 1e-2}])
+    x = torch.randn(1, 16, 6, 8, requires_grad=True)
+
+    def fwd_bwd():
+        opt.zero_grad()
+        y = net(x)
+        y.pow(2).mean().backward()
+        return y.detach().clone()
+
+    def check_packed(tag):
+        for l in layers:
+            c = l._packed
+            # (packed into CLONES of the cache's buffers: bytes beyond the mode's layout are don't-care and stay equal)
+            f, b = ops.conv2d_pack(l.weight.detach().contiguous(), c.wp_fwd.clone(), c.wp_bwd.clone())
+            assert torch.equal(f, c.wp_fwd), tag + ': forward pack is stale / in the wrong layout'
+            assert torch.equal(b, c.wp_bwd), tag + ': backward pack is stale / in the wrong layout'
+
+    try:
+        for first, second in (('bx3', 'f32'), ('f32', 'bx3')):
+            HF.set_conv_math(first)
+            fwd_bwd()
+            opt.step()                       # builds the table under `first`
+            HF.set_conv_math(second)
+            fwd_bwd()                        # lazy re-pack in the new layout (new buffers)
+            opt.step()                       # the batched launch must not replay the old table
+            y = fwd_bwd()                    # (weights the new mode's table does not cover re-pack lazily here)
+            check_packed('%s -> %s' % (first, second))
+            ref = torch.nn.functional.conv2d(torch.nn.functional.conv2d(x.detach(), layers[0].weight, layers[0].bias, padding=1),
+                                             layers[1].weight, layers[1].bias, padding=1)
+            P.check(y, ref, 1e-5, 'forward after the mode switch')
+    finally:
+        HF.set_conv_math('bx3')
+        opt._slots.remove()
+
+
 def test_flat_adam_skips_parameters_without_gradient(emulated_kernels):
     """torch.optim.Adam skips a parameter whose .grad is None (value and moments frozen); FlatAdam's flat launch must leave such
     parameters untouched too (they used to decay on stale momentum)."""

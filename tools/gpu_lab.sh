@@ -14,7 +14,7 @@ for w in $WHAT; do case $w in
 tests)
   echo "== pytest (selected)"
   timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 -x \
-    -k "${PYTEST_K:-conv2d_vs_cpu_oracle or tap_major or graphed or accumulation or trainer_fit or 384x1280 or training_step_golden or groupnorm}" \
+    -k "${PYTEST_K:-conv2d_vs_cpu_oracle or tap_major or accumulation or trainer_fit or 384x1280 or training_step_golden or groupnorm}" \
     > $O/pytest_$TAG.log 2>&1
   tail -15 $O/pytest_$TAG.log ;;
 alltests)
@@ -32,8 +32,8 @@ bench)
   PNSFM_TUNE_LOG=$O/tunelog_$TAG.txt timeout 900 python bench.py --steps 10 --warmup 3 --layer-table $O/layers_$TAG.csv > $O/bench_$TAG.log 2>&1
   tail -2 $O/bench_$TAG.log | cut -c1-1800 ;;
 bench_eager)
-  echo "== bench --graph off"
-  timeout 600 python bench.py --steps 10 --warmup 3 --graph off --no-cpu-baseline > $O/bench_eager_$TAG.log 2>&1
+  echo "== bench"
+  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_eager_$TAG.log 2>&1
   tail -1 $O/bench_eager_$TAG.log | cut -c1-600 ;;
 bench_c3)
   echo "== bench 384x1280 batch 2 (configs[2] shape)"
@@ -57,14 +57,14 @@ prof_iso)
   tail -1 $O/rocprof_iso_$TAG.log | cut -c1-400 ;;
 prof_eager)
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_eager_$TAG -o bench -- \
-      python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --graph off > $O/rocprof_eager_$TAG.log 2>&1)
+      python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/rocprof_eager_$TAG.log 2>&1)
   tail -1 $O/rocprof_eager_$TAG.log | cut -c1-400 ;;
 pmc)
   echo "== rocprofv3 PMC passes (counters only, separate runs)"
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)
     (cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${TAG}_$n -o bench -- \
-      python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof --graph off > $O/pmc_${TAG}_$n.log 2>&1)
+      python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/pmc_${TAG}_$n.log 2>&1)
     tail -1 $O/pmc_${TAG}_$n.log | cut -c1-300
   done ;;
 esac; done

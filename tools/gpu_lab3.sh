@@ -93,10 +93,6 @@ c3)
       python $R/bench.py $C3 --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-extra > $O/pmc_c3_${TAG}_$c.log 2>&1)
   done
   python tools/pmc_traffic.py $(find $O/pmc_c3_${TAG}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_c3_${TAG}_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/traffic_c3_$TAG.json $O/layers_c3_$TAG.csv 384,1280,2 | head -6 ;;
-bench_graph)
-  echo "== bench, whole step replayed as a hipGraph (same database)"
-  PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 15 --warmup 3 --graph on --no-cpu-baseline --no-extra --no-prof > $O/bench_graph_$TAG.log 2>&1
-  tail -1 $O/bench_graph_$TAG.log | cut -c1-200 ;;
 bench2)
   echo "== bench again on the primed database (run-to-run spread)"
   PNSFM_TUNE_DB=$DB timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --no-prof > $O/bench2_$TAG.log 2>&1

@@ -14,7 +14,8 @@
 //   * v_mfma_f32_32x32x2_f32 (A: lane l holds W[m = l&31][k = l>>5], B: lane l holds X[k = l>>5][n = l&31]),
 //     i.e. two input channels per instruction, exact fp32 (bitwise an fmaf chain) -- no TF32/bf16 shortcut;
 //   * K (= taps x channels) can be split across blockIdx.z for the low-resolution layers whose pixel
-//     count cannot fill 256 CUs (pack4/pack5: 480 pixels, K = 147456); partial sums meet with fp32 atomics.
+//     count cannot fill 256 CUs (pack4/pack5: 480 pixels, K = 147456); the splits' partial outputs are summed in a
+//     fixed order by a second kernel (conv_splitk_reduce_kernel; round 4 -- fp32 atomics before).
 // Roofline: MFMA-bound. 2*Cout*Cin*k*k*B*H*W flop per launch against the 157.3 TFLOP/s fp32 matrix peak.
 #include "pnsfm_common.h"
 #include <cstring>
@@ -343,6 +344,7 @@ struct ConvArgs {
   const float* wp;    // [KK][KP][MP]
   const float* bias;  // [Cout] or null
   float* y;           // [B][Cout][H][W]
+  float* ws;          // K-split launches: [splitK][B][Cout][H][W] partial outputs (stream scratch), summed by conv_splitk_reduce_kernel
   int B, Cin, Cout, H, W, KS;   // H, W: OUTPUT size
   int S, Hi, Wi;                // stride (1 | 2) and INPUT size (Hi = H, Wi = W when S == 1)
   int CI, mode, tiles_x, tiles_per_img, PH, PW, KP, MP, nchunks, chunks_per_split, splitK;
@@ -366,15 +368,19 @@ __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 
 // ---- epilogue shared by the forward / backward-data kernels: D row = (r&3) + 8*(r>>2) + 4*half, col = l32.
 // The 16*MT bias values a lane needs are fetched up front in ONE batch (the store loop used to fetch each one right
-// before its store and wait for it: 32 dependent L2 round trips per workgroup), and the plain-store / atomic (split-K)
+// before its store and wait for it: 32 dependent L2 round trips per workgroup).
 // paths are separate loops so the compiler can stream the stores.
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int co0, int half,
-                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], bool first_split) {
+                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], int bz) {
   const int HW = a.H * a.W;
-  float* yb = a.y + (size_t)b * a.Cout * HW;
-  const bool add_bias = a.bias != nullptr && first_split;      // one K split adds the bias
-  if (add_bias) {
+  // K-split launches: every split stores its partial tile into its own slab of the workspace (plain stores; no zero-fill, no
+  // atomics) and conv_splitk_reduce_kernel adds the slabs in split order, bias included -- the result does not depend on which
+  // workgroup finishes first (round 3 met the splits with fp32 atomics in a zero-filled y: 97 fills per step, and two runs of
+  // one step differed in the last bits)
+  const bool split = a.splitK > 1;
+  float* yb = split ? a.ws + ((size_t)bz * a.B + b) * a.Cout * HW : a.y + (size_t)b * a.Cout * HW;
+  if (a.bias != nullptr && !split) {
     float bval[MT][16];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -393,26 +399,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
   int poff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) poff[nt] = oy[nt] * a.W + ox[nt];
-  if (a.splitK == 1) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          if (co < a.Cout && pvalid[nt]) yb[(size_t)co * HW + poff[nt]] = acc[mt][nt][r];
-      }
+      for (int nt = 0; nt < NT; ++nt)
+        if (co < a.Cout && pvalid[nt]) yb[(size_t)co * HW + poff[nt]] = acc[mt][nt][r];
+    }
+}
+
+// second stage of a K-split launch: y = bias + sum over the splits' slabs, in split order (bit-reproducible)
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int Z, int Cout, int HW, size_t total) {
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  if ((HW & 3) == 0) {                 // (then total % 4 == 0 and the four elements share a channel)
+    float4 s = *reinterpret_cast<const float4*>(ws + i4);
+    for (int z = 1; z < Z; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)z * total + i4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) { const float bv = bias[(i4 / HW) % Cout]; s.x += bv; s.y += bv; s.z += bv; s.w += bv; }
+    *reinterpret_cast<float4*>(y + i4) = s;
   } else {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          if (co < a.Cout && pvalid[nt]) atomicAdd(yb + (size_t)co * HW + poff[nt], acc[mt][nt][r]);
-      }
+    for (size_t i = i4; i < i4 + 4 && i < total; ++i) {
+      float s = ws[i];
+      for (int z = 1; z < Z; ++z) s += ws[(size_t)z * total + i];
+      if (bias) s += bias[(i / HW) % Cout];
+      y[i] = s;
+    }
   }
 }
 
@@ -597,7 +614,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if constexpr (DMA) dma_cur ^= 1;
   }
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, blockIdx.z == 0);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z);
 }
 
 
@@ -831,7 +848,7 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, blockIdx.z == 0);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();
@@ -872,9 +889,13 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.trace = g_trace_buf;
   a.trace_flags = g_trace_flags;
 #endif
+  // K-split launch: partial outputs in the stream's scratch buffer (api.hip), summed in split order by conv_splitk_reduce_kernel
+  const size_t out_elems = (size_t)B * Cout * H * W;
+  ScratchLease lease(stream, g.splitK > 1 ? (size_t)g.splitK * out_elems * sizeof(float) : 0);
+  a.ws = nullptr;
   if (g.splitK > 1) {
-    int e = (int)hipMemsetAsync(y, 0, (size_t)B * Cout * H * W * sizeof(float), stream);
-    if (e) { set_error("%s: memset failed", what); return e; }
+    if (!lease.p) return -1;
+    a.ws = lease.as<float>();
   }
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
@@ -930,7 +951,13 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   } else if (g.DMA) PNSFM_CONV_DISPATCH(true);
   else PNSFM_CONV_DISPATCH(false);
 #undef PNSFM_CONV_DISPATCH
-  return check_launch(what);
+  int rc = check_launch(what);
+  if (!rc && g.splitK > 1) {
+    PNSFM_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)ceil_div_sz(out_elems, 1024)), dim3(256), 0, stream, (const float*)a.ws, bias, y,
+                 g.splitK, Cout, H * W, out_elems);
+    rc = check_launch(what);
+  }
+  return rc;
 }
 
 #ifndef PNSFM_EMU
@@ -1085,14 +1112,31 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   }
 }
 
+// second stage of the pixel-split f32 weight-gradient kernels (this file and conv2d_wgrad2.hip): out = sum over Z slabs, in slab
+// order.  A slab is [n0 floats -> out0 | n1 floats -> out1] (dw, then dbias).
+__global__ void __launch_bounds__(256) sum_slabs_kernel(const float* __restrict__ ws, size_t zstride, int Z, float* __restrict__ out0,
+                                                        size_t n0, float* __restrict__ out1, size_t n1) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n0 + n1) return;
+  float s = ws[i];
+  for (int z = 1; z < Z; ++z) s += ws[(size_t)z * zstride + i];
+  if (i < n0) out0[i] = s; else out1[i - n0] = s;
+}
+int launch_sum_slabs(const float* ws, size_t zstride, int Z, float* out0, size_t n0, float* out1, size_t n1, hipStream_t s) {
+  if (!out1) n1 = 0;
+  PNSFM_LAUNCH(sum_slabs_kernel, dim3((unsigned)ceil_div_sz(n0 + n1, 256)), dim3(256), 0, s, ws, zstride, Z, out0, n0, out1, n1);
+  return check_launch("conv2d_backward_weight (slab sum)");
+}
+
 // ---- backward-weight -------------------------------------------------------------------------------
 // dW[co][n] with n = ci*KK + tap (the reference's [Cout][Cin][k][k] layout, contiguous in n):
 //   dW[co][n] = sum_{b, pixel} dY[co][pixel] * X[ci(n)][pixel + off(tap(n))]
 // GEMM view: M = co (32*MT per block), N = n (4 waves x 32), K = pixels (tiles of PT pixels).
 // A operand: dY tile in LDS [BM][PT+1] (lane m = l&31, k = pixel parity l>>5) -- stride PT+1 is conflict-free;
 // B operand: the halo patch of the <= NCI input channels this n-range touches; each lane owns one (ci, tap)
-// and walks the pixels through a per-tile offset table.  Pixel tiles are split over blockIdx.z and the
-// partial dW meet with fp32 atomics (dW is small next to the activations).
+// and walks the pixels through a per-tile offset table.  Pixel tiles are split over blockIdx.z; each split stores its partial
+// [dW | dbias] into its own slab of the stream's scratch buffer and sum_slabs_kernel adds the slabs in split order (round 4: no
+// atomics, no zero-fill -- the gradient is bit-reproducible, as the split-bf16 kernels' always was).
 struct WgradArgs {
   const float* x;   // [B][Cin][H][W]
   const float* dy;  // [B][Cout][H][W]
@@ -1104,6 +1148,7 @@ struct WgradArgs {
   int S, Hi, Wi; // stride and INPUT (x) size; dY / the pixel tiles live on the OUTPUT grid
   int vec4, PTlog;
   float invPW, invPS;
+  size_t zstride;  // pixel-split launch: floats between the partial [dw | dbias] slabs of consecutive splits (0: un-split)
 };
 
 template <int MT>
@@ -1290,8 +1335,8 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < a.Cout && nvalid) {
-        float* dst = a.dw + (size_t)co * N + n;
-        if (a.splitP == 1) *dst = acc[mt][r]; else atomicAdd(dst, acc[mt][r]);
+        // (pixel-split launch: a.dw / a.dbias point at slab blockIdx.z of the workspace, see enqueue -- plain stores either way)
+        a.dw[(size_t)blockIdx.z * a.zstride + (size_t)co * N + n] = acc[mt][r];
       }
     }
   }
@@ -1300,7 +1345,7 @@ __global__ void __launch_bounds__(256) conv2d_wgrad_kernel(WgradArgs a) {
     bsum += __shfl_down(bsum, 1);
     const int m = tid >> 2;
     if ((tid & 3) == 0 && m < BM && co0 + m < a.Cout) {
-      if (a.splitP == 1) a.dbias[co0 + m] = bsum; else atomicAdd(&a.dbias[co0 + m], bsum);
+      a.dbias[(size_t)blockIdx.z * a.zstride + co0 + m] = bsum;
     }
   }
 }
@@ -1493,19 +1538,23 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     WgradArgs c = a;
     c.tiles_per_split = ceil_div(a.total_tiles, split);
     c.splitP = ceil_div(a.total_tiles, c.tiles_per_split);
-    // un-split: every dw element and every dbias[co] has exactly one writer -> plain stores, nothing to zero.
-    // split over pixel tiles: fp32 atomics into zeroed buffers; one fill covers both when the caller laid dbias right
-    // behind dw (the Python wrapper does), two otherwise.
+    // un-split: every dw element and every dbias[co] has exactly one writer -> plain stores into dw / dbias.
+    // split over pixel tiles: every split writes a whole [dw | dbias] slab of the scratch buffer; sum_slabs_kernel adds them.
+    const size_t slab = (size_t)Cout * N + Cout;
+    ScratchLease lease(s, c.splitP > 1 ? (size_t)c.splitP * slab * sizeof(float) : 0);
+    c.zstride = 0;
     if (c.splitP > 1) {
-      const bool joined = dbias == dw + (size_t)Cout * N;
-      int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
-      if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-      if (e) { set_error("backward_weight: memset failed"); return e; }
+      if (!lease.p) return -1;
+      c.dw = lease.as<float>();
+      c.dbias = dbias ? c.dw + (size_t)Cout * N : nullptr;
+      c.zstride = slab;
     }
     dim3 grid(n_tiles, m_tiles, c.splitP);
     if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_kernel<2>), grid, dim3(256), smem, s, c);
     else PNSFM_LAUNCH((conv2d_wgrad_kernel<1>), grid, dim3(256), smem, s, c);
-    return check_launch("conv2d_backward_weight");
+    int rc = check_launch("conv2d_backward_weight");
+    if (!rc && c.splitP > 1) rc = launch_sum_slabs(c.dw, slab, c.splitP, dw, (size_t)Cout * N, dbias, (size_t)Cout, s);
+    return rc;
   };
   // split-bf16 kernel (conv2d_wgrad3.hip): part of the split arithmetic mode (pnsfm_set_conv_math), the default there
   // split-bf16 kernel: a 1x1 layer has no halo, so its map is handed over as 32-wide rows of the flattened image when that

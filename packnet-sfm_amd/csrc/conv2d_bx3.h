@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, bz == 0);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();

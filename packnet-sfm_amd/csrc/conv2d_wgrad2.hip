@@ -38,6 +38,7 @@ struct Wgrad2Args {
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_per_img, total_tiles, tiles_per_split, splitP;
   int ci_tiles;      // gridDim.x = ci_tiles * (tap groups: KS for a 5x5, 1 otherwise)
+  size_t zstride;    // pixel-split launch: floats between the partial [dw | dbias] slabs of consecutive splits (0: un-split)
 };
 
 template <int KS, int FC>
@@ -228,12 +229,12 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
       for (int row = 0; row < 16; ++row) {
         const int co = co_b + row;
         if (co >= a.Cout) break;
-        float* drow = a.dw + ((size_t)co * a.Cin + ci_w) * KK + ky0 * KS;
+        float* drow = a.dw + (size_t)blockIdx.z * a.zstride + ((size_t)co * a.Cin + ci_w) * KK + ky0 * KS;
         for (int col = lane; col < ncol; col += 64) {
           // KS == 5: a row group covers TG = 5 of the 25 taps of each channel -> runs of 5 floats, 25 apart
           const int dcol = (KS == 5) ? (col / TG) * KK + (col % TG) : col;
           const float v = tb[row * RW + col];
-          if (a.splitP == 1) drow[dcol] = v; else atomicAdd(drow + dcol, v);
+          drow[dcol] = v;        // (pixel-split launch: slab blockIdx.z of the workspace; sum_slabs_kernel adds the slabs)
         }
       }
     }
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256, 1) conv2d_wgrad2_kernel(Wgrad2Args a) {
     bsum += __shfl_down(bsum, 1);
     const int m = tid >> 2;
     if ((tid & 3) == 0 && co0 + m < a.Cout) {
-      if (a.splitP == 1) a.dbias[co0 + m] = bsum; else atomicAdd(&a.dbias[co0 + m], bsum);
+      a.dbias[(size_t)blockIdx.z * a.zstride + co0 + m] = bsum;
     }
   }
 }
@@ -297,23 +298,30 @@ int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int
   a.splitP = ceil_div(a.total_tiles, a.tiles_per_split);
   a.ci_tiles = ceil_div(Cin, 64);
   const size_t N = (size_t)Cin * ks * ks;
+  // pixel-split launch: partial [dw | dbias] slabs in the stream's scratch buffer, added in split order by sum_slabs_kernel
+  const size_t slab = (size_t)Cout * N + Cout;
+  ScratchLease lease(s, a.splitP > 1 ? (size_t)a.splitP * slab * sizeof(float) : 0);
+  a.zstride = 0;
   if (a.splitP > 1) {
-    const bool joined = dbias == dw + (size_t)Cout * N;
-    int e = (int)hipMemsetAsync(dw, 0, ((size_t)Cout * N + (joined ? Cout : 0)) * sizeof(float), s);
-    if (!e && dbias && !joined) e = (int)hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), s);
-    if (e) { set_error("conv2d_backward_weight: memset failed"); return e; }
+    if (!lease.p) return -1;
+    a.dw = lease.as<float>();
+    a.dbias = dbias ? a.dw + (size_t)Cout * N : nullptr;
+    a.zstride = slab;
   }
   dim3 grid(a.ci_tiles * (ks == 5 ? 5 : 1), ceil_div(Cout, 64), a.splitP);
+  int rc = 0;
 #define PNSFM_W2(KSv)                                                     \
   do {                                                                    \
-    if (fc == 32) return launch_wgrad2<KSv, 32>(a, grid, s);              \
-    if (fc == 16) return launch_wgrad2<KSv, 16>(a, grid, s);              \
-    return launch_wgrad2<KSv, 8>(a, grid, s);                             \
+    if (fc == 32) rc = launch_wgrad2<KSv, 32>(a, grid, s);                \
+    else if (fc == 16) rc = launch_wgrad2<KSv, 16>(a, grid, s);           \
+    else rc = launch_wgrad2<KSv, 8>(a, grid, s);                          \
   } while (0)
   if (ks == 1) PNSFM_W2(1);
-  if (ks == 3) PNSFM_W2(3);
-  PNSFM_W2(5);
+  else if (ks == 3) PNSFM_W2(3);
+  else PNSFM_W2(5);
 #undef PNSFM_W2
+  if (!rc && a.splitP > 1) rc = launch_sum_slabs(a.dw, slab, a.splitP, dw, (size_t)Cout * N, dbias, (size_t)Cout, s);
+  return rc;
 }
 
 }  // namespace pnsfm

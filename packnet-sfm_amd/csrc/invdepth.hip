@@ -68,8 +68,7 @@ constexpr int kIdPass = 16;
 
 __global__ void __launch_bounds__(256) invdepth_conv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ dz, float* __restrict__ dx,
-                                                                 float* __restrict__ dw, float* __restrict__ db,
-                                                                 int C, int H, int W, int ppt) {
+                                                                 float* __restrict__ part, int C, int H, int W, int ppt) {
   __shared__ float red[kIdPass * kIdRow];
   const int tid = threadIdx.x;
   const int HW = H * W;
@@ -138,15 +137,24 @@ __global__ void __launch_bounds__(256) invdepth_conv_bwd_kernel(const float* __r
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 1);
     if (rj == 0) {
+      // one slot per (pixel block, image, channel group, value): plain stores, no zero-fill; invdepth_conv_bwd_finish_kernel adds
+      // the pixel blocks in a fixed order (round 3: fp32 atomics into a zero-filled dw / db)
       const int v = pass * kIdPass + rv;
-      if (v < kIdCh * 9) {
-        const int ch = c0 + v / 9;
-        if (ch < C) atomicAdd(&dw[ch * 9 + v % 9], s);
-      } else if (v == kIdCh * 9 && want_db) {
-        atomicAdd(db, s);
-      }
+      if (v < kIdVals) part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * kIdVals + v] = s;
     }
   }
+}
+
+// dw[ch][t] (and db) = sum over the (image, pixel block) partials of the channel's group, in index order
+__global__ void __launch_bounds__(256) invdepth_conv_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                        float* __restrict__ db, int C, int npart, int cgroups) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o > C * 9) return;
+  const int ch = o / 9, t = o - ch * 9;
+  const int cg = o < C * 9 ? ch / kIdCh : 0, v = o < C * 9 ? (ch - cg * kIdCh) * 9 + t : kIdCh * 9;
+  float s = 0.f;
+  for (int p = 0; p < npart; ++p) s += part[((size_t)p * cgroups + cg) * kIdVals + v];
+  if (o < C * 9) dw[o] = s; else if (db) *db = s;
 }
 
 }  // namespace pnsfm
@@ -170,18 +178,20 @@ int pnsfm_invdepth_conv_backward(const float* x, const float* w, const float* dz
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("invdepth_conv_backward: bad shape"); return -1; }
   if ((size_t)H * W * 4 >= 0x7fffffffull) { set_error("invdepth_conv_backward: plane exceeds the 2 GiB buffer window"); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  // dw [C*9] and db [1]: one fill when db sits right behind dw (the Python wrapper allocates them together)
-  const bool joined = db == dw + (size_t)C * 9;
-  int e = (int)hipMemsetAsync(dw, 0, ((size_t)C * 9 + (joined ? 1 : 0)) * sizeof(float), s);
-  if (!e && !joined) e = (int)hipMemsetAsync(db, 0, sizeof(float), s);
-  if (e) { set_error("invdepth_conv_backward: memset failed"); return e; }
   // pixels per thread: up to 16 (amortises the 73-value block reduction) while the grid keeps >= ~2 blocks per CU
   const int HW = H * W, cgroups = ceil_div(C, kIdCh);
   int ppt = 16;
   while (ppt > 1 && (long)ceil_div(HW, 256 * ppt) * cgroups * B < 512) ppt >>= 1;
-  PNSFM_LAUNCH(invdepth_conv_bwd_kernel, dim3(ceil_div(HW, 256 * ppt), cgroups, B), dim3(256), 0, s, x, w, dz, dx, dw, db, C,
-               H, W, ppt);
-  return check_launch("invdepth_conv_backward");
+  const int gx = ceil_div(HW, 256 * ppt);
+  ScratchLease lease(s, (size_t)gx * B * cgroups * kIdVals * sizeof(float));
+  float* const part = lease.as<float>();
+  if (!part) return -1;
+  PNSFM_LAUNCH(invdepth_conv_bwd_kernel, dim3(gx, cgroups, B), dim3(256), 0, s, x, w, dz, dx, part, C, H, W, ppt);
+  int rc = check_launch("invdepth_conv_backward");
+  if (rc) return rc;
+  PNSFM_LAUNCH(invdepth_conv_bwd_finish_kernel, dim3(ceil_div(C * 9 + 1, 256)), dim3(256), 0, s, (const float*)part, dw, db,
+               C, gx * B, cgroups);
+  return check_launch("invdepth_conv_backward (finish)");
 }
 
 }  // extern "C"

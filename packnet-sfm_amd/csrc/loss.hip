@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
       }
       if (rho >= 1e-6f) g_rho += -gd * q.d * q.d;
     }
-    // 12 pose-gradient partials: wave shuffles (fp32), one LDS stage across the 4 waves, then 12 fp64 atomics per block
+    // 12 pose-gradient partials: wave shuffles (fp32), one LDS stage across the 4 waves, then one fp64 slot per (matrix, pixel
+    // block, entry) -- view_synthesis_bwd_finish_kernel adds the pixel blocks in a fixed order (round 3: fp64 atomics)
     {
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
       if (threadIdx.x < 12) {
         const int i = threadIdx.x;
         const double s = (double)redT[0][i] + (double)redT[1][i] + (double)redT[2][i] + (double)redT[3][i];
-        atomicAdd(&ws[((size_t)j * B + b) * 12 + i], s);
+        ws[(((size_t)j * B + b) * gridDim.x + blockIdx.x) * 12 + i] = s;
       }
       __syncthreads();
     }
@@ -247,12 +248,25 @@ __global__ void __launch_bounds__(256) view_synthesis_bwd_kernel(const float* __
   if (active) d_inv_depth[(size_t)b * HW + pix] = g_rho;
 }
 
-__global__ void view_synthesis_bwd_finish_kernel(const double* __restrict__ ws, float* __restrict__ dT, int n_mats) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_mats * 16) {
-    const int m = i >> 4, e = i & 15;
-    dT[i] = e < 12 ? (float)ws[m * 12 + e] : 0.f;
+// dT[m] (4x4, last row zero) = sum over the pixel blocks' partials of matrix m: one wave per matrix, lane l adds blocks l, l + 64,
+// ... in order and the 64 lane sums meet in a fixed shuffle tree -- bit-reproducible
+__global__ void __launch_bounds__(64) view_synthesis_bwd_finish_kernel(const double* __restrict__ part, float* __restrict__ dT, int nblk) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  double s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0.0;
+  for (int p = lane; p < nblk; p += 64) {
+    const double* q = part + ((size_t)m * nblk + p) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] += q[i];
   }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    double v = s[i];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+    if (lane == 0) dT[m * 16 + i] = (float)v;
+  }
+  if (lane < 4) dT[m * 16 + 12 + lane] = 0.f;
 }
 
 // ---- SSIM / L1 photometric terms -------------------------------------------------------------------
@@ -581,14 +595,16 @@ int pnsfm_view_synthesis_backward_pad(const float* d_warped, const float* inv_de
   if (J < 1 || B < 1 || H < 2 || W < 2) { set_error("view_synthesis_backward: bad shape"); return -1; }
   if (padding_mode < 0 || padding_mode > 2) { set_error("view_synthesis_backward: bad padding_mode"); return -1; }
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(ws, 0, (size_t)J * B * 12 * sizeof(double), s);
-  if (e) { set_error("view_synthesis_backward: memset failed"); return e; }
+  (void)ws;     // (round 3's zero-filled atomics target; the per-block partials now live in the stream's scratch buffer)
   dim3 grid(ceil_div(H * W, 256), B);
-  PNSFM_LAUNCH(view_synthesis_bwd_kernel, grid, dim3(256), 0, s, d_warped, inv_depth, ref, K, refK, T, d_inv_depth, ws, J, B, H, W,
-               padding_mode);
-  e = check_launch("view_synthesis_backward");
+  ScratchLease lease(s, (size_t)J * B * grid.x * 12 * sizeof(double));
+  double* const part = lease.as<double>();
+  if (!part) return -1;
+  PNSFM_LAUNCH(view_synthesis_bwd_kernel, grid, dim3(256), 0, s, d_warped, inv_depth, ref, K, refK, T, d_inv_depth, part, J, B,
+               H, W, padding_mode);
+  int e = check_launch("view_synthesis_backward");
   if (e) return e;
-  PNSFM_LAUNCH(view_synthesis_bwd_finish_kernel, dim3(ceil_div(J * B * 16, 256)), dim3(256), 0, s, (const double*)ws, dT, J * B);
+  PNSFM_LAUNCH(view_synthesis_bwd_finish_kernel, dim3(J * B), dim3(64), 0, s, (const double*)part, dT, (int)grid.x);
   return check_launch("view_synthesis_backward_finish");
 }
 

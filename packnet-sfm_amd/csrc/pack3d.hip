@@ -274,10 +274,10 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
 // run of `len` consecutive d, one (y, x)); it keeps the three p planes d-1, d, d+1 (27 registers, rotated by a 3x
 // unrolled loop instead of moves), loads 9 new p values + 4 dout values per step, and accumulates 4 x 27 products (+ 4
 // bias sums) in registers.  Lanes run along x, so every load is coalesced.  The 112 per-thread partials are reduced
-// through LDS 16 at a time (conflict-free padded rows, then a 16-lane shuffle), one fp64 atomic per value per block.
+// through LDS 16 at a time (conflict-free padded rows, then a 16-lane shuffle), one partial slot per value per block.
 constexpr int kW3Pass = 16, kW3Row = 256 + 16;
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
-                                                            double* __restrict__ ws, int D, int H, int W, int len, int NF) {
+                                                            float* __restrict__ part, int D, int H, int W, int len, int NF) {
   __shared__ float red[kW3Pass * kW3Row];
   const int tid = threadIdx.x;
   const int HW = H * W, DHW = D * HW;
@@ -368,18 +368,24 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restri
     if (rj == 0) {
       const int v = pass * kW3Pass + rv;
       const int f = v / 28, t = v - f * 28;
-      atomicAdd(&ws[(fg * 4 + f) * 28 + t], (double)sacc);
+      // one slot per (block, value): plain stores, no zero-fill; conv3d_wgrad_finish_kernel adds the blocks in a fixed order
+      // (round 3: fp64 atomics)
+      (void)f; (void)t;
+      part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + fg) * 112 + v] = sacc;
     }
   }
 }
 
-__global__ void conv3d_wgrad_finish_kernel(const double* __restrict__ ws, float* __restrict__ dw3, float* __restrict__ db3,
-                                           int NF) {
-  const int i = threadIdx.x;
-  if (i < NF * 28) {
-    const int f = i / 28, t = i - f * 28;
-    if (t < 27) dw3[f * 27 + t] = (float)ws[i]; else db3[f] = (float)ws[i];
-  }
+// dw3 / db3 entry (f, t) = sum over the blocks' partials (fp64), one wave per entry: lane l adds blocks l, l + 64, ... in order, the
+// lane sums meet in a fixed shuffle tree -- bit-reproducible
+__global__ void __launch_bounds__(64) conv3d_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw3,
+                                                                 float* __restrict__ db3, int nblk, int ngroups) {
+  const int i = blockIdx.x, lane = threadIdx.x;             // i = f * 28 + t over all NF features
+  const int f = i / 28, t = i - f * 28, fg = f >> 2, v = (f & 3) * 28 + t;
+  double s = 0.0;
+  for (int p = lane; p < nblk; p += 64) s += (double)part[((size_t)p * ngroups + fg) * 112 + v];
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+  if (lane == 0) { if (t < 27) dw3[f * 27 + t] = (float)s; else db3[f] = (float)s; }
 }
 
 static int grid_for(size_t total) {
@@ -461,18 +467,21 @@ int pnsfm_conv3d_backward_weight(const float* p, const float* dout, float* dw3, 
                                  int W, int NF, void* stream) {
   if (!nf_ok(NF, "conv3d_backward_weight")) return -1;
   hipStream_t s = (hipStream_t)stream;
-  int e = (int)hipMemsetAsync(ws, 0, 8 * 28 * sizeof(double), s);
-  if (e) { set_error("conv3d_backward_weight: memset failed"); return e; }
+  (void)ws;     // (round 3's zero-filled fp64 atomics target; the per-block partials now live in the stream's scratch buffer)
   // run length along d per thread: as long as possible (amortises the block reduction) while the grid still gives every
   // CU a few blocks
   int len = D;
   while (len > 12 && (long)B * (NF / 4) * ceil_div(D, len) * H * W < 4L * 256 * 256) len = ceil_div(len, 2);
   len = ceil_div(len, 3) * 3;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, dim3(ceil_div(ceil_div(D, len) * H * W, 256), NF / 4, B), dim3(256), 0, s, p, dout, ws, D,
-               H, W, len, NF);
-  e = check_launch("conv3d_backward_weight");
+  const dim3 grid(ceil_div(ceil_div(D, len) * H * W, 256), NF / 4, B);
+  ScratchLease lease(s, (size_t)grid.x * grid.y * grid.z * 112 * sizeof(float));
+  float* const part = lease.as<float>();
+  if (!part) return -1;
+  PNSFM_LAUNCH(conv3d_wgrad_kernel, grid, dim3(256), 0, s, p, dout, part, D, H, W, len, NF);
+  int e = check_launch("conv3d_backward_weight");
   if (e) return e;
-  PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, dw3, db3, NF);
+  PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(NF * 28), dim3(64), 0, s, (const float*)part, dw3, db3, (int)(grid.x * grid.z),
+               (int)grid.y);
   return check_launch("conv3d_backward_weight_finish");
 }
 

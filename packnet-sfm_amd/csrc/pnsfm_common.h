@@ -228,6 +228,9 @@ int wgrad2_base_blocks(int Cin, int Cout, int ks);
 int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
                    int split, hipStream_t stream);
 
+// second stage of the pixel-split f32 weight-gradient kernels (conv2d.hip): out0[n0] | out1[n1] = sum of Z slabs, in slab order
+int launch_sum_slabs(const float* ws, size_t zstride, int Z, float* out0, size_t n0, float* out1, size_t n1, hipStream_t s);
+
 // split-bf16 weight-gradient kernel (conv2d_wgrad3.hip)
 bool wgrad3_supported(int Cin, int Cout, int H, int W, int ks);
 bool wgrad3_nt2_ok(int Cin, int ks);

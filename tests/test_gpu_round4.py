@@ -1,0 +1,102 @@
+"""GPU (MI355X): round-4 properties of the training step.
+
+  (a) bit-reproducibility: since round 4 no kernel on the self-supervised step meets partial sums with atomics (K-split forward /
+      backward-data, pixel-split weight gradients, Conv3d weight gradient, InvDepth head, pose gradient all finish in a second,
+      fixed-order stage), so two executions of one step from one state must agree BIT FOR BIT in the loss and in every gradient --
+      at the golden step's size and at BASELINE.json's 192x640 batch 4, where the K-split and pixel-split layers are the real ones;
+  (b) the K-split forward / backward-data path against an fp64 convolution at a real split layer shape.
+Reference semantics: packnet_sfm/models/SelfSupModel.py:63-97 (the step), trainers/horovod_trainer.py:85-93 (backward + optimizer)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from packnet_sfm.hip import _lib
+    assert _lib.get().pnsfm_build_target() == b'gfx950'
+    assert _lib.REQUIRE_CUDA
+
+
+def _grads_of_one_step(model, batch, flip):
+    for p in model.parameters():
+        p.grad = None
+    model._flip_override = flip
+    out = model(batch, progress=0.0)
+    model._flip_override = None
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    return out['loss'].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _assert_bitwise_equal_runs(model, batch, flips, what):
+    _grads_of_one_step(model, batch, False)            # autotuning (which times candidates) happens here, not between the runs
+    for flip in flips:
+        l0, g0 = _grads_of_one_step(model, batch, flip)
+        for rep in range(2):
+            l1, g1 = _grads_of_one_step(model, batch, flip)
+            assert torch.equal(l0, l1), '%s: loss differs between two runs of one step (flip=%s): %r vs %r' % (what, flip, l0.item(), l1.item())
+            assert g0.keys() == g1.keys()
+            bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+            assert not bad, '%s: %d gradients differ between two runs of one step (flip=%s), e.g. %s (max |d| %.3e)' % (
+                what, len(bad), flip, bad[0], float((g0[bad[0]] - g1[bad[0]]).abs().max()))
+
+
+def test_deterministic_step_golden_size():
+    """Two executions of the golden training step (PackNet01 + PoseNet + loss, forward + backward) are bit-identical."""
+    from test_gpu_parity import _selfsup, _step_batch
+    fx = dict(P.golden('step')['step_flip0'])
+    model, dn, pn = _selfsup(DEV, fx)
+    _assert_bitwise_equal_runs(model, _step_batch(fx), (False, True), 'golden-size step')
+
+
+def test_deterministic_step_full_size():
+    """The same at BASELINE.json configs[1]: 192x640, batch 4 -- the shapes whose low-resolution layers really split K (pack4 /
+    pack5, conv4 / conv5) and whose weight gradients really split pixels."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
+    import bench
+    model = bench.build_model(torch.device(DEV))
+    batch = bench.synthetic_batch(4, 192, 640, 1234, DEV)
+    _assert_bitwise_equal_runs(model, batch, (False,), '192x640 batch-4 step')
+
+
+@pytest.mark.parametrize('shape', [(4, 512, 512, 12, 40, 3), (2, 1024, 256, 6, 20, 3)])
+@pytest.mark.parametrize('split', [2, 5])
+def test_conv2d_split_k_two_stage_vs_fp64(shape, split):
+    """K-split forward / backward-data (partial outputs in the stream's scratch buffer, conv_splitk_reduce_kernel adds them in
+    split order, bias included) at a real low-resolution layer shape, pinned through pnsfm_tune_set: error against an fp64
+    convolution in the class of the un-split kernel (1e-6 of sum |x||w|), and bit-identical between two launches."""
+    import ctypes
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    wf, wb = ops.conv2d_pack(w)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
+    dx64 = F.conv_transpose2d(dy.double(), w.double(), padding=ks // 2)
+    scale_y = F.conv2d(x.abs().double(), w.abs().double(), padding=ks // 2).max()
+    scale_dx = F.conv_transpose2d(dy.abs().double(), w.abs().double(), padding=ks // 2).max()
+    try:
+        for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+            key = (ctypes.c_int * 7)(kind + 10 + 100, B, K, M, H, W, ks)
+            assert lib.pnsfm_tune_set(key, 2 | (3 << 4), split) == 0
+        y = ops.conv2d_forward(x, wf, b, Cout, ks)
+        dx = ops.conv2d_backward_data(dy, wb, Cin, ks)
+        assert float((y.double() - y64).abs().max() / scale_y) < 1e-6
+        assert float((dx.double() - dx64).abs().max() / scale_dx) < 1e-6
+        assert torch.equal(y, ops.conv2d_forward(x, wf, b, Cout, ks))
+        assert torch.equal(dx, ops.conv2d_backward_data(dy, wb, Cin, ks))
+    finally:
+        lib.pnsfm_set_conv_variant(3)      # clears the pinned entries

@@ -61,6 +61,20 @@ bool conv_bx3_supported(int Kc, int ks) {
 }
 static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_supported(Kc, ks); }
 
+// PNSFM_STAGGER="<units>[,mode]": start offset between co-resident workgroups of the split-bf16 kernels (conv2d_bx3.h), in units
+// of 512 cycles; mode 1 = by the wave slot the hardware reports (HW_ID), 2 = by the position in the first round of the grid
+static int g_stagger = -1, g_stagger_mode = 1;
+static void stagger_init() {
+  if (g_stagger >= 0) return;
+  const char* e = getenv("PNSFM_STAGGER");
+  int u = 0, m = 1;
+  if (e && e[0]) { if (sscanf(e, "%d,%d", &u, &m) < 2) m = 1; }
+  g_stagger_mode = (m == 2) ? 2 : 1;
+  g_stagger = u < 0 ? 0 : (u > 64 ? 64 : u);
+}
+static int stagger_units() { stagger_init(); return g_stagger; }
+static int stagger_mode() { stagger_init(); return g_stagger_mode; }
+
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
 static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
 static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
@@ -354,6 +368,7 @@ struct ConvArgs {
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
   int playout;        // bx3 variants: patch layout in LDS (1: half planes, conflict-free B fragments; 0: round 2's)
   int gx, gy, bmap;   // bx3 variants (1-D launch): pixel tiles, output-channel tiles, block order (pnsfm_common.h: block_map_mode)
+  int stagger, stagger_mode;   // bx3 variants: start offset between the workgroups that share a CU (units of 512 cycles; conv2d_bx3.h)
   float invPW, invPS;
 #ifdef PNSFM_PIPE_TRACE
   long long* trace;   // debug build only (tools/pipe_trace.py): per wave {barrier wait, stage compute, prologue, epilogue} cycles
@@ -900,6 +915,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
   { static const int pl = [] { const char* e = getenv("PNSFM_PATCH_LAYOUT"); return (e && e[0] == '0') ? 0 : 1; }(); a.playout = pl; }
+  a.stagger = stagger_units(); a.stagger_mode = stagger_mode();
   const dim3 grid1(grid.x * grid.y * grid.z);      // split-bf16 kernels: 1-D launch, block order decoded in the kernel
 #define PNSFM_CONV_DISPATCH(DMAv)                                                                                 \
   do {                                                                                                             \

@@ -277,6 +277,23 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 #else
 #define PNSFM_TR(acc_, expr) do { expr; } while (0)
 #endif
+  // ---- start offset between the workgroups that share a CU.  Co-resident workgroups of a grid that is resident in ONE round start
+  // together and stay in phase: they stage / issue DMA at the same time (matrix pipe idle) and then share the pipe at half rate each
+  // (tools/bx3_trace.py: a wave's own MFMAs fill ~41 % of its MFMA-loop cycles; r03_mfma_busy: 47 %).  A lag between them persists
+  // (nothing re-synchronises two workgroups), so delaying the second (third) workgroup of a CU by about one staging phase puts its
+  // staging under the first one's MFMAs.
+#ifndef PNSFM_EMU
+  if (a.stagger > 0) {
+    unsigned pos;
+    if (a.stagger_mode == 2) {
+      pos = blockIdx.x >> 8;                                     // n-th workgroup of its CU if the first round fills the CUs one by one
+      if (pos >= (unsigned)OCC) pos = 0;
+    } else {
+      pos = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u) % (unsigned)OCC;     // HW_REG_HW_ID, WAVE_ID[3:0]: slot in the SIMD
+    }
+    for (unsigned i = 0; i < pos * (unsigned)a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   // ---- prologue: first chunk's patch and first stage's weights
   const int SG = (KK + G - 1) / G;               // stages per chunk
   issue_weights(c_begin, 0, wbuf0);

@@ -70,13 +70,14 @@ class DistributedOptimizer:
     Gradients are reduced bucket-by-bucket on a side stream while backward is still running."""
 
     def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=32 << 20,
-                 force_collectives=False, overlap=None):
+                 force_collectives=False, overlap=None, chunk_bytes=64 << 20):
         self._opt = optimizer
         params = [p for g in optimizer.param_groups for p in g['params']]
         # an optimizer that keeps its gradients in a flat arena (rccl/flat_adam.py) lends its buckets: reduce + update in place
         buckets = optimizer.grad_buckets(bucket_bytes) if hasattr(optimizer, 'grad_buckets') else None
         self._reducer = GradBucketReducer(params, bucket_bytes=bucket_bytes, average=True,
-                                          force_collectives=force_collectives, buckets=buckets, overlap=overlap)
+                                          force_collectives=force_collectives, buckets=buckets, overlap=overlap,
+                                          chunk_bytes=chunk_bytes)
 
     def zero_grad(self, set_to_none=False):
         self._reducer.zero_grad()

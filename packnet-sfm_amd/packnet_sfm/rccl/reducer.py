@@ -14,8 +14,10 @@ MI355X-first choices (not a translation of horovod's tensor-fusion queue):
     but the LAST bucket of a step completes when backward ends, so its all-reduce is fully exposed: with 128 MiB buckets
     that was 112 MB (pack4.conv3d ... pre_calc: ~1 ms on 8 GPUs).  The default is therefore 32 MiB (large enough to run at
     link speed: ~0.2 ms of transfer against ~30 us of latency), cut at parameter boundaries: 519.5 MB of PackNet01+PoseNet
-    gradients -> 10 collectives, the 302 MB pack5 and 75 MB pack4 weights are buckets of their own (they complete in the
-    middle of backward and hide behind the rest of it), <= 32 MB stays exposed at the end;
+    gradients -> 10 buckets, the 302 MB pack5 and 75 MB pack4 weights are buckets of their own (they complete in the
+    middle of backward and hide behind the rest of it), <= 32 MB stays exposed at the end.  A bucket larger than
+    `chunk_bytes` (64 MiB: a single parameter that big) is reduced as several back-to-back collectives over contiguous
+    slices of its flat buffer, so the overlap with backward never hinges on one giant ring pass (SURVEY 2.3 C1);
   * a bucket's all-reduce is enqueued on a dedicated side stream the moment its last gradient has been accumulated
     (post-accumulate-grad hooks), while the compute stream keeps running backward; `synchronize()` joins the side
     stream before the optimizer reads the gradients and applies the 1/world_size averaging.
@@ -74,13 +76,15 @@ class GradBucketReducer:
     ----------
     params : iterable of nn.Parameter (requires_grad ones are bucketed)
     bucket_bytes : int        flat-bucket capacity
+    chunk_bytes : int         largest single collective: a bigger bucket (one huge parameter) is reduced in slices of this size
     process_group             torch.distributed group (default: WORLD)
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
     def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True, force_collectives=False, buckets=None,
-                 overlap=None):
+                 overlap=None, chunk_bytes=64 << 20):
         self.group = process_group
+        self.chunk_bytes = int(chunk_bytes)
         # overlap=False (or PNSFM_DDP_OVERLAP=0): no collective starts before synchronize() -- the A/B leg that shows what the
         # side-stream overlap with backward is worth (tests/rccl_two_ranks.py, bench.py)
         self.overlap = (os.environ.get('PNSFM_DDP_OVERLAP', '1') != '0') if overlap is None else bool(overlap)
@@ -131,6 +135,7 @@ class GradBucketReducer:
                 p.grad = None
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
         self._launched = 0
+        self.collectives_issued = 0      # all-reduce calls since construction (a bucket > chunk_bytes counts once per slice)
         self._next = 0          # index of the next bucket to launch
         self._synced = False
         self._exposed = None    # [(event before the join, event after it)] while bench.py measures the exposed all-reduce time
@@ -194,17 +199,23 @@ class GradBucketReducer:
         if self.world == 1 and not self.force:
             return
         op = self._reduce_op
+        # the same slices on every rank (a function of the bucket size only): the collective sequences pair up
+        per = max(1, self.chunk_bytes // bucket.flat.element_size())
+        n = bucket.flat.numel()
+        chunks = [bucket.flat] if n <= per else [bucket.flat[o:min(o + per, n)] for o in range(0, n, per)]
+        self.collectives_issued += len(chunks)
         if self._host_staged:
-            host = bucket.flat.cpu()                    # synchronises: rehearsal path only
-            dist.all_reduce(host, op=op, group=self.group)
-            bucket.flat.copy_(host)
+            for c in chunks:
+                host = c.cpu()                          # synchronises: rehearsal path only
+                dist.all_reduce(host, op=op, group=self.group)
+                c.copy_(host)
             bucket.work = None
         elif self.side_stream is not None:
             self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side_stream):
-                bucket.work = dist.all_reduce(bucket.flat, op=op, group=self.group, async_op=True)
+                bucket.work = [dist.all_reduce(c, op=op, group=self.group, async_op=True) for c in chunks]
         else:
-            bucket.work = dist.all_reduce(bucket.flat, op=op, group=self.group, async_op=True)
+            bucket.work = [dist.all_reduce(c, op=op, group=self.group, async_op=True) for c in chunks]
 
     def zero_grad(self):
         """Drop the gradients (autograd will hand out fresh tensors; nothing is zero-filled) and re-arm the hooks."""
@@ -235,7 +246,8 @@ class GradBucketReducer:
             before.record(cur)                 # backward's last kernel is behind this point of the compute stream
         for b in self.buckets:
             if b.work is not None:
-                b.work.wait()                  # compute stream waits for the collective (stream-ordered, the host does not block)
+                for w in b.work:
+                    w.wait()                   # compute stream waits for the collective (stream-ordered, the host does not block)
                 b.work = None
         if self.side_stream is not None and (self.world > 1 or self.force):
             cur.wait_stream(self.side_stream)

@@ -112,3 +112,97 @@ def test_gloo_world2_gradient_average(opt_kind):
         for p, r in zip(params, net.parameters()):
             assert torch.allclose(torch.tensor(p), r.detach(), atol=1e-5), 'replicas diverged from the full-batch run'
     assert results[0][2] == results[1][2], 'replicas are not bit-identical'
+
+
+def _worker_uneven(rank, world, port, q):
+    """Two ranks whose losses reach DIFFERENT subsets of the parameters (rank r only uses head r), FlatAdam buckets reduced in
+    place, tiny buckets and a tiny chunk size so that one parameter is reduced in several slices."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, os.path.join(root, 'packnet-sfm_amd'))
+    sys.path.insert(0, os.path.join(root, 'tests', 'emu'))
+    import emu_loader
+    emu_loader.use_emulated_kernels()
+    from packnet_sfm.rccl import hvd
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+    hvd.init()
+    torch.manual_seed(0)
+    trunk = torch.nn.Linear(8, 40)
+    heads = torch.nn.ModuleList([torch.nn.Linear(40, 3), torch.nn.Linear(40, 3)])
+    net = torch.nn.ModuleList([trunk, heads])
+    inner = FlatAdam([{'params': list(trunk.parameters()), 'lr': 1e-2}, {'params': list(heads.parameters()), 'lr': 1e-2}])
+    opt = hvd.DistributedOptimizer(inner, named_parameters=net.named_parameters(), compression=hvd.Compression.none,
+                                   bucket_bytes=300, chunk_bytes=256)     # trunk.weight: 1280 B -> one bucket, five 256-byte slices
+    log = []
+    real = dist.all_reduce
+
+    def logging_all_reduce(t, *a, **k):
+        log.append(int(t.numel()))
+        return real(t, *a, **k)
+
+    dist.all_reduce = logging_all_reduce
+    data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
+    target = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    shard = slice(rank * 4, rank * 4 + 4)
+    seqs = []
+    for it in range(3):
+        del log[:]
+        opt.zero_grad()
+        loss = ((heads[rank](torch.tanh(trunk(data[shard]))) - target[shard]) ** 2).mean()
+        loss.backward()
+        opt.step()
+        seqs.append(list(log))
+    dist.all_reduce = real
+    q.put((rank, seqs, [p.detach().tolist() for p in net.parameters()], opt._reducer.collectives_issued))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_uneven_unused_parameters_same_collective_sequence():
+    """ranks that see different sets of unused parameters (rank r's loss only reaches head r) must issue the
+    SAME sequence of collectives -- bucket order, and the slices of a bucket larger than chunk_bytes -- and end bit-identical,
+    equal to one process that averaged the two per-rank gradients (a missing gradient counts as zero, like horovod's
+    synchronize() in the reference, trainers/horovod_trainer.py:46-48)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu'))
+    from build_emu import build_emu
+    build_emu()
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, seq0, params0, n0), (_, seq1, params1, n1) = results
+    assert seq0 == seq1, 'ranks issued different collective sequences: %r vs %r' % (seq0, seq1)
+    assert n0 == n1 and n0 == sum(len(s) for s in seq0)
+    assert all(len(s) == len(seq0[0]) for s in seq0), 'the sequence must not depend on the step'
+    assert max(seq0[0]) <= 64, 'a collective larger than chunk_bytes (256 B = 64 floats) was issued: %r' % (seq0[0],)
+    assert sum(seq0[0]) >= 8 * 40 + 40 + 2 * (40 * 3 + 3), 'not every parameter was reduced'
+    assert params0 == params1, 'replicas are not bit-identical'
+    # single-process reference: average of the two per-rank gradients (unused head = zero gradient on that rank), torch Adam
+    torch.manual_seed(0)
+    trunk = torch.nn.Linear(8, 40)
+    heads = torch.nn.ModuleList([torch.nn.Linear(40, 3), torch.nn.Linear(40, 3)])
+    params = list(trunk.parameters()) + list(heads.parameters())
+    opt = torch.optim.Adam(params, lr=1e-2)
+    data = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
+    target = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    for it in range(3):
+        acc = [torch.zeros_like(p) for p in params]
+        for r in range(2):
+            shard = slice(r * 4, r * 4 + 4)
+            gs = torch.autograd.grad(((heads[r](torch.tanh(trunk(data[shard]))) - target[shard]) ** 2).mean(), params, allow_unused=True)
+            for a, g in zip(acc, gs):
+                if g is not None:
+                    a += g
+        for p, a in zip(params, acc):
+            p.grad = a / 2
+        opt.step()
+    for got, ref in zip(params0, params):
+        assert torch.allclose(torch.tensor(got), ref.detach(), atol=1e-5), 'replicas diverged from the averaged-gradient run'

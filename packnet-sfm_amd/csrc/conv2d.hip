@@ -61,20 +61,6 @@ bool conv_bx3_supported(int Kc, int ks) {
 }
 static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_supported(Kc, ks); }
 
-// PNSFM_STAGGER="<units>[,mode]": start offset between co-resident workgroups of the split-bf16 kernels (conv2d_bx3.h), in units
-// of 512 cycles; mode 1 = by the wave slot the hardware reports (HW_ID), 2 = by the position in the first round of the grid
-static int g_stagger = -1, g_stagger_mode = 1;
-static void stagger_init() {
-  if (g_stagger >= 0) return;
-  const char* e = getenv("PNSFM_STAGGER");
-  int u = 0, m = 1;
-  if (e && e[0]) { if (sscanf(e, "%d,%d", &u, &m) < 2) m = 1; }
-  g_stagger_mode = (m == 2) ? 2 : 1;
-  g_stagger = u < 0 ? 0 : (u > 64 ? 64 : u);
-}
-static int stagger_units() { stagger_init(); return g_stagger; }
-static int stagger_mode() { stagger_init(); return g_stagger_mode; }
-
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
 static const size_t kMaxSmemPipe = 160 * 1024;   // pipelined variant: all of a CDNA4 CU's LDS (needs hipFuncSetAttribute)
 static const size_t kPipeTwoBlocks = 80 * 1024;  // ... but prefer a K-chunk that lets two workgroups share the CU
@@ -146,7 +132,8 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     const int KK = ks * ks;
     const size_t plane = (size_t)round_up(g.PH * g.PW * 32, 1024);
     const size_t patch = (size_t)g.PB * 3 * plane;
-    auto smem_bx3 = [&](int G) -> size_t { return patch + 2 * (size_t)G * g.MT * 3072; };
+    // (+ 256 B: the M tile's 64 bias values, staged in the prologue for the epilogue)
+    auto smem_bx3 = [&](int G) -> size_t { return patch + 2 * (size_t)G * g.MT * 3072 + 256; };
     const int cand[6] = {KK <= 9 ? KK : ks, ks, 4, 3, 2, 1};
     g.G = 0;
     if (DMA == 5) {
@@ -368,7 +355,9 @@ struct ConvArgs {
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
   int playout;        // bx3 variants: patch layout in LDS (1: half planes, conflict-free B fragments; 0: round 2's)
   int gx, gy, bmap;   // bx3 variants (1-D launch): pixel tiles, output-channel tiles, block order (pnsfm_common.h: block_map_mode)
-  int stagger, stagger_mode;   // bx3 variants: start offset between the workgroups that share a CU (units of 512 cycles; conv2d_bx3.h)
+#ifdef PNSFM_BX3_ABLATE
+  int ablate;         // debug build only (tools/bx3_ablate.py): what-if switches of conv2d_bx3_kernel -- results are wrong
+#endif
   float invPW, invPS;
 #ifdef PNSFM_PIPE_TRACE
   long long* trace;   // debug build only (tools/pipe_trace.py): per wave {barrier wait, stage compute, prologue, epilogue} cycles
@@ -387,7 +376,8 @@ __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 // paths are separate loops so the compiler can stream the stores.
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int co0, int half,
-                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], int bz) {
+                                              const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], int bz,
+                                              const float* lds_bias = nullptr) {
   const int HW = a.H * a.W;
   // K-split launches: every split stores its partial tile into its own slab of the workspace (plain stores; no zero-fill, no
   // atomics) and conv_splitk_reduce_kernel adds the slabs in split order, bias included -- the result does not depend on which
@@ -401,8 +391,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        bval[mt][r] = a.bias[co < a.Cout ? co : a.Cout - 1];
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + row;
+        // (split-bf16 kernels: the tile's bias values were staged in LDS by the prologue -- 32 L2 round trips at the very end of a
+        // workgroup, in front of its stores, otherwise)
+        bval[mt][r] = lds_bias ? lds_bias[row] : a.bias[co < a.Cout ? co : a.Cout - 1];
       }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -873,6 +865,10 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
 #endif
 }
 
+#ifdef PNSFM_BX3_ABLATE
+static int g_ablate = 0;
+extern "C" int pnsfm_debug_set_ablate(int f) { g_ablate = f; return 0; }
+#endif
 #ifdef PNSFM_PIPE_TRACE
 static long long* g_trace_buf = nullptr;
 static int g_trace_flags = 0;
@@ -915,7 +911,9 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
   { static const int pl = [] { const char* e = getenv("PNSFM_PATCH_LAYOUT"); return (e && e[0] == '0') ? 0 : 1; }(); a.playout = pl; }
-  a.stagger = stagger_units(); a.stagger_mode = stagger_mode();
+#ifdef PNSFM_BX3_ABLATE
+  a.ablate = g_ablate;
+#endif
   const dim3 grid1(grid.x * grid.y * grid.z);      // split-bf16 kernels: 1-D launch, block order decoded in the kernel
 #define PNSFM_CONV_DISPATCH(DMAv)                                                                                 \
   do {                                                                                                             \

@@ -25,7 +25,7 @@
 //     double-buffered in stages of G taps: one barrier per G taps;
 //   * per tap and wave: 3*(MT+NT) ds_read_b128 feed 6*MT*NT MFMAs (MT = NT = 2: 12 reads, 24 MFMAs = 768 matrix cycles),
 //     fragments of tap j+1 are read before the MFMAs of tap j are issued.
-// LDS per block = PB*3*PS*32 B (patch) + 2*G*MT*3072 B (weights); the host picks G (and PB) so that two blocks share a CU
+// LDS per block = PB*3*PS*32 B (patch) + 2*G*MT*3072 B (weights) + 256 B (the tile's bias values); the host picks G (and PB) so that two blocks share a CU
 // where possible (the second block's math covers this block's staging).
 #pragma once
 
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const int G = a.G;
   const int stageB = G * MT * PNSFM_BX3_SLAB;
   unsigned char* const wbuf0 = smem + a.PB * patchB;
+  float* const lds_bias = reinterpret_cast<float*>(wbuf0 + 2 * stageB);      // 64 floats behind the weight stages
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
@@ -277,26 +278,18 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
 #else
 #define PNSFM_TR(acc_, expr) do { expr; } while (0)
 #endif
-  // ---- start offset between the workgroups that share a CU.  Co-resident workgroups of a grid that is resident in ONE round start
-  // together and stay in phase: they stage / issue DMA at the same time (matrix pipe idle) and then share the pipe at half rate each
-  // (tools/bx3_trace.py: a wave's own MFMAs fill ~41 % of its MFMA-loop cycles; r03_mfma_busy: 47 %).  A lag between them persists
-  // (nothing re-synchronises two workgroups), so delaying the second (third) workgroup of a CU by about one staging phase puts its
-  // staging under the first one's MFMAs.
-#ifndef PNSFM_EMU
-  if (a.stagger > 0) {
-    unsigned pos;
-    if (a.stagger_mode == 2) {
-      pos = blockIdx.x >> 8;                                     // n-th workgroup of its CU if the first round fills the CUs one by one
-      if (pos >= (unsigned)OCC) pos = 0;
-    } else {
-      pos = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u) % (unsigned)OCC;     // HW_REG_HW_ID, WAVE_ID[3:0]: slot in the SIMD
-    }
-    for (unsigned i = 0; i < pos * (unsigned)a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
-  }
+#ifdef PNSFM_BX3_ABLATE
+  // timing experiments (tools/bx3_ablate.py; results are WRONG): 1 no weight DMA in the loop, 2 no patch loads / split / ds_write at
+  // chunk ends, 4 no stage barriers, 8 fragments read once per stage, 16 no MFMAs, 32 no epilogue stores
+  const int AB = a.ablate;
+#define PNSFM_AB(bit) (AB & (bit))
+#else
+#define PNSFM_AB(bit) 0
 #endif
   // ---- prologue: first chunk's patch and first stage's weights
   const int SG = (KK + G - 1) / G;               // stages per chunk
   issue_weights(c_begin, 0, wbuf0);
+  if (a.bias != nullptr && a.splitK == 1 && tid < BM) lds_bias[tid] = a.bias[co0 + tid < a.Cout ? co0 + tid : a.Cout - 1];   // published by the first stage barrier
   if (prefetch) { load_items(c_begin); write_items(smem); }
   else stage_sync(c_begin, smem);
 
@@ -312,15 +305,17 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
       const int gcount = (KK - tap0 < G) ? KK - tap0 : G;
       const bool last = sg + 1 == SG;
       PNSFM_TR(tr_wait, pnsfm_dma_wait();    // this wave's weight DMA for the stage has landed ...
-               __syncthreads());             // ... and so has everyone's; the patch is visible, the previous stage is consumed
+               if (!PNSFM_AB(4)) __syncthreads());             // ... and so has everyone's; the patch is visible, the previous stage is consumed
       unsigned char* const wst = wbuf0 + (stage & 1) * stageB;
       unsigned char* const wnext = wbuf0 + ((stage & 1) ^ 1) * stageB;
       // (handing this DMA / load burst out in slices between the taps' MFMA batches was measured and is slower: 124 vs 134 img/s --
       // an LDS-DMA issued inside the MFMA stream stalls the wave longer than the same instruction in a burst)
       PNSFM_TR(tr_issue, {
-        if (!last) issue_weights(c, tap0 + G, wnext);
-        else if (more) issue_weights(c + 1, 0, wnext);
-        if (last && more && prefetch) PNSFM_TR(tr_load, load_items(c + 1));      // (inside the issue bracket: also counted there)
+        if (!PNSFM_AB(1)) {
+          if (!last) issue_weights(c, tap0 + G, wnext);
+          else if (more) issue_weights(c + 1, 0, wnext);
+        }
+        if (last && more && prefetch && !PNSFM_AB(2)) PNSFM_TR(tr_load, load_items(c + 1));      // (inside the issue bracket: also counted there)
       });
 #ifdef PNSFM_PIPE_TRACE
       const long long tr_m0 = __builtin_readcyclecounter();
@@ -339,23 +334,33 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
           mma(f0);
         }
       } else {
+        // Two fragment sets: the reads of tap j+1 are issued before the MFMAs of tap j.  The loop body is written so that EVERY path
+        // into an MFMA batch has exactly one younger batch of ds_reads behind the fragments it consumes: LGKM operations retire in
+        // order, and hipcc's wait insertion takes the most conservative count over the paths that merge in front of an instruction --
+        // round 3's `if (j + 1 < gcount) load(f1); mma(f0);` merged "12 younger reads" with "none" and waited lgkmcnt(3..0), i.e. for
+        // the prefetch it had just issued (one exposed LDS round trip per tap pair; tools/bx3_ablate.py: fragments are worth 5-8 us
+        // of a 60 us launch).  The tail (1 or 2 taps left) is peeled.
         Frag f0, f1;
         load_frag(f0, wst, 0, patch, tapoff());
-        for (int j = 0; j < gcount; j += 2) {
-          if (j + 1 < gcount) load_frag(f1, wst, j + 1, patch, tapoff());
-          mma(f0);
-          if (j + 1 < gcount) {
-            if (j + 2 < gcount) load_frag(f0, wst, j + 2, patch, tapoff());
-            mma(f1);
-          }
+        if (PNSFM_AB(8)) load_frag(f1, wst, 0, patch, 0);
+        int j = 0;
+        for (; j + 2 < gcount; j += 2) {
+          if (!PNSFM_AB(8)) load_frag(f1, wst, j + 1, patch, tapoff());
+          if (!PNSFM_AB(16)) mma(f0);
+          if (!PNSFM_AB(8)) load_frag(f0, wst, j + 2, patch, tapoff());
+          if (!PNSFM_AB(16)) mma(f1);
         }
+        if (j + 1 < gcount) {
+          if (!PNSFM_AB(8)) load_frag(f1, wst, j + 1, patch, tapoff());
+          if (!PNSFM_AB(16)) { mma(f0); mma(f1); }
+        } else if (!PNSFM_AB(16)) mma(f0);
       }
 
 #ifdef PNSFM_PIPE_TRACE
       tr_mma += __builtin_readcyclecounter() - tr_m0;
       const long long tr_s0 = __builtin_readcyclecounter();
 #endif
-      if (last && more) {
+      if (last && more && !PNSFM_AB(2)) {
         if (a.PB == 2) {
           // the other patch buffer was last read two chunks ago: write the next chunk's patch while the other waves finish
           if (prefetch) write_items(smem + (pcur ^ 1) * patchB);
@@ -376,7 +381,8 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz);
+  if (!PNSFM_AB(32) || acc[0][0][0] == 1.2345f) conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz, lds_bias);
+#undef PNSFM_AB
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();

@@ -1,10 +1,14 @@
-"""GPU lab: time the forward launches of the step's body layers under the library's tuned configurations for the PNSFM_STAGGER value
-of this process (csrc/conv2d_bx3.h: start offset between co-resident workgroups).  One process per setting:
-    for s in 0 4,1 8,1 8,2; do PNSFM_STAGGER=$s python tools/stagger_lab.py; done"""
+"""GPU lab: time the forward launches of the step's body layers under the library's tuned configurations.  Same-box A/B of two builds:
+    PNSFM_LAB_LIB=tools/micro/libpnsfm_base.so python tools/conv_lab.py ; python tools/conv_lab.py
+(PNSFM_LAB_LIB: another build of libpnsfm_hip.so, e.g. the previous commit's, with its tuned_gfx950.db next to it; PNSFM_LAB_TAG
+labels the output lines)."""
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'packnet-sfm_amd'))
 import torch
+from packnet_sfm.hip import _lib
+if os.environ.get('PNSFM_LAB_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['PNSFM_LAB_LIB'])
 from packnet_sfm.hip import ops
 
 dev = torch.device('cuda:0')
@@ -31,7 +35,7 @@ def timeit(fn, reps=20):
     return best
 
 
-tag = os.environ.get('PNSFM_STAGGER', '0')
+tag = os.environ.get('PNSFM_LAB_TAG', 'base' if os.environ.get('PNSFM_LAB_LIB') else 'new')
 tot = 0.0
 for shape in SHAPES:
     B, Cin, Cout, H, W, ks = shape
@@ -42,5 +46,5 @@ for shape in SHAPES:
     gf = 2.0 * B * Cin * Cout * H * W * ks * ks / 1e9
     ms = timeit(lambda: ops.conv2d_forward(x, wf, None, Cout, ks))
     tot += ms
-    print('stagger %-5s %-28s %.4f ms  %.1f TF' % (tag, shape, ms, gf / ms), flush=True)
-print('stagger %-5s total %.4f ms' % (tag, tot), flush=True)
+    print('lab %-5s %-28s %.4f ms  %.1f TF' % (tag, shape, ms, gf / ms), flush=True)
+print('lab %-5s total %.4f ms' % (tag, tot), flush=True)

@@ -184,6 +184,10 @@ def cpu_baseline(H, W, seconds_budget=75.0):
     med = sorted(times)[len(times) // 2]
     torch.set_num_threads(saved)
     return {'value': round(nb / med, 4), 'unit': 'images/sec', 'cores': best_th, 'kind': kind,
+            # the REFERENCE's own modules (kind "reference") cannot run on the GPU box (/root/reference is absent there); what they
+            # measured in the build container (8 vCPU Xeon @2.1 GHz, torch 2.10 CPU, 8 threads, batch 1, best of 3 steps)
+            'reference_kind_in_build_container': {'value': 0.30, 'unit': 'images/sec', 'cores': 8, 'batch': 1,
+                                                  'source': 'BASELINE.md section 3 (survey probe: 3.32 s per 192x640 step)'},
             'thread_sweep_batch1': {str(k): round(v, 4) for k, v in sweep.items()},
             'timed_steps_s': [round(t, 3) for t in times], 'batch': nb, 'host_cpus': ncpu,
             'sample': '%s, full train step (fwd+loss+bwd+Adam), %dx%d: thread sweep at batch 1 (1 timed step per count), then '
@@ -191,6 +195,48 @@ def cpu_baseline(H, W, seconds_budget=75.0):
                       % ('the reference itself (/root/reference modules on torch CPU fp32)' if kind == 'reference' else
                          'oracle port (torch CPU fp32 restatement of the reference path; no /root/reference on this box)',
                          H, W, nb, best_th, len(times))}
+
+
+def gpu_eager_baseline(H, W, B, device, seconds_budget=90.0):
+    """Like-for-like GPU baseline: the reference path's math through STOCK PyTorch-ROCm eager
+    ops (MIOpen / ATen, fp32) on this same MI355X -- the full training step incl. torch.optim.Adam.  The GPU box has no
+    /root/reference, so the ops are driven by oracle/packnet_oracle.py, the torch restatement of the reference's modules that
+    the parity tests pin against the reference (the same role it has in `cpu_baseline`; a reported baseline, never the product).
+    Bounded: 1 warm-up step (MIOpen picks its kernels there) + up to 3 timed steps inside `seconds_budget`."""
+    from oracle import packnet_oracle as O
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    batch = synthetic_batch(B, H, W, 1234, device)
+    sd = {k: v.to(device).requires_grad_(True) for k, v in O.init_params(O.packnet01_param_shapes('1A'), seed=42).items()}
+    psd = {k: v.to(device).requires_grad_(True) for k, v in O.init_params(O.posenet_param_shapes(2), seed=43).items()}
+    opt = torch.optim.Adam([{'params': list(sd.values()), 'lr': 2e-4}, {'params': list(psd.values()), 'lr': 2e-4}])
+    kw = {k: LOSS_DEFAULTS[k] for k in ('num_scales', 'ssim_loss_weight', 'smooth_loss_weight', 'C1', 'C2',
+                                         'photometric_reduce_op', 'automask_loss')}
+
+    def step():
+        opt.zero_grad()
+        out = O.selfsup_forward(sd, psd, batch, flip=False, **kw)
+        out['loss'].sum().backward()
+        opt.step()
+
+    t_start = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t_start
+    times = []
+    while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < seconds_budget):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    del opt, sd, psd
+    torch.cuda.empty_cache()
+    return {'value': round(B / med, 3), 'unit': 'images/sec', 'kind': 'port',
+            'ms_per_step': round(1e3 * med, 2), 'timed_steps_s': [round(t, 4) for t in times], 'warmup_step_s': round(warm, 2),
+            'sample': 'stock PyTorch-ROCm eager ops (MIOpen / ATen, fp32, no TF32) driven by the oracle port of the reference path, '
+                      'full train step (fwd+loss+bwd+Adam), %dx%d batch %d on this GPU: 1 warm-up + %d timed steps, value = batch / median'
+                      % (H, W, B, len(times))}
 
 
 def measured_traffic(H, W, B):
@@ -361,6 +407,8 @@ def main():
     ap.add_argument('--depth-net', default='PackNet01', choices=['PackNet01', 'PackNetSlim01'],
                     help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gpu-baseline', action='store_true',
+                    help='skip the stock PyTorch-ROCm eager baseline of the same step on this GPU (`gpu_eager_baseline`, N=1 only)')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the short 384x1280 batch-2 measurement (BASELINE.json configs[2] shape) that the default 192x640 '
@@ -465,6 +513,12 @@ def main():
                                                       '(BASELINE.json configs[2] shape)', 'global_batch': 2,
                                           'final_loss': round(extra['loss'], 6)},
                                'roofline': eroof}
+        if world == 1 and not ddp and not args.no_gpu_baseline:
+            try:
+                result['gpu_eager_baseline'] = gpu_eager_baseline(H, W, B, device)
+                result['gpu_eager_baseline']['speedup_of_value'] = round(value / result['gpu_eager_baseline']['value'], 2)
+            except Exception as e:          # a baseline must never take the measurement down
+                result['gpu_eager_baseline'] = {'value': None, 'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
         try:        # RCCL prints a version banner through C stdio (block-buffered when stdout is a file): push it out FIRST

@@ -334,26 +334,23 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
           mma(f0);
         }
       } else {
-        // Two fragment sets: the reads of tap j+1 are issued before the MFMAs of tap j.  The loop body is written so that EVERY path
-        // into an MFMA batch has exactly one younger batch of ds_reads behind the fragments it consumes: LGKM operations retire in
-        // order, and hipcc's wait insertion takes the most conservative count over the paths that merge in front of an instruction --
-        // round 3's `if (j + 1 < gcount) load(f1); mma(f0);` merged "12 younger reads" with "none" and waited lgkmcnt(3..0), i.e. for
-        // the prefetch it had just issued (one exposed LDS round trip per tap pair; tools/bx3_ablate.py: fragments are worth 5-8 us
-        // of a 60 us launch).  The tail (1 or 2 taps left) is peeled.
+        // Two fragment sets: the reads of tap j+1 are issued before the MFMAs of tap j.  hipcc's wait insertion merges the "f1 was
+        // prefetched" and "last tap" paths in front of mma(f0) and waits lgkmcnt(3..0) there, i.e. also for the prefetch it has just
+        // issued.  Round 4 peeled the loop so that the steady state waits lgkmcnt(12) (ISA checked) -- and measured it 2 % SLOWER
+        // over the step's layer mix in a same-box A/B (7x7 216 -> 211 TFLOP/s, 128 -> 128 @ 48x160 146 -> 138; only 256 -> 256 @ 24x80
+        // gained, 132 -> 145): MFMAs that start while the partner wave's and this wave's LDS reads are still streaming are issued
+        // less densely than a batch behind a drained counter.  The merged form stays.
         Frag f0, f1;
         load_frag(f0, wst, 0, patch, tapoff());
         if (PNSFM_AB(8)) load_frag(f1, wst, 0, patch, 0);
-        int j = 0;
-        for (; j + 2 < gcount; j += 2) {
-          if (!PNSFM_AB(8)) load_frag(f1, wst, j + 1, patch, tapoff());
+        for (int j = 0; j < gcount; j += 2) {
+          if (j + 1 < gcount && !PNSFM_AB(8)) load_frag(f1, wst, j + 1, patch, tapoff());
           if (!PNSFM_AB(16)) mma(f0);
-          if (!PNSFM_AB(8)) load_frag(f0, wst, j + 2, patch, tapoff());
-          if (!PNSFM_AB(16)) mma(f1);
+          if (j + 1 < gcount) {
+            if (j + 2 < gcount && !PNSFM_AB(8)) load_frag(f0, wst, j + 2, patch, tapoff());
+            if (!PNSFM_AB(16)) mma(f1);
+          }
         }
-        if (j + 1 < gcount) {
-          if (!PNSFM_AB(8)) load_frag(f1, wst, j + 1, patch, tapoff());
-          if (!PNSFM_AB(16)) { mma(f0); mma(f1); }
-        } else if (!PNSFM_AB(16)) mma(f0);
       }
 
 #ifdef PNSFM_PIPE_TRACE

@@ -239,19 +239,80 @@ def gpu_eager_baseline(H, W, B, device, seconds_budget=90.0):
                       % (H, W, B, len(times))}
 
 
+def gpu_eager_baseline_bounded(H, W, B, value, budget_s):
+    """`gpu_eager_baseline` in a child process with a wall-clock budget (None: unbounded).  MIOpen's first-use kernel compilation
+    cannot be interrupted in-process; a child that overruns is killed (its own process group, nothing else) and the line quotes
+    the figure recorded by an earlier unbounded run of this same leg (profiles/r*_gpu_eager_baseline.json)."""
+    import glob
+    import signal
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpu-baseline-worker', '%d,%d,%d' % (H, W, B)]
+    res, note = None, None
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True, text=True)
+        try:
+            out, _ = p.communicate(timeout=budget_s)
+            line = [ln for ln in out.splitlines() if ln.startswith('{')]
+            res = json.loads(line[-1]) if line else None
+            if res is None:
+                note = 'the baseline process printed no result (exit code %s)' % p.returncode
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.communicate()
+            note = 'not finished within %.0f s (MIOpen compiles its kernels on first use on a fresh box)' % budget_s
+    except OSError as e:
+        note = 'could not start the baseline process: %s' % e
+    if res is None:
+        res = {'value': None, 'unit': 'images/sec', 'note': note}
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_gpu_eager_baseline*.json')), reverse=True):
+            try:
+                rec = json.load(open(f))
+                if tuple(rec.get('workload_shape', (192, 640, 4))) == (H, W, B):
+                    res['recorded'] = {k: rec[k] for k in ('value', 'ms_per_step', 'sample') if k in rec}
+                    res['recorded']['source'] = os.path.relpath(f, ROOT)
+                    break
+            except Exception:
+                continue
+    ref = res['value'] if res.get('value') else (res.get('recorded') or {}).get('value')
+    if ref:
+        res['speedup_of_value'] = round(value / ref, 2)
+    return res
+
+
+def csrc_sha():
+    """sha256 (first 16 hex digits) over the kernel sources the running library was built from (csrc/*.hip, *.h, sorted)."""
+    import hashlib
+    d = os.path.join(ROOT, 'packnet-sfm_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith('.hip') or f.endswith('.h'):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(H, W, B):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json; PMC
     counters cannot be collected from inside this process).  Only returned for the workload the passes were collected on
-    (192x640 batch 4 unless the file says otherwise): None for any other shape, and None if no profile has been committed."""
+    (192x640 batch 4 unless the file says otherwise) AND for the kernel sources they were collected on: a profile whose `csrc_sha`
+    differs from the running build's is refused (None) -- the number must describe the kernel that ran.  FETCH_SIZE is corrected
+    with the factor calibrated on this part (tools/micro/fetch_calib.hip, profiles/r04_pmc_calibration.json: 2.0 for 4-byte and
+    16-byte per-lane streams and LDS-DMA alike; WRITE_SIZE 1.0)."""
     import glob
+    sha = csrc_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic*.json')), reverse=True):      # latest round first
         try:
             d = json.load(open(f))
             if tuple(d.get('workload_shape', (192, 640, 4))) != (H, W, B):
                 continue
+            if d.get('csrc_sha') != sha:
+                continue
             k = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
-            return {'hbm_bytes_per_launch': round(k['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch':
-                    round(k.get('algorithmic_bytes_per_launch', 0)), 'source': os.path.relpath(f, ROOT)}
+            alg = k.get('algorithmic_bytes_per_launch', 0)
+            return {'hbm_bytes_per_launch': round(k['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch': round(alg),
+                    'ratio_vs_algorithmic': round(k['hbm_bytes_per_launch'] / alg, 3) if alg else None,
+                    'fetch_bytes_corrected': round(k.get('fetch_bytes_per_launch', 0)), 'write_bytes': round(k.get('write_bytes_per_launch', 0)),
+                    'fetch_correction_factor': d.get('fetch_factor'), 'csrc_sha': sha, 'source': os.path.relpath(f, ROOT)}
         except Exception:
             continue
     return None
@@ -407,8 +468,11 @@ def main():
     ap.add_argument('--depth-net', default='PackNet01', choices=['PackNet01', 'PackNetSlim01'],
                     help='PackNet01 = the BASELINE.json metric; PackNetSlim01 = the d=4 / 32-channel-stem variant (not the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-gpu-baseline', action='store_true',
-                    help='skip the stock PyTorch-ROCm eager baseline of the same step on this GPU (`gpu_eager_baseline`, N=1 only)')
+    ap.add_argument('--gpu-baseline', default='auto', choices=['auto', 'on', 'off'],
+                    help='stock PyTorch-ROCm eager baseline of the same step on this GPU (`gpu_eager_baseline`, N=1 only).  On a '
+                         'fresh box MIOpen compiles its kernels during the first step (~4 minutes for the ~100 conv shapes), so '
+                         '`auto` gives a child process 45 s and otherwise quotes the figure recorded in profiles/; `on` waits')
+    ap.add_argument('--gpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the short 384x1280 batch-2 measurement (BASELINE.json configs[2] shape) that the default 192x640 '
@@ -418,6 +482,12 @@ def main():
     ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps here')
     args = ap.parse_args()
 
+    if args.gpu_baseline_worker:          # child of gpu_eager_baseline_bounded: one JSON line, nothing else
+        h, w, b = (int(v) for v in args.gpu_baseline_worker.split(','))
+        rec = gpu_eager_baseline(h, w, b, torch.device('cuda', 0), seconds_budget=1e9)
+        rec['workload_shape'] = [h, w, b]
+        print(json.dumps(rec), flush=True)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(_self_launch(args))
     if not torch.cuda.is_available():
@@ -513,12 +583,8 @@ def main():
                                                       '(BASELINE.json configs[2] shape)', 'global_batch': 2,
                                           'final_loss': round(extra['loss'], 6)},
                                'roofline': eroof}
-        if world == 1 and not ddp and not args.no_gpu_baseline:
-            try:
-                result['gpu_eager_baseline'] = gpu_eager_baseline(H, W, B, device)
-                result['gpu_eager_baseline']['speedup_of_value'] = round(value / result['gpu_eager_baseline']['value'], 2)
-            except Exception as e:          # a baseline must never take the measurement down
-                result['gpu_eager_baseline'] = {'value': None, 'error': '%s: %s' % (type(e).__name__, e)}
+        if world == 1 and not ddp and args.gpu_baseline != 'off':
+            result['gpu_eager_baseline'] = gpu_eager_baseline_bounded(H, W, B, value, None if args.gpu_baseline == 'on' else 45.0)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(H, W)
         try:        # RCCL prints a version banner through C stdio (block-buffered when stdout is a file): push it out FIRST

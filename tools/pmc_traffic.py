@@ -1,13 +1,24 @@
 """Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-launch HBM traffic of the dominant
 kernels (profiles/rNN_traffic.json).  Counters are in KB (TCC_EA0_RDREQ/WRREQ based, MI355X_MICROARCH.md section HBM):
-bytes = counter * 1024.  The conv kernels stage with 4-byte-per-lane loads, an access width for which FETCH_SIZE is
-NOT calibrated on gfx950 (the guide only pins the 2x under-count of 16-B/lane streams), so the read side is quoted raw
-and as-is; ratios between kernel versions are unaffected."""
+bytes = counter * 1024 * calibration factor.  Round 4 calibrated the factors on this part with kernels that move a known 2 GiB
+in the conv kernels' own access widths (tools/micro/fetch_calib.hip -> profiles/r04_pmc_calibration.json): FETCH_SIZE reports
+exactly half of the bytes for 4-byte-per-lane buffer loads, 16-byte-per-lane loads and 16-byte LDS-DMA alike (factor 2.0),
+WRITE_SIZE is exact (1.0).  The output records the factors and the sha of the kernel sources the passes ran on (bench.py only
+quotes a profile whose sha matches the running build)."""
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+try:
+    CAL = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_calibration.json')))
+    FETCH_FACTOR = float(CAL['fetch_factor']['read_dword'])        # (== read_ldsdma == read_dwordx4 on gfx950)
+    WRITE_FACTOR = float(CAL['write_factor']['write_dword'])
+except Exception:
+    FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 
 fetch_csv, write_csv, out = sys.argv[1:4]
 layer_csv = sys.argv[4] if len(sys.argv) > 4 else None   # bench.py --layer-table: adds the algorithmic bytes
@@ -31,10 +42,11 @@ res = {}
 for k in f:
     if not k.startswith('pnsfm::'):
         continue
-    fb = f[k] * 1024 / fn[k]
-    wb = w.get(k, 0.0) * 1024 / max(wn.get(k, 1), 1)
-    res[k] = {'launches_in_pass': fn[k], 'fetch_bytes_per_launch': fb, 'write_bytes_per_launch': wb,
-              'hbm_bytes_per_launch': fb + wb}
+    fraw = f[k] * 1024 / fn[k]
+    fb = fraw * FETCH_FACTOR
+    wb = w.get(k, 0.0) * 1024 / max(wn.get(k, 1), 1) * WRITE_FACTOR
+    res[k] = {'launches_in_pass': fn[k], 'fetch_bytes_per_launch': fb, 'fetch_bytes_per_launch_raw_counter': fraw,
+              'write_bytes_per_launch': wb, 'hbm_bytes_per_launch': fb + wb}
 if layer_csv:
     # algorithmic bytes of a conv launch = its input + output + weight tensors once (fp32)
     acc = {}
@@ -55,10 +67,18 @@ if layer_csv:
             res[name]['algorithmic_bytes_per_launch'] = a[0] / a[1]
 res['workload_shape'] = [int(v) for v in sys.argv[5].split(',')] if len(sys.argv) > 5 else [192, 640, 4]      # H, W, batch of the bench.py run the passes were collected on (bench.py only quotes
                                            # these numbers for that workload)
+res['fetch_factor'], res['write_factor'] = FETCH_FACTOR, WRITE_FACTOR
+sys.path.insert(0, ROOT)
+try:
+    import bench
+    res['csrc_sha'] = bench.csrc_sha()
+except Exception as e:
+    res['csrc_sha'] = None
+    print('csrc_sha unavailable:', e)
 res['_note'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` with a '
                 'primed tuning database (PNSFM_TUNE_DB: every launch is a training-step launch, no autotune candidates); '
-                'bytes = counter*1024 averaged over the launches of each kernel; FETCH_SIZE is quoted raw (4-byte/lane loads are '
-                'not a calibrated access width on gfx950). algorithmic = (input + output + weight) bytes of the layer, averaged '
+                'bytes = counter*1024*factor averaged over the launches of each kernel (FETCH_SIZE x 2.0, WRITE_SIZE x 1.0: '
+                'profiles/r04_pmc_calibration.json). algorithmic = (input + output + weight) bytes of the layer, averaged '
                 'over the launches of bench.py --layer-table.')
 json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
 for k, v in sorted(((k, v) for k, v in res.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches_in_pass'])[:12]:

@@ -73,6 +73,8 @@ int pnsfm_conv2d_backward_weight(const float* x, const float* dy, float* dw, flo
 int pnsfm_conv2d_forward_cat(const float* x0, int C0, const float* x1, int C1, const float* x2 /*nullable*/, int C2,
                              const float* wp_fwd, const float* bias /*nullable*/, float* y, int B, int Cout, int H, int W, int ks,
                              void* stream);
+/* 1 if pnsfm_conv2d_backward_weight_cat takes sources of C0 / C1 / C2 channels for this layer shape, else 0 (pure query) */
+int pnsfm_conv2d_cat_wgrad_supported(int C0, int C1, int C2, int Cout, int B, int H, int W, int ks);
 int pnsfm_conv2d_backward_weight_cat(const float* x0, int C0, const float* x1, int C1, const float* x2 /*nullable*/, int C2,
                                      const float* dy, float* dw, float* dbias /*nullable*/, int B, int Cout, int H, int W, int ks,
                                      void* stream);
@@ -274,6 +276,15 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
                               double* loss_sum, uint8_t* argmin, int J, int B, int H, int W,
                               float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
 /* d_warped:[J,B,3,H,W] = grad_scale * d(loss_sum)/d(warped), overwritten. */
+/* Variants that keep scalars on the device (round 4: no ATen launch between these kernels and autograd): forward_mean writes
+ * loss_mean float[1] = loss_sum / (B*H*W); backward_dev multiplies grad_scale by upstream[0] (device scalar, nullable) and takes
+ * clip = 0 | 1 (the byte layout of pnsfm_photometric_forward / _forward_clip). */
+int pnsfm_photometric_forward_mean(const float* warped, const float* ref, const float* target, float* loss_mean, uint8_t* argmin,
+                                   int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
+                                   void* stream);
+int pnsfm_photometric_backward_dev(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
+                                   float grad_scale, const float* upstream /*nullable*/, int J, int B, int H, int W,
+                                   float ssim_weight, float C1, float C2, int automask, int reduce_op, int clip, void* stream);
 int pnsfm_photometric_backward(const float* warped, const float* target, const uint8_t* argmin,
                                float* d_warped, float grad_scale, int J, int B, int H, int W,
                                float ssim_weight, float C1, float C2, int automask, int reduce_op, void* stream);
@@ -296,6 +307,14 @@ int pnsfm_photometric_backward_clip(const float* warped, const float* target, co
  * image:[B,3,H,W].  sums: double[2] = { sum |Sx|, sum |Sy| }. */
 int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums,
                              int B, int H, int W, void* stream);
+/* The same with the mean normalisation of the inverse depth fused (multiview_photometric_loss.py:269-271: inv /
+ * inv.mean(2, True).mean(3, True).clamp(min=1e-6)): inv_depth:[B,1,H,W] RAW inverse depth.  loss: float[1] = mean|Sx| + mean|Sy|,
+ * mean: float[B] = the clamped per-sample means (kept for backward).  Backward overwrites d_inv_depth with upstream[0] (device
+ * scalar, nullable = 1) * dloss/d(inv_depth), the normalisation's own gradient path included. */
+int pnsfm_smoothness_norm_forward(const float* inv_depth, const float* image, float* loss, float* mean,
+                                  int B, int H, int W, void* stream);
+int pnsfm_smoothness_norm_backward(const float* inv_depth, const float* image, const float* mean, const float* upstream /*nullable*/,
+                                   float* d_inv_depth, int B, int H, int W, void* stream);
 /* d_inv_norm = gx * d(sum|Sx|)/d(inv_norm) + gy * d(sum|Sy|)/d(inv_norm), overwritten. */
 int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* d_inv_norm,
                               float gx, float gy, int B, int H, int W, void* stream);

@@ -1742,6 +1742,17 @@ int pnsfm_conv2d_backward_weight_cat(const float* x0, int C0, const float* x1, i
   return wgrad_impl(x0, dy, dw, dbias, B, C0 + C1 + C2, Cout, H, W, ks, 1, H, W, stream, &ms);
 }
 
+// 1 when pnsfm_conv2d_backward_weight_cat takes these sources (the caller decides ONCE, up front, whether to concatenate for the
+// weight gradient instead of finding out from an error), else 0.  No launch, no error state.
+int pnsfm_conv2d_cat_wgrad_supported(int C0, int C1, int C2, int Cout, int B, int H, int W, int ks) {
+  if (C0 <= 0 || C1 <= 0 || C2 < 0 || C0 % 32 != 0 || (C2 > 0 && (C0 + C1) % 32 != 0)) return 0;
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) return 0;
+  const int Cin = C0 + C1 + C2;
+  const bool flat3 = ks == 1 && (H * W) % 32 == 0;
+  const int H3 = flat3 ? (H * W) / 32 : H, W3 = flat3 ? 32 : W;
+  return (conv_math() == 1 && wgrad3_supported(Cin, Cout, H3, W3, ks) && wgrad3_fits(B, Cin, Cout, H3, W3)) ? 1 : 0;
+}
+
 int pnsfm_conv2d_forward_strided(const float* x, const float* wp_fwd, const float* bias, float* y, int B, int Cin,
                                  int Cout, int Hin, int Win, int ks, int stride, void* stream) {
   const int P = ks / 2;

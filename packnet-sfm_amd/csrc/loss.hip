@@ -38,6 +38,23 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restr
   }
 }
 
+// the same second stage, finishing the scalar the caller wants: fout[0] = (float)(sum_v out[v] * scale[v]) -- the pixel mean of a loss
+// map, or sum|Sx|/nx + sum|Sy|/ny -- so that no ATen launch is needed between the kernels and autograd (round 4)
+__global__ void __launch_bounds__(256) sum_partials_scaled_kernel(const double* __restrict__ part, int n, int nvals, double s0, double s1,
+                                                                  double* __restrict__ out, float* __restrict__ fout) {
+  __shared__ double red[4];
+  double acc_out = 0.0;
+  for (int v = 0; v < nvals; ++v) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[(size_t)i * nvals + v];
+    const double tot = block_sum_256d(acc, red);
+    if (threadIdx.x == 0 && out) out[v] = tot;
+    acc_out += tot * (v == 0 ? s0 : s1);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fout[0] = (float)acc_out;
+}
+
 struct Cam {
   float k[9];     // target intrinsics K (row major)
   float ki[9];    // Kinv as the reference builds it (camera.py:72-80): K with 4 entries replaced
@@ -408,8 +425,10 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
 __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __restrict__ warped, const float* __restrict__ target,
                                                                const uint8_t* __restrict__ argmin, float* __restrict__ d_warped,
                                                                float grad_scale, int J, int B, int H, int W, float ssim_w,
-                                                               float C1, float C2, int automask, int reduce_op, int clip) {
+                                                               float C1, float C2, int automask, int reduce_op, int clip,
+                                                               const float* __restrict__ gdev) {
   PNSFM_DYN_SMEM(float, smem);
+  if (gdev) grad_scale *= gdev[0];        // upstream gradient of the scalar loss, still on the device (no `d * g` pass over d_warped)
   const int HW = H * W;
   const int b = blockIdx.z;
   const int tx0 = blockIdx.x * PH_T, ty0 = blockIdx.y * PH_T;
@@ -561,6 +580,103 @@ __global__ void __launch_bounds__(256) smoothness_bwd_kernel(const float* __rest
   d_inv[(size_t)b * HW + pix] = g;
 }
 
+// ---- smoothness of the MEAN-NORMALISED inverse depth, normalisation fused (round 4).  The reference normalises on the host side of
+// the kernel boundary: inv / inv.mean(2, True).mean(3, True).clamp(min=1e-6) (multiview_photometric_loss.py:269-271) -- four ATen
+// launches forward and ~eight backward per scale around two tiny kernels.  Here:
+//   forward : sn_mean_kernel (per-sample partial sums of d)  ->  sn_fwd_kernel (every block adds its sample's partials in a fixed
+//             order, m = max(mean, 1e-6), smoothness of d / m, partial |Sx|, |Sy| sums; block 0 of a sample stores m)  ->
+//             sum_partials_scaled_kernel (loss = sum|Sx|/nx + sum|Sy|/ny as a float)
+//   backward: with n = d / m and g_n = dL/dn:  dL/dd_i = g_n,i / m - [mean > 1e-6] * (sum_j g_n,j d_j) / (m^2 HW)
+//             sn_bwd_kernel writes g_n and per-block partials of sum g_n d;  sn_bwd_apply_kernel finishes in place.
+__global__ void __launch_bounds__(256) sn_mean_kernel(const float* __restrict__ inv, double* __restrict__ part, int HW) {
+  __shared__ double red[4];
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const double v = pix < HW ? (double)inv[(size_t)blockIdx.y * HW + pix] : 0.0;
+  const double t = block_sum_256d(v, red);
+  if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// m_b = clamp(mean of sample b, 1e-6): the partials are added in index order by every block alike (identical bits everywhere)
+__device__ __forceinline__ float sn_sample_mean(const double* __restrict__ mpart, int nblk, int HW, double* red, bool* clamped) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += mpart[i];
+  const double tot = block_sum_256d(acc, red);
+  __syncthreads();
+  const float mean = (float)(tot / (double)HW);
+  if (clamped) *clamped = !(mean > 1e-6f);
+  return mean > 1e-6f ? mean : 1e-6f;
+}
+
+__global__ void __launch_bounds__(256) sn_fwd_kernel(const float* __restrict__ inv, const float* __restrict__ image,
+                                                      const double* __restrict__ mpart, double* __restrict__ sums,
+                                                      float* __restrict__ mean_out, int H, int W) {
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const float m = sn_sample_mean(mpart + (size_t)b * gridDim.x, (int)gridDim.x, HW, red, nullptr);
+  if (blockIdx.x == 0 && threadIdx.x == 0) mean_out[b] = m;
+  float sx = 0.f, sy = 0.f;
+  if (pix < HW) {
+    const int y = pix / W, x = pix - y * W;
+    const float* ib = inv + (size_t)b * HW;
+    const float* im = image + (size_t)b * 3 * HW;
+    const float r = ib[pix] / m;
+    if (x + 1 < W) sx = fabsf((r - ib[pix + 1] / m) * edge_weight(im, HW, pix, pix + 1));
+    if (y + 1 < H) sy = fabsf((r - ib[pix + W] / m) * edge_weight(im, HW, pix, pix + W));
+  }
+  const double tx = block_sum_256d((double)sx, red);
+  const double ty = block_sum_256d((double)sy, red);
+  if (threadIdx.x == 0) {
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    sums[2 * blk] = tx;
+    sums[2 * blk + 1] = ty;
+  }
+}
+
+__global__ void __launch_bounds__(256) sn_bwd_kernel(const float* __restrict__ inv, const float* __restrict__ image,
+                                                      const float* __restrict__ mean, float* __restrict__ g_n, double* __restrict__ part,
+                                                      float gx, float gy, int H, int W) {
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const float m = mean[b];
+  float g = 0.f, d = 0.f;
+  if (pix < HW) {
+    const int y = pix / W, x = pix - y * W;
+    const float* ib = inv + (size_t)b * HW;
+    const float* im = image + (size_t)b * 3 * HW;
+    d = ib[pix];
+    const float r = d / m;
+    if (x + 1 < W) { const float w = edge_weight(im, HW, pix, pix + 1); g += gx * sgnf((r - ib[pix + 1] / m) * w) * w; }
+    if (x >= 1)    { const float w = edge_weight(im, HW, pix - 1, pix); g -= gx * sgnf((ib[pix - 1] / m - r) * w) * w; }
+    if (y + 1 < H) { const float w = edge_weight(im, HW, pix, pix + W); g += gy * sgnf((r - ib[pix + W] / m) * w) * w; }
+    if (y >= 1)    { const float w = edge_weight(im, HW, pix - W, pix); g -= gy * sgnf((ib[pix - W] / m - r) * w) * w; }
+    g_n[(size_t)b * HW + pix] = g;
+  }
+  const double t = block_sum_256d((double)g * (double)d, red);
+  if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(256) sn_bwd_apply_kernel(float* __restrict__ d_inv, const float* __restrict__ mean,
+                                                            const double* __restrict__ part, const float* __restrict__ gdev, int HW) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += part[(size_t)b * gridDim.x + i];
+  const double dot = block_sum_256d(acc, red);
+  const float m = mean[b];
+  // m == 1e-6 means the clamp was active (a mean that is exactly 1e-6 un-clamped differs from it by the clamp's own tie rule only)
+  const float corr = m > 1e-6f ? (float)(dot / ((double)m * (double)m * (double)HW)) : 0.f;
+  const float g = gdev ? gdev[0] : 1.f;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix < HW) {
+    float* p = d_inv + (size_t)b * HW + pix;
+    *p = g * (*p / m - corr);
+  }
+}
+
 }  // namespace pnsfm
 
 using namespace pnsfm;
@@ -674,12 +790,12 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
 
 static int photometric_backward_impl(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
                                      float grad_scale, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
-                                     int automask, int reduce_op, int clip, void* stream) {
+                                     int automask, int reduce_op, int clip, void* stream, const float* gdev = nullptr) {
   if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_backward: bad shape (J<=3)"); return -1; }
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
   const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
   PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, warped, target, argmin, d_warped,
-               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op, clip);
+               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op, clip, gdev);
   return check_launch("photometric_backward");
 }
 
@@ -707,6 +823,67 @@ int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* 
   PNSFM_LAUNCH(smoothness_fwd_kernel, grid, dim3(256), 0, s, inv_norm, image, part, H, W);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 2, sums);
   return check_launch("smoothness_forward");
+}
+
+int pnsfm_photometric_forward_mean(const float* warped, const float* ref, const float* target, float* loss_mean, uint8_t* argmin,
+                                   int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
+                                   void* stream) {
+  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
+  if (!(ssim_weight >= 0.f) || (ssim_weight == 0.f && reduce_op == 0)) {
+    set_error("photometric_forward: ssim_weight must be > 0 (or == 0 with the 'mean' reduce op)");
+    return -1;
+  }
+  if (automask && reduce_op != 0) { set_error("photometric_forward: automask requires the 'min' reduce op"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
+  const int nblk = (int)(grid.x * grid.y * grid.z);
+  ScratchLease lease(s, (size_t)nblk * sizeof(double));
+  double* part = lease.as<double>();
+  if (!part) return -1;
+  const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
+  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
+               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
+  PNSFM_LAUNCH(sum_partials_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, 1.0 / ((double)B * H * W), 0.0,
+               (double*)nullptr, loss_mean);
+  return check_launch("photometric_forward_mean");
+}
+
+int pnsfm_photometric_backward_dev(const float* warped, const float* target, const uint8_t* argmin, float* d_warped,
+                                   float grad_scale, const float* upstream, int J, int B, int H, int W, float ssim_weight, float C1,
+                                   float C2, int automask, int reduce_op, int clip, void* stream) {
+  return photometric_backward_impl(warped, target, argmin, d_warped, grad_scale, J, B, H, W, ssim_weight, C1, C2, automask,
+                                   reduce_op, clip ? 1 : 0, stream, upstream);
+}
+
+int pnsfm_smoothness_norm_forward(const float* inv_depth, const float* image, float* loss, float* mean, int B, int H, int W,
+                                  void* stream) {
+  if (B < 1 || H < 2 || W < 2) { set_error("smoothness_norm_forward: bad shape"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ceil_div(H * W, 256), B);
+  const int nblk = (int)(grid.x * grid.y);
+  ScratchLease lease(s, (size_t)3 * nblk * sizeof(double));
+  double* mpart = lease.as<double>();
+  if (!mpart) return -1;
+  double* part = mpart + nblk;
+  PNSFM_LAUNCH(sn_mean_kernel, grid, dim3(256), 0, s, inv_depth, mpart, H * W);
+  PNSFM_LAUNCH(sn_fwd_kernel, grid, dim3(256), 0, s, inv_depth, image, (const double*)mpart, part, mean, H, W);
+  PNSFM_LAUNCH(sum_partials_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 2, 1.0 / ((double)B * H * (W - 1)),
+               1.0 / ((double)B * (H - 1) * W), (double*)nullptr, loss);
+  return check_launch("smoothness_norm_forward");
+}
+
+int pnsfm_smoothness_norm_backward(const float* inv_depth, const float* image, const float* mean, const float* upstream,
+                                   float* d_inv_depth, int B, int H, int W, void* stream) {
+  if (B < 1 || H < 2 || W < 2) { set_error("smoothness_norm_backward: bad shape"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(ceil_div(H * W, 256), B);
+  ScratchLease lease(s, (size_t)grid.x * grid.y * sizeof(double));
+  double* part = lease.as<double>();
+  if (!part) return -1;
+  PNSFM_LAUNCH(sn_bwd_kernel, grid, dim3(256), 0, s, inv_depth, image, mean, d_inv_depth, part, (float)(1.0 / ((double)B * H * (W - 1))),
+               (float)(1.0 / ((double)B * (H - 1) * W)), H, W);
+  PNSFM_LAUNCH(sn_bwd_apply_kernel, grid, dim3(256), 0, s, d_inv_depth, mean, (const double*)part, upstream, H * W);
+  return check_launch("smoothness_norm_backward");
 }
 
 int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* d_inv_norm, float gx, float gy, int B, int H,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_forward_cat": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight_cat": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv2d_cat_wgrad_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "pnsfm_conv2d_forward_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_groupnorm_ws_doubles": (_sz, [_i, _i, _i]),
@@ -64,6 +65,10 @@ SIGNATURES = {
     "pnsfm_photometric_backward": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
     "pnsfm_photometric_forward_clip": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _f, _p, _p, _p]),
     "pnsfm_photometric_backward_clip": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
+    "pnsfm_photometric_forward_mean": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _p]),
+    "pnsfm_photometric_backward_dev": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _p]),
+    "pnsfm_smoothness_norm_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_smoothness_norm_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_smoothness_forward": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_smoothness_backward": (_i, [_p, _p, _p, _f, _f, _i, _i, _i, _p]),
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),

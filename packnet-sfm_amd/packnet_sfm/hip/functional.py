@@ -177,7 +177,18 @@ class _WgradStream:
     side stream next to the node's own data gradient, but the compute stream waits for it before the node returns.
     """
     import os as _os
-    enabled = _os.environ.get('PNSFM_WGRAD_STREAM', '0') == '1'
+    _env = _os.environ.get('PNSFM_WGRAD_STREAM', '0')
+    enabled = _env not in ('0', '')
+    # PNSFM_WGRAD_STREAM=<n> with n > 1: only layers whose gradient map has at most n pixels (batch x H x W) go to the side stream --
+    # the low-resolution layers, whose launches are resident in one round and latency-bound (tools/bx3_ablate.py), overlap well;
+    # the full-resolution ones are MFMA-bound and only contend
+    max_pixels = int(_env) if _env.isdigit() and int(_env) > 1 else None
+
+    @classmethod
+    def use_for(cls, dy):
+        if not (cls.enabled and dy.is_cuda):
+            return False
+        return cls.max_pixels is None or dy.shape[0] * dy.shape[-2] * dy.shape[-1] <= cls.max_pixels
     _streams = {}
     _pending = set()
     _uses = {}          # id(parameter) -> [forward uses whose backward has not run yet, shared-in-this-step flag]
@@ -367,7 +378,7 @@ class Conv2dFn(Function):
         detached = _WgradStream.side_ok(*ctx.params)
         sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[1])
         wait = None
-        if want_w and _WgradStream.enabled and dy.is_cuda:
+        if want_w and _WgradStream.use_for(dy):
             r = _WgradStream.run(lambda: ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb), x, dy,
                                  detached=detached)
             (dw, db), wait = (r, None) if detached else r
@@ -392,9 +403,10 @@ class Conv2dCatFn(Function):
     the inputs receive channel slices of it (views)."""
 
     @staticmethod
-    def forward(ctx, weight, bias, cache, recording, *xs):
+    def forward(ctx, weight, bias, cache, recording, cat_wgrad, *xs):
         xs = tuple(t.contiguous() for t in xs)
-        need_dx = any(ctx.needs_input_grad[4:])
+        ctx.cat_wgrad = cat_wgrad
+        need_dx = any(ctx.needs_input_grad[5:])
         wp_fwd, wp_bwd = cache.get(weight, need_dx)
         Cout, Cin, ks, _ = weight.shape
         if sum(t.shape[1] for t in xs) != Cin:
@@ -416,31 +428,52 @@ class Conv2dCatFn(Function):
         dw = db = None
         detached = _WgradStream.side_ok(*ctx.params)
         sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[0])
-        if any(ctx.needs_input_grad[4:]):
+        want_w = ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1])
+
+        def wgrad():
+            if ctx.cat_wgrad:
+                return ops.conv2d_backward_weight_cat(xs, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+            # outside the multi-source weight-gradient kernel's envelope (decided once, in conv2d_cat): concatenate for this kernel
+            return ops.conv2d_backward_weight(torch.cat(xs, 1), dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+
+        wait = None
+        if want_w and _WgradStream.use_for(dy):
+            r = _WgradStream.run(wgrad, dy, *xs, detached=detached)
+            (dw, db), wait = (r, None) if detached else r
+            want_w = False
+        if any(ctx.needs_input_grad[5:]):
             dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
             c0 = 0
             for i, t in enumerate(xs):
-                if ctx.needs_input_grad[4 + i]:
+                if ctx.needs_input_grad[5 + i]:
                     dxs[i] = dx[:, c0:c0 + t.shape[1]]
                 c0 += t.shape[1]
-        if ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1]):
-            try:
-                dw, db = ops.conv2d_backward_weight_cat(xs, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
-            except _HipError:      # outside the split weight-gradient kernel's envelope: concatenate for this one kernel
-                dw, db = ops.conv2d_backward_weight(torch.cat(xs, 1), dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
-        return (dw, db, None, None) + tuple(dxs)
+        if want_w:
+            dw, db = wgrad()
+        if wait is not None:
+            wait()
+        return (dw, db, None, None, None) + tuple(dxs)
+
+
+def _cat_wgrad_ok(xs, weight):
+    """May the multi-source weight-gradient kernels (wgrad3 / wgrad4, pnsfm_conv2d_backward_weight_cat) take these sources?  Their
+    channel tiles are 32 wide (64 with two ci tiles per wave): every source but the last must end on such a boundary.  Decided ONCE
+    per call here (the backward used to find out by catching every HipError, real launch failures included)."""
+    return ops.conv2d_cat_wgrad_supported([t.shape[1] for t in xs], weight.shape[0], xs[0].shape[2], xs[0].shape[3], weight.shape[2],
+                                          B=xs[0].shape[0])
 
 
 def conv2d_cat(xs, weight, bias, cache):
-    """xs: tuple of 2 or 3 NCHW tensors.  Falls back to torch.cat + conv2d when the shape is outside the multi-source kernels'
-    envelope (first / second tensor not ending on a 16-channel boundary, < 16 channels, f32 arithmetic mode)."""
+    """xs: tuple of 2 or 3 NCHW tensors.  Falls back to torch.cat + conv2d when the shape is outside the multi-source FORWARD
+    kernel's envelope (first / second tensor not ending on a 16-channel boundary, < 16 channels, f32 arithmetic mode); a shape
+    the forward takes but the multi-source weight-gradient kernels do not concatenates for that one kernel only."""
     import os
     C0 = xs[0].shape[1]
     ok = os.environ.get('PNSFM_CAT_FOLD', '1') != '0' and len(xs) in (2, 3) and C0 % 16 == 0 and (len(xs) == 2 or (C0 + xs[1].shape[1]) % 16 == 0) and get_conv_math() == 'bx3' \
         and sum(t.shape[1] for t in xs) >= 16
     if not ok:
         return conv2d(torch.cat(xs, 1), weight, bias, cache)
-    return Conv2dCatFn.apply(weight, bias, cache, torch.is_grad_enabled(), *xs)
+    return Conv2dCatFn.apply(weight, bias, cache, torch.is_grad_enabled(), _cat_wgrad_ok(xs, weight), *xs)
 
 
 class Conv2dStride2Fn(Function):
@@ -470,7 +503,7 @@ class Conv2dStride2Fn(Function):
         want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
         detached = _WgradStream.side_ok(*ctx.params)
         wait = None
-        if want_w and _WgradStream.enabled and dy.is_cuda:
+        if want_w and _WgradStream.use_for(dy):
             r = _WgradStream.run(lambda: ops.conv2d_backward_weight_strided(x, dy, ks, 2, want_bias=has_bias), x, dy,
                                  detached=detached)
             (dw, db), wait = (r, None) if detached else r
@@ -569,7 +602,7 @@ class Conv3d1to8Fn(Function):
         want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         detached = _WgradStream.side_ok(*ctx.params)
         wait = None
-        if want_w and _WgradStream.enabled and dout.is_cuda:
+        if want_w and _WgradStream.use_for(dout):
             r = _WgradStream.run(lambda: ops.conv3d_backward_weight(p, dout), p, dout, detached=detached)
             (dw3, db3), wait = (r, None) if detached else r
             want_w = False
@@ -968,24 +1001,31 @@ REDUCE_MIN, REDUCE_MEAN = 0, 1
 
 
 class PhotometricFn(Function):
-    """mean over pixels of min/mean over candidates of (w*SSIM-loss + (1-w)*L1); scalar float32."""
+    """mean over pixels of min/mean over candidates of (w*SSIM-loss + (1-w)*L1); scalar float32.  Without clipping the scalar is
+    finished on the device (pixel mean as float32) and backward hands the upstream gradient to the kernel as a device scalar: no
+    ATen launch around the kernels (round 4; the `d * g` pass over the [J,B,3,H,W] gradient alone was 25 us per scale)."""
 
     @staticmethod
     def forward(ctx, warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):
         warped, ref, target = warped.contiguous(), ref.contiguous(), target.contiguous()
-        loss_sum, argmin = ops.photometric_forward(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
         J, B, _, H, W = warped.shape
-        ctx.save_for_backward(warped, target, argmin)
         ctx.meta = (ssim_w, C1, C2, automask, reduce_op, B * H * W, clip_loss > 0.0)
-        return (loss_sum / float(B * H * W)).to(torch.float32).reshape(())
+        if clip_loss > 0.0:
+            loss_sum, argmin = ops.photometric_forward(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
+            ctx.save_for_backward(warped, target, argmin)
+            return (loss_sum / float(B * H * W)).to(torch.float32).reshape(())
+        loss, argmin = ops.photometric_forward_mean(warped, ref, target, ssim_w, C1, C2, automask, reduce_op)
+        ctx.save_for_backward(warped, target, argmin)
+        return loss.reshape(())
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         warped, target, argmin = ctx.saved_tensors
         ssim_w, C1, C2, automask, reduce_op, n, clip = ctx.meta
-        d = ops.photometric_backward(warped, target, argmin, 1.0 / n, ssim_w, C1, C2, automask, reduce_op, clip)
-        return d * g, None, None, None, None, None, None, None, None
+        up = g.reshape(1).to(torch.float32).contiguous()
+        d = ops.photometric_backward_dev(warped, target, argmin, 1.0 / n, up, ssim_w, C1, C2, automask, reduce_op, clip)
+        return d, None, None, None, None, None, None, None, None
 
 
 def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):
@@ -1015,3 +1055,27 @@ class SmoothnessFn(Function):
 
 def smoothness(inv_norm, image):
     return SmoothnessFn.apply(inv_norm, image)
+
+
+class SmoothnessNormFn(Function):
+    """mean|Sx| + mean|Sy| of the edge-aware first differences of inv_depth / clamp(mean_hw(inv_depth), 1e-6): the reference's
+    calc_smoothness_loss (multiview_photometric_loss.py:255-285) for ONE scale, the mean normalisation fused into the kernels
+    (3 launches forward, 2 backward; the ATen form around SmoothnessFn is ~10 + ~12)."""
+
+    @staticmethod
+    def forward(ctx, inv_depth, image):
+        inv_depth, image = inv_depth.contiguous(), image.contiguous()
+        loss, mean = ops.smoothness_norm_forward(inv_depth, image)
+        ctx.save_for_backward(inv_depth, image, mean)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        inv_depth, image, mean = ctx.saved_tensors
+        up = g.reshape(1).to(torch.float32).contiguous()
+        return ops.smoothness_norm_backward(inv_depth, image, mean, up), None
+
+
+def smoothness_norm(inv_depth, image):
+    return SmoothnessNormFn.apply(inv_depth, image)

@@ -152,6 +152,12 @@ def conv2d_forward_cat(xs, wp_fwd, bias, Cout, ks):
     return y
 
 
+def conv2d_cat_wgrad_supported(channels, Cout, H, W, ks, B=1):
+    """Will conv2d_backward_weight_cat take sources with these channel counts (list of 2 or 3)?  Pure query."""
+    C = list(channels) + [0] * (3 - len(channels))
+    return bool(_lib.get().pnsfm_conv2d_cat_wgrad_supported(C[0], C[1], C[2], Cout, B, H, W, ks))
+
+
 def conv2d_backward_weight_cat(xs, dy, ks, want_bias=True, dw_out=None, db_out=None):
     _chk(*xs, dy); _f32(*xs, dy)
     B, _, H, W = xs[0].shape
@@ -412,6 +418,54 @@ def photometric_backward(warped, target, argmin, grad_scale, ssim_weight, C1, C2
                                                      J, B, H, W, float(ssim_weight), float(C1), float(C2), int(automask),
                                                      int(reduce_op), _stream(warped)), "photometric_backward")
     return d_warped
+
+
+def photometric_forward_mean(warped, ref, target, ssim_weight, C1, C2, automask, reduce_op):
+    """-> (loss float32[1] = pixel mean of the reduced photometric map, argmin uint8[B,H,W]); no clipping."""
+    _chk(warped, ref, target); _f32(warped, ref, target)
+    J, B, _, H, W = warped.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=warped.device)
+    argmin = torch.empty((B, H, W), dtype=torch.uint8, device=warped.device)
+    _lib.check(_lib.get().pnsfm_photometric_forward_mean(_ptr(warped), _ptr(ref), _ptr(target), _ptr(loss), _ptr(argmin), J, B, H, W,
+                                                         float(ssim_weight), float(C1), float(C2), int(automask), int(reduce_op),
+                                                         _stream(warped)), "photometric_forward_mean")
+    return loss, argmin
+
+
+def photometric_backward_dev(warped, target, argmin, grad_scale, upstream, ssim_weight, C1, C2, automask, reduce_op, clip=False):
+    """d_warped = grad_scale * upstream[0] * d(loss_sum)/d(warped); `upstream`: float32 device scalar (or None)."""
+    _chk(warped, target, argmin); _f32(warped, target)
+    if upstream is not None:
+        _chk(upstream); _f32(upstream)
+    J, B, _, H, W = warped.shape
+    d_warped = torch.empty_like(warped)
+    _lib.check(_lib.get().pnsfm_photometric_backward_dev(_ptr(warped), _ptr(target), _ptr(argmin), _ptr(d_warped), float(grad_scale),
+                                                         _ptr(upstream), J, B, H, W, float(ssim_weight), float(C1), float(C2),
+                                                         int(automask), int(reduce_op), int(bool(clip)), _stream(warped)),
+               "photometric_backward_dev")
+    return d_warped
+
+
+def smoothness_norm_forward(inv_depth, image):
+    """-> (loss float32[1], mean float32[B]): smoothness of inv_depth / clamp(mean_hw(inv_depth), 1e-6)."""
+    _chk(inv_depth, image); _f32(inv_depth, image)
+    B, _, H, W = image.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=image.device)
+    mean = torch.empty((B,), dtype=torch.float32, device=image.device)
+    _lib.check(_lib.get().pnsfm_smoothness_norm_forward(_ptr(inv_depth), _ptr(image), _ptr(loss), _ptr(mean), B, H, W, _stream(image)),
+               "smoothness_norm_forward")
+    return loss, mean
+
+
+def smoothness_norm_backward(inv_depth, image, mean, upstream):
+    _chk(inv_depth, image, mean); _f32(inv_depth, image, mean)
+    if upstream is not None:
+        _chk(upstream); _f32(upstream)
+    B, _, H, W = image.shape
+    d = torch.empty_like(inv_depth)
+    _lib.check(_lib.get().pnsfm_smoothness_norm_backward(_ptr(inv_depth), _ptr(image), _ptr(mean), _ptr(upstream), _ptr(d), B, H, W,
+                                                         _stream(image)), "smoothness_norm_backward")
+    return d
 
 
 def smoothness_forward(inv_norm, image):

@@ -97,9 +97,8 @@ class MultiViewPhotometricLoss(LossBase):
         if self.smooth_loss_weight > 0.0:
             smoothness_loss = 0.0
             for i in range(n):
-                d = inv_depths[i]
-                d_norm = d / d.mean(2, True).mean(3, True).clamp(min=1e-6)
-                smoothness_loss = smoothness_loss + HF.smoothness(d_norm, images[i]) / 2 ** i
+                # (mean normalisation of the inverse depth, reference :269-271, fused into the kernels)
+                smoothness_loss = smoothness_loss + HF.smoothness_norm(inv_depths[i], images[i]) / 2 ** i
             smoothness_loss = self.smooth_loss_weight * (smoothness_loss / n)
             self.add_metric('smoothness_loss', smoothness_loss)
             # in place, as the reference does (:338-339): its 'photometric_loss' metric is a detached alias of this

@@ -101,6 +101,36 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
+@pytest.mark.parametrize('scale', [1.0, 1e-7])
+def test_smoothness_norm_fused(emulated_kernels, scale):
+    """hip.functional.smoothness_norm (mean normalisation of the inverse depth fused into the smoothness kernels, round 4) against
+    the reference's formula on torch autograd (multiview_photometric_loss.py:255-285, utils/depth.py:165-198): value and gradient,
+    the normalisation's own gradient path included; scale 1e-7 makes the per-sample mean fall under the 1e-6 clamp (no gradient
+    through the mean then).  An upstream gradient != 1 checks the device-scalar path."""
+    from packnet_sfm.hip import functional as HF
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 9, 21
+    d = ((0.2 + torch.rand(B, 1, H, W, generator=g)) * scale).requires_grad_(True)
+    img = torch.rand(B, 3, H, W, generator=g)
+
+    def ref(dd):
+        n = dd / dd.mean(2, True).mean(3, True).clamp(min=1e-6)
+        gx = n[:, :, :, :-1] - n[:, :, :, 1:]
+        gy = n[:, :, :-1, :] - n[:, :, 1:, :]
+        wx = torch.exp(-(img[:, :, :, :-1] - img[:, :, :, 1:]).abs().mean(1, True))
+        wy = torch.exp(-(img[:, :, :-1, :] - img[:, :, 1:, :]).abs().mean(1, True))
+        return (gx * wx).abs().mean() + (gy * wy).abs().mean()
+
+    lr = ref(d) * 0.37
+    lr.backward()
+    gr = d.grad.clone()
+    d.grad = None
+    lh = HF.smoothness_norm(d, img) * 0.37
+    lh.backward()
+    P.check(lh, lr.detach(), 1e-5, 'smoothness_norm value')
+    P.check(d.grad, gr, 2e-5, 'smoothness_norm gradient')
+
+
 @pytest.mark.parametrize('direct_a', [6, 5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
                                    (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3),

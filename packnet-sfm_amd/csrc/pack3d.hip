@@ -211,53 +211,70 @@ __global__ void __launch_bounds__(256) conv3d_fwd_x4_kernel(const float* __restr
 // then keeps all 216 in VGPRs.  Dropped.)
 // Lanes still run along x (coalesced); the flattened (chunk, pixel) index keeps tiny planes (6x20 maps, 5x5 / 7x7 weight
 // volumes of the kernel composition) on full waves.  Weights are uniform global reads (scalar loads -> SGPR operands).
+// Round 4: the kernel is bound by the number of load instructions (72 per plane and thread: ~90 per output, TA-limited at 1.24 TB/s
+// effective).  Lanes run along x, so the x - 1 / x + 1 neighbours of a lane's centre value ARE its neighbour lanes' centre values:
+// a thread now loads the three centre values of a plane (one per dy) per feature -- 24 loads instead of 72 -- and takes the other
+// 48 from the lanes next to it (wave shifts).  A wave covers 62 outputs: lanes 0 and 63 are halo lanes that only supply centres
+// (97 % lane efficiency); row / image ends are masked (x == 0 has no left neighbour whatever lane holds pixel - 1).  The d loop
+// has the SAME trip count (len + 2) on every lane -- lanes of a wave may sit in different d chunks -- so the shifts are never
+// executed under divergence.
 template <int NF>
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
                                                             float* __restrict__ dp, int D, int H, int W, int len) {
   const int HW = H * W, DHW = D * HW;
   const int nchunk = (D + len - 1) / len;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const bool active = idx < nchunk * HW;
-  const int chunk = active ? idx / HW : 0;
-  const int pix = active ? idx - chunk * HW : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long lin = ((long)blockIdx.x * 4 + wave) * 62 + lane - 1;      // flattened (chunk, pixel) index of this lane
+  const bool inr = lin >= 0 && lin < (long)nchunk * HW;
+  const bool active = inr && lane >= 1 && lane <= 62;
+  const int chunk = inr ? (int)(lin / HW) : 0;
+  const int pix = inr ? (int)(lin - (long)chunk * HW) : 0;
   const int y = pix / W, x = pix - y * W;
   const int d0 = chunk * len;
   const int dend = (d0 + len < D) ? d0 + len : D;
+  const bool has_l = x > 0, has_r = x + 1 < W;
   // one descriptor per feature slab [D][H][W] (the range-checked window); all wave-uniform, they live in SGPRs
   pnsfm_buf gbuf[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) gbuf[f] = pnsfm_make_buf(dout + ((size_t)blockIdx.z * NF + f) * DHW, (unsigned)DHW * 4u);
   float* ob = dp + (size_t)blockIdx.z * DHW + pix;
   const unsigned kOut = 0x7fffffffu;       // out-of-range byte offset -> the load returns 0
-  unsigned off[9];                         // in-plane byte offsets of the 9 neighbours (kOut outside the image)
+  unsigned off[3];                         // in-plane byte offsets of the centre column in rows y + 1, y, y - 1 (kOut outside the image)
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int yy = y - dy + 1, xx = x - dx + 1;
-      const bool ok = active && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      off[dy * 3 + dx] = ok ? (unsigned)(yy * W + xx) * 4u : kOut;
-    }
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y - dy + 1;
+    off[dy] = (inr && yy >= 0 && yy < H) ? (unsigned)(yy * W + x) * 4u : kOut;
+  }
   // a_lo -> output dd-1 (complete after this plane), a_mid -> output dd, a_hi -> output dd+1
   float a_lo = 0.f, a_mid = 0.f, a_hi = 0.f;
 #pragma unroll 1
-  for (int dd = d0 - 1; dd <= dend; ++dd) {
-    const bool dok = dd >= 0 && dd < D;
+  for (int t = 0; t < len + 2; ++t) {
+    const int dd = d0 - 1 + t;
+    const bool dok = dd >= 0 && dd < D && dd <= dend;
     const unsigned plane = dok ? (unsigned)dd * (unsigned)HW * 4u : 0u;
     float g[NF][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const unsigned vo = (dok && off[t] != kOut) ? plane + off[t] : kOut;
+    for (int dy = 0; dy < 3; ++dy) {
+      const unsigned vo = (dok && off[dy] != kOut) ? plane + off[dy] : kOut;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) g[f][t] = pnsfm_buf_load(gbuf[f], vo, 0u);
+      for (int f = 0; f < NF; ++f) g[f][dy * 3 + 1] = pnsfm_buf_load(gbuf[f], vo, 0u);
     }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const float c = g[f][dy * 3 + 1];
+        const float r = __shfl_down(c, 1), l = __shfl_up(c, 1);
+        g[f][dy * 3 + 0] = has_r ? r : 0.f;       // dx = 0: xx = x + 1
+        g[f][dy * 3 + 2] = has_l ? l : 0.f;       // dx = 2: xx = x - 1
+      }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        a_lo = fmaf(w3[f * 27 + t], g[f][t], a_lo);             // dz = 0: d = dd - 1
-        a_mid = fmaf(w3[f * 27 + 9 + t], g[f][t], a_mid);       // dz = 1: d = dd
-        a_hi = fmaf(w3[f * 27 + 18 + t], g[f][t], a_hi);        // dz = 2: d = dd + 1
+      for (int tp = 0; tp < 9; ++tp) {
+        a_lo = fmaf(w3[f * 27 + tp], g[f][tp], a_lo);             // dz = 0: d = dd - 1
+        a_mid = fmaf(w3[f * 27 + 9 + tp], g[f][tp], a_mid);       // dz = 1: d = dd
+        a_hi = fmaf(w3[f * 27 + 18 + tp], g[f][tp], a_hi);        // dz = 2: d = dd + 1
       }
     if (active && dd - 1 >= d0 && dd - 1 < dend) ob[(size_t)(dd - 1) * HW] = a_lo;
     a_lo = a_mid;
@@ -457,7 +474,7 @@ int pnsfm_conv3d_backward_data(const float* dout, const float* w3, float* dp, in
   // run length along d: 8 (25 % halo planes) when that still gives every CU a few blocks, shorter for small volumes
   int len = D < 8 ? D : 8;
   while (len > 2 && (long)B * ceil_div(D, len) * H * W < 2L * 256 * 256) len = ceil_div(len, 2);
-  const dim3 grid(ceil_div(ceil_div(D, len) * H * W, 256), 1, B);
+  const dim3 grid(ceil_div(ceil_div(ceil_div(D, len) * H * W, 62), 4), 1, B);      // 62 outputs per wave (two halo lanes)
   if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
   else PNSFM_LAUNCH((conv3d_dgrad_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
   return check_launch("conv3d_backward_data");

@@ -260,6 +260,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, F f) {
 
 #define __syncthreads() hipemu::syncthreads()
 template <class T> inline T __shfl_down(T v, unsigned d) { return hipemu::shfl_generic(v, hipemu::my_lane() + (int)d); }
+template <class T> inline T __shfl_up(T v, unsigned d) { return hipemu::shfl_generic(v, hipemu::my_lane() - (int)d); }
 template <class T> inline T __shfl_xor(T v, int m) { return hipemu::shfl_generic(v, hipemu::my_lane() ^ m); }
 template <class T> inline T __shfl(T v, int src) { return hipemu::shfl_generic(v, src); }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

@@ -319,6 +319,23 @@ int pnsfm_smoothness_norm_backward(const float* inv_depth, const float* image, c
 int pnsfm_smoothness_backward(const float* inv_norm, const float* image, float* d_inv_norm,
                               float gx, float gy, int B, int H, int W, void* stream);
 
+/* ---- batched strided-window operations (one launch for a list of copies / accumulations / zero-fills) -------------------------
+ * The collapsed form of PackLayerConv3d (layers01.py:213-247) computes the r-pixel border frame on thin strips: gathering
+ * the strips, dropping rows of the Conv3d output, pasting the results into the interior result and the mirror-image gradient
+ * scatters are windows of NCHW tensors.  ops_host: HOST array of n_ops (<= PNSFM_MAX_REGION_OPS) descriptors, copied into the kernel
+ * arguments; pointers are device pointers, strides in ELEMENTS.  op: 0 dst = src, 1 dst += src, 2 dst = 0 (src ignored).  Operations
+ * of one launch must not overlap each other's destinations. */
+#define PNSFM_MAX_REGION_OPS 12
+typedef struct {
+  const float* src;
+  float* dst;
+  int n[4];
+  long long src_stride[4];
+  long long dst_stride[4];
+  int op;
+} pnsfm_region_op;
+int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream);
+
 /* ---- Adam over a flat fp32 parameter buffer (torch.optim.Adam semantics, no amsgrad) -------
  * replaces the optimizer.step() of models/model_wrapper.py:128-149 / trainers/horovod_trainer.py:93
  * for one parameter group.  grad_scale multiplies the gradient first (1/world_size after a

@@ -1126,19 +1126,44 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   }
 }
 
-// second stage of the pixel-split f32 weight-gradient kernels (this file and conv2d_wgrad2.hip): out = sum over Z slabs, in slab
-// order.  A slab is [n0 floats -> out0 | n1 floats -> out1] (dw, then dbias).
+// second stage of the pixel-split f32 weight-gradient kernels (this file and conv2d_wgrad2.hip): out = sum over Z slabs.  A slab is
+// [n0 floats -> out0 | n1 floats -> out1] (dw, then dbias).  The slabs of an output are shared out to ZG = 256 / OPB thread groups
+// (group g adds slabs g, g + ZG, ... with four independent partial sums) that meet in LDS in a fixed order: bit-reproducible, and
+// Z = 640 slabs (the 3 -> 64 stem at 192x640) are 10-40 dependent steps instead of 640 (the serial form took 41 us per launch).
+template <int OPB>
 __global__ void __launch_bounds__(256) sum_slabs_kernel(const float* __restrict__ ws, size_t zstride, int Z, float* __restrict__ out0,
                                                         size_t n0, float* __restrict__ out1, size_t n1) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n0 + n1) return;
-  float s = ws[i];
-  for (int z = 1; z < Z; ++z) s += ws[(size_t)z * zstride + i];
-  if (i < n0) out0[i] = s; else out1[i - n0] = s;
+  constexpr int ZG = 256 / OPB;
+  __shared__ float red[ZG][OPB];
+  const int ol = threadIdx.x % OPB, zg = threadIdx.x / OPB;
+  const size_t i = (size_t)blockIdx.x * OPB + ol;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n0 + n1) {
+    const float* p = ws + i;
+    int z = zg;
+    for (; z + 3 * ZG < Z; z += 4 * ZG) {
+      s0 += p[(size_t)z * zstride];
+      s1 += p[(size_t)(z + ZG) * zstride];
+      s2 += p[(size_t)(z + 2 * ZG) * zstride];
+      s3 += p[(size_t)(z + 3 * ZG) * zstride];
+    }
+    for (; z < Z; z += ZG) s0 += p[(size_t)z * zstride];
+  }
+  red[zg][ol] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zg == 0 && i < n0 + n1) {
+    float s = red[0][ol];
+#pragma unroll
+    for (int g = 1; g < ZG; ++g) s += red[g][ol];
+    if (i < n0) out0[i] = s; else out1[i - n0] = s;
+  }
 }
 int launch_sum_slabs(const float* ws, size_t zstride, int Z, float* out0, size_t n0, float* out1, size_t n1, hipStream_t s) {
   if (!out1) n1 = 0;
-  PNSFM_LAUNCH(sum_slabs_kernel, dim3((unsigned)ceil_div_sz(n0 + n1, 256)), dim3(256), 0, s, ws, zstride, Z, out0, n0, out1, n1);
+  const size_t n = n0 + n1;
+  // few outputs (a 64 x 75 stem gradient): 16 per workgroup, 16 slab groups each, so that the launch still covers the chip
+  if (n < (size_t)64 * 512) PNSFM_LAUNCH((sum_slabs_kernel<16>), dim3((unsigned)ceil_div_sz(n, 16)), dim3(256), 0, s, ws, zstride, Z, out0, n0, out1, n1);
+  else PNSFM_LAUNCH((sum_slabs_kernel<64>), dim3((unsigned)ceil_div_sz(n, 64)), dim3(256), 0, s, ws, zstride, Z, out0, n0, out1, n1);
   return check_launch("conv2d_backward_weight (slab sum)");
 }
 
@@ -1649,7 +1674,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
               if ((long)base3 * split < 200 && split < tiles3) continue;      // cannot fill the chip
               if ((long)base3 * split > 16L * 256 && split > 1) break;
               if (WMv != wm_most && split > 2) break;     // fewer co tiles per workgroup only pays when it replaces the pixel split
-              if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) continue;
+              if (ms && NT == 2 && !conv_src_aligned(*ms, Cin, 64)) continue;
               for (int occ = 0; occ < ((ks == 3 && NT == 1 && W3 % 8 == 0) ? 2 : 1); ++occ) {    // occ 1: the three-workgroups-per-CU build
                 const int wmv = WMv | (occ ? 8 : 0);
                 const float tms = time_on_stream(s, 2, [&]() { return enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split, NT, wmv, s, ms); });

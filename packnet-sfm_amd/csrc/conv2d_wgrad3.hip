@@ -502,12 +502,12 @@ int enqueue_wgrad3(const float* x, const float* dy, float* dw, float* dbias, int
     return -1;
   }
   if (NT != 2 || !wgrad3_nt2_ok(Cin, ks)) NT = 1;
-  if (ms && NT == 2 && (ms->C0 % 64 != 0 || (ms->C0 + ms->C1) % 64 != 0)) NT = 1;     // a 64-channel tile would straddle two tensors
+  if (ms && NT == 2 && !conv_src_aligned(*ms, Cin, 64)) NT = 1;     // a 64-channel tile would straddle two tensors
   // two instantiations do not fit their register budget without spilling (3x3, four co tiles per workgroup, 32-column tiles: two
   // ci tiles per wave, and the three-workgroups-per-CU build): those requests run the one-ci-tile / two-workgroup build instead
   const bool tight = ks == 3 && wgrad3_WM(Cout, WMwant & 7) == 4 && wgrad3_tc(W) == 32 && W % 8 == 0;
   if (tight) { NT = 1; WMwant &= 7; }
-  if (ms && (ms->C0 % 32 != 0 || (ms->C0 + ms->C1) % 32 != 0)) {
+  if (ms && !conv_src_aligned(*ms, Cin, 32)) {
     set_error("conv2d_backward_weight (split-bf16): the input tensors must end on 32-channel boundaries");
     return -1;
   }

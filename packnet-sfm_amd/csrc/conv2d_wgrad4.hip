@@ -357,7 +357,7 @@ int enqueue_wgrad4(const float* x, const float* dy, float* dw, float* dbias, int
     set_error("conv2d_backward_weight (nine taps): tensor too large for 32-bit buffer offsets");
     return -1;
   }
-  if (ms && (ms->C0 % 32 != 0 || (ms->C0 + ms->C1) % 32 != 0)) {
+  if (ms && !conv_src_aligned(*ms, Cin, 32)) {
     set_error("conv2d_backward_weight (nine taps): the input tensors must end on 32-channel boundaries");
     return -1;
   }

@@ -153,6 +153,36 @@ static int grid_for(size_t total) {
   return (int)g;
 }
 
+// ---- batched 4-D region operations: ONE launch for a list of (copy | add | zero) operations on strided 4-D windows of fp32 tensors.
+// The collapsed packing block (layers01.py: PackLayerConv3d) gathers border strips, selects rows of them, pastes results into the
+// interior result and scatters / accumulates the matching gradients: ~33 slice-assignments, cats, fills and strided adds per block and
+// step on ATen (profiles/r04: ~0.5 ms per step in launches of 4-30 us).  Each autograd Function now issues one launch of this kernel.
+// dst / src addresses are base + sum_i idx_i * stride_i (element strides, any layout); blockIdx.y = operation, grid-stride over elements.
+struct RegionOp {
+  const float* src;      // null for zero
+  float* dst;
+  int n[4];
+  long long ss[4], ds[4];
+  int op;                // 0 copy, 1 add (dst += src), 2 zero
+};
+struct RegionOps { RegionOp o[PNSFM_MAX_REGION_OPS]; };
+
+__global__ void __launch_bounds__(256) region_ops_kernel(RegionOps ops) {
+  const RegionOp& r = ops.o[blockIdx.y];
+  const long long total = (long long)r.n[0] * r.n[1] * r.n[2] * r.n[3];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    long long t = e;
+    const int i3 = (int)(t % r.n[3]); t /= r.n[3];
+    const int i2 = (int)(t % r.n[2]); t /= r.n[2];
+    const int i1 = (int)(t % r.n[1]);
+    const int i0 = (int)(t / r.n[1]);
+    float* d = r.dst + i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
+    if (r.op == 2) { *d = 0.f; continue; }
+    const float v = r.src[i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3]];
+    *d = r.op == 1 ? *d + v : v;
+  }
+}
+
 }  // namespace pnsfm
 
 using namespace pnsfm;
@@ -202,6 +232,29 @@ int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float*
   PNSFM_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, hp);
   PNSFM_LAUNCH(adam_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, (const float*)hp);
   return check_launch("adam_flat_step");
+}
+
+int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream) {
+  if (n_ops < 1 || n_ops > PNSFM_MAX_REGION_OPS) { set_error("region_ops: 1..%d operations per launch (got %d)", PNSFM_MAX_REGION_OPS, n_ops); return -1; }
+  RegionOps ops;
+  long long most = 0;
+  const pnsfm_region_op* in = static_cast<const pnsfm_region_op*>(ops_host);
+  for (int i = 0; i < n_ops; ++i) {
+    RegionOp& r = ops.o[i];
+    r.src = in[i].src; r.dst = in[i].dst; r.op = in[i].op;
+    long long total = 1;
+    for (int k = 0; k < 4; ++k) {
+      r.n[k] = in[i].n[k]; r.ss[k] = in[i].src_stride[k]; r.ds[k] = in[i].dst_stride[k];
+      if (r.n[k] < 1) { set_error("region_ops: empty extent in operation %d", i); return -1; }
+      total *= r.n[k];
+    }
+    if (r.op < 0 || r.op > 2 || !r.dst || (r.op != 2 && !r.src)) { set_error("region_ops: bad operation %d", i); return -1; }
+    if (total > most) most = total;
+  }
+  long long gx = (most + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  PNSFM_LAUNCH(region_ops_kernel, dim3((unsigned)gx, (unsigned)n_ops), dim3(256), 0, (hipStream_t)stream, ops);
+  return check_launch("region_ops");
 }
 
 }  // extern "C"

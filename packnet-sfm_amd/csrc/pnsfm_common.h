@@ -194,6 +194,11 @@ struct ConvSrc {
   const float* x2;
   int C0, C1;
 };
+// every source but the LAST ends on a `granule`-channel boundary (two sources: C0 + C1 == Cin is the ragged end of the channels,
+// handled like a single tensor's ragged end by the buffer range check -- not a boundary)
+static inline bool conv_src_aligned(const ConvSrc& ms, int Cin, int granule) {
+  return ms.C0 % granule == 0 && (ms.C0 + ms.C1 == Cin || (ms.C0 + ms.C1) % granule == 0);
+}
 
 // --- conv2d implicit-GEMM geometry (shared by forward / backward-data / packers) -----------
 // GEMM view: M = output channels, N = output pixels, K = (tap, input channel).

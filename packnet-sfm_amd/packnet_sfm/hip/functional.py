@@ -656,17 +656,24 @@ def compose_pack_weight(W2, W3):
     return ComposePackWeightFn.apply(W2, W3, torch.is_grad_enabled())
 
 
+def _R(op, dst, src=None):
+    return (op, dst, src)
+
+
 class PackBorderSplitFn(Function):
     """Collapsed packing block, input side: P -> (P itself for the interior convolution, the top+bottom row strips,
     the left+right column strips; strips batched along dim 0).  Plain slicing would make autograd zero-fill and add a
-    full-size dP four times (slice_backward); here the strip gradients are added straight into the interior path's dP."""
+    full-size dP four times (slice_backward); here the strip gradients are added straight into the interior path's dP.
+    Round 4: the four strip gathers are ONE launch (ops.region_ops), and so are the four gradient accumulations."""
 
     @staticmethod
     def forward(ctx, P, S):
-        h, w = P.shape[2], P.shape[3]
+        B, C, h, w = P.shape
         ctx.S = S
-        tb = torch.cat((P[:, :, :S], P[:, :, h - S:]), 0)
-        lr = torch.cat((P[:, :, :, :S], P[:, :, :, w - S:]), 0)
+        tb = P.new_empty((2 * B, C, S, w))
+        lr = P.new_empty((2 * B, C, h, S))
+        ops.region_ops([_R(ops.REGION_COPY, tb[:B], P[:, :, :S]), _R(ops.REGION_COPY, tb[B:], P[:, :, h - S:]),
+                        _R(ops.REGION_COPY, lr[:B], P[:, :, :, :S]), _R(ops.REGION_COPY, lr[B:], P[:, :, :, w - S:])])
         return P.view_as(P), tb, lr
 
     @staticmethod
@@ -677,12 +684,13 @@ class PackBorderSplitFn(Function):
             raise RuntimeError('pack_border_split: the interior path must be used')
         dP = dP.contiguous()        # the interior conv's freshly written backward-data buffer: accumulate in place
         B, h, w = dP.shape[0], dP.shape[2], dP.shape[3]
+        # (the row strips and the column strips overlap in the corners: two launches keep every destination single-writer per launch)
         if d_tb is not None:
-            dP[:, :, :S] += d_tb[:B]
-            dP[:, :, h - S:] += d_tb[B:]
+            d_tb = d_tb.contiguous()
+            ops.region_ops([_R(ops.REGION_ADD, dP[:, :, :S], d_tb[:B]), _R(ops.REGION_ADD, dP[:, :, h - S:], d_tb[B:])])
         if d_lr is not None:
-            dP[:, :, :, :S] += d_lr[:B]
-            dP[:, :, :, w - S:] += d_lr[B:]
+            d_lr = d_lr.contiguous()
+            ops.region_ops([_R(ops.REGION_ADD, dP[:, :, :, :S], d_lr[:B]), _R(ops.REGION_ADD, dP[:, :, :, w - S:], d_lr[B:])])
         return dP, None
 
 
@@ -693,30 +701,33 @@ def pack_border_split(P, S):
 class StripSelectFn(Function):
     """z: [2B, C, S, w] (dim=2) or [2B, C, h, S] (dim=3), the Conv3d of the batched strips.  Keeps the 2r rows/cols whose
     Conv3d neighbourhood lies inside the strip: the first 2r of the leading half, the last 2r of the trailing half.
-    Backward writes every element of dz exactly once (no zero-fill + copy)."""
+    Backward writes every element of dz exactly once (no zero-fill + copy).  One launch each way (ops.region_ops)."""
 
     @staticmethod
     def forward(ctx, z, B, r, dim):
         ctx.meta = (B, r, dim, tuple(z.shape))
+        n2 = 2 * r
         if dim == 2:
-            return torch.cat((z[:B, :, :2 * r], z[B:, :, 1:]), 0)
-        return torch.cat((z[:B, :, :, :2 * r], z[B:, :, :, 1:]), 0)
+            out = z.new_empty((z.shape[0], z.shape[1], n2, z.shape[3]))
+            ops.region_ops([_R(ops.REGION_COPY, out[:B], z[:B, :, :n2]), _R(ops.REGION_COPY, out[B:], z[B:, :, 1:])])
+        else:
+            out = z.new_empty((z.shape[0], z.shape[1], z.shape[2], n2))
+            ops.region_ops([_R(ops.REGION_COPY, out[:B], z[:B, :, :, :n2]), _R(ops.REGION_COPY, out[B:], z[B:, :, :, 1:])])
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
         B, r, dim, shape = ctx.meta
+        g = g.contiguous()
         dz = g.new_empty(shape)
+        n2 = 2 * r
         if dim == 2:
-            dz[:B, :, :2 * r] = g[:B]
-            dz[:B, :, 2 * r:] = 0
-            dz[B:, :, 1:] = g[B:]
-            dz[B:, :, :1] = 0
+            ops.region_ops([_R(ops.REGION_COPY, dz[:B, :, :n2], g[:B]), _R(ops.REGION_ZERO, dz[:B, :, n2:]),
+                            _R(ops.REGION_COPY, dz[B:, :, 1:], g[B:]), _R(ops.REGION_ZERO, dz[B:, :, :1])])
         else:
-            dz[:B, :, :, :2 * r] = g[:B]
-            dz[:B, :, :, 2 * r:] = 0
-            dz[B:, :, :, 1:] = g[B:]
-            dz[B:, :, :, :1] = 0
+            ops.region_ops([_R(ops.REGION_COPY, dz[:B, :, :, :n2], g[:B]), _R(ops.REGION_ZERO, dz[:B, :, :, n2:]),
+                            _R(ops.REGION_COPY, dz[B:, :, :, 1:], g[B:]), _R(ops.REGION_ZERO, dz[B:, :, :, :1])])
         return dz, None, None, None
 
 
@@ -727,16 +738,18 @@ def strip_select(z, B, r, dim):
 class PackBorderPasteFn(Function):
     """Collapsed packing block, output side: overwrite the r-pixel frame of the interior result y (in place: y is the
     interior conv's own output buffer) with the strip results o_tb [2B,C,2r,w] / o_lr [2B,C,h,2r] (only their outer r
-    rows / columns are valid).  Replaces two torch.cat copies forward and a zero-fill + copy backward."""
+    rows / columns are valid).  Replaces two torch.cat copies forward and a zero-fill + copy backward; one launch forward, one
+    backward (every element of d_tb, d_lr and dy has exactly one writer)."""
 
     @staticmethod
     def forward(ctx, y, o_tb, o_lr, r):
         B, h, w = y.shape[0], y.shape[2], y.shape[3]
         ctx.r = r
-        y[:, :, r:h - r, :r] = o_lr[:B, :, r:h - r, :r]
-        y[:, :, r:h - r, w - r:] = o_lr[B:, :, r:h - r, r:]
-        y[:, :, :r] = o_tb[:B, :, :r]
-        y[:, :, h - r:] = o_tb[B:, :, r:]
+        o_tb, o_lr = o_tb.contiguous(), o_lr.contiguous()
+        ops.region_ops([_R(ops.REGION_COPY, y[:, :, r:h - r, :r], o_lr[:B, :, r:h - r, :r]),
+                        _R(ops.REGION_COPY, y[:, :, r:h - r, w - r:], o_lr[B:, :, r:h - r, r:]),
+                        _R(ops.REGION_COPY, y[:, :, :r], o_tb[:B, :, :r]),
+                        _R(ops.REGION_COPY, y[:, :, h - r:], o_tb[B:, :, r:])])
         ctx.mark_dirty(y)
         ctx.shapes = (tuple(o_tb.shape), tuple(o_lr.shape))
         return y
@@ -745,19 +758,23 @@ class PackBorderPasteFn(Function):
     @once_differentiable
     def backward(ctx, g):
         r = ctx.r
+        g = g.contiguous()
         B, h, w = g.shape[0], g.shape[2], g.shape[3]
         s_tb, s_lr = ctx.shapes
-        d_tb = g.new_zeros(s_tb)
-        d_lr = g.new_zeros(s_lr)
-        d_tb[:B, :, :r] = g[:, :, :r]
-        d_tb[B:, :, r:] = g[:, :, h - r:]
-        d_lr[:B, :, r:h - r, :r] = g[:, :, r:h - r, :r]
-        d_lr[B:, :, r:h - r, r:] = g[:, :, r:h - r, w - r:]
-        dy = g.clone()
-        dy[:, :, :r] = 0
-        dy[:, :, h - r:] = 0
-        dy[:, :, :, :r] = 0
-        dy[:, :, :, w - r:] = 0
+        d_tb, d_lr, dy = g.new_empty(s_tb), g.new_empty(s_lr), torch.empty_like(g)
+        ops.region_ops([
+            # d_tb [2B,C,2r,w]: leading half rows 0..r-1 <- top frame, rows r.. zero; trailing half rows r.. <- bottom frame, rows ..r-1 zero
+            _R(ops.REGION_COPY, d_tb[:B, :, :r], g[:, :, :r]), _R(ops.REGION_ZERO, d_tb[:B, :, r:]),
+            _R(ops.REGION_COPY, d_tb[B:, :, r:], g[:, :, h - r:]), _R(ops.REGION_ZERO, d_tb[B:, :, :r]),
+            # dy: the interior of g, frame zero (the frame's gradient belongs to the strips)
+            _R(ops.REGION_COPY, dy[:, :, r:h - r, r:w - r], g[:, :, r:h - r, r:w - r]),
+            _R(ops.REGION_ZERO, dy[:, :, :r]), _R(ops.REGION_ZERO, dy[:, :, h - r:]),
+            _R(ops.REGION_ZERO, dy[:, :, r:h - r, :r]), _R(ops.REGION_ZERO, dy[:, :, r:h - r, w - r:])])
+        ops.region_ops([
+            # d_lr [2B,C,h,2r]: only rows r..h-r-1 of the outer r columns carry gradient (the corners went to the row strips)
+            _R(ops.REGION_COPY, d_lr[:B, :, r:h - r, :r], g[:, :, r:h - r, :r]), _R(ops.REGION_ZERO, d_lr[:B, :, r:h - r, r:]),
+            _R(ops.REGION_COPY, d_lr[B:, :, r:h - r, r:], g[:, :, r:h - r, w - r:]), _R(ops.REGION_ZERO, d_lr[B:, :, r:h - r, :r]),
+            _R(ops.REGION_ZERO, d_lr[:, :, :r]), _R(ops.REGION_ZERO, d_lr[:, :, h - r:])])
         return dy, d_tb, d_lr, None
 
 

@@ -675,6 +675,46 @@ def adam_flat_step(param, grad, exp_avg, exp_avg_sq, hp):
                                                _stream(param)), "adam_flat_step")
 
 
+# ------------------------------------------------------------------------------- batched region ops
+class _RegionOp(ctypes.Structure):          # mirrors pnsfm_region_op (include/pnsfm.h)
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n', ctypes.c_int * 4), ('src_stride', ctypes.c_longlong * 4),
+                ('dst_stride', ctypes.c_longlong * 4), ('op', ctypes.c_int)]
+
+
+REGION_COPY, REGION_ADD, REGION_ZERO = 0, 1, 2
+MAX_REGION_OPS = 12
+
+
+def region_ops(items):
+    """items: list of (op, dst_view, src_view | None).  Views are <= 4-D windows (any strides) of fp32 tensors on one device; shapes of
+    dst and src must match.  ONE kernel launch per MAX_REGION_OPS items (csrc/elementwise.hip: region_ops_kernel)."""
+    if not items:
+        return
+    ref = items[0][1]
+    for i0 in range(0, len(items), MAX_REGION_OPS):
+        chunk = items[i0:i0 + MAX_REGION_OPS]
+        arr = (_RegionOp * len(chunk))()
+        for k, (op, dst, src) in enumerate(chunk):
+            if dst.dtype != torch.float32 or (src is not None and src.dtype != torch.float32):
+                raise RuntimeError("region_ops needs float32 tensors")
+            if _lib.REQUIRE_CUDA and not dst.is_cuda:
+                raise RuntimeError("packnet_sfm HIP op got a %s tensor: the HIP kernels run on MI355X only, there is no CPU fallback" % dst.device)
+            if dst.dim() > 4 or (src is not None and tuple(src.shape) != tuple(dst.shape)) or dst.device != ref.device:
+                raise RuntimeError("region_ops: windows must be <= 4-D, of equal shape, on one device")
+            pad = 4 - dst.dim()
+            shape = (1,) * pad + tuple(dst.shape)
+            if 0 in shape:
+                raise RuntimeError("region_ops: empty window")
+            arr[k].dst = dst.data_ptr()
+            arr[k].src = src.data_ptr() if src is not None else None
+            arr[k].op = int(op)
+            for d in range(4):
+                arr[k].n[d] = shape[d]
+                arr[k].dst_stride[d] = 0 if d < pad else dst.stride(d - pad)
+                arr[k].src_stride[d] = 0 if (src is None or d < pad) else src.stride(d - pad)
+        _lib.check(_lib.get().pnsfm_region_ops(ctypes.byref(arr), len(chunk), _stream(ref)), "region_ops")
+
+
 # ---------------------------------------------------------------------------------------------- prof
 def prof_enable(on):
     _lib.get().pnsfm_prof_enable(1 if on else 0)

@@ -360,7 +360,7 @@ def test_two_rank_gradient_averaging():
 
 # ------------------------------------------------------------------------------------- (f) the decoder's concatenations
 @pytest.mark.parametrize('case', [(2, (64, 64, 1), 64, 48, 160, 3, 0), (4, (128, 128, 1), 128, 24, 80, 3, 1), (2, (512, 512), 512, 12, 40, 3, 2),
-                                  (1, (64, 64, 1), 64, 192, 640, 3, 3)])
+                                  (1, (64, 64, 1), 64, 192, 640, 3, 3), (2, (64, 1), 64, 48, 160, 3, 4), (2, (128, 33), 64, 24, 80, 3, 5)])
 def test_conv2d_cat_multi_source_gpu(case):
     """iconv1 .. iconv5 of PackNet01 read cat(unpacked, skip[, upsampled inverse depth]) (reference PackNet01.py:138-174); here the
     concatenation is folded into the K loop of the split-bf16 forward and weight-gradient kernels.  Against F.conv2d on the

@@ -893,9 +893,15 @@ def _check_conv2d_cat(device, B, Cs, Cout, H, W, ks, seed):
 
 
 @pytest.mark.parametrize('case', [(2, (32, 32, 1), 16, 6, 20, 3, 0), (1, (64, 32), 40, 5, 8, 3, 1), (1, (16, 5), 32, 4, 32, 5, 2),
-                                  (1, (32, 64, 3), 8, 3, 16, 3, 3), (1, (8, 8), 16, 4, 8, 3, 4)])
+                                  (1, (32, 64, 3), 8, 3, 16, 3, 3), (1, (8, 8), 16, 4, 8, 3, 4), (1, (64, 1), 32, 6, 24, 3, 5),
+                                  (2, (32, 33), 16, 5, 16, 3, 6)])
 def test_conv2d_cat_multi_source(emulated_kernels, case):
     """The decoder's cat(unpacked, skip[, upsampled disparity]) as a multi-source K loop: three and two tensors, a ragged last tensor, a
     first tensor of 16 channels (forward folds, the weight gradient falls back to one concatenation: 32-channel granule), and a shape
-    outside the envelope (8-channel tensors: plain torch.cat path)."""
+    outside the envelope (8-channel tensors: plain torch.cat path); two tensors whose SECOND is ragged (PackNet01 version '1B':
+    (up + skip, upsampled inverse depth) = 64 + 1 channels) -- the end of the channels is not a boundary, the multi-source weight
+    gradient takes them (round 4: the guard used to demand a 32-channel boundary there and the caller fell back silently)."""
     _check_conv2d_cat('cpu', *case)
+    if case[1] in ((64, 1), (32, 33)):
+        from packnet_sfm.hip import ops
+        assert ops.conv2d_cat_wgrad_supported(list(case[1]), case[2], case[3], case[4], case[5], B=case[0])

@@ -307,6 +307,15 @@ int pnsfm_photometric_backward_clip(const float* warped, const float* target, co
  * image:[B,3,H,W].  sums: double[2] = { sum |Sx|, sum |Sy| }. */
 int pnsfm_smoothness_forward(const float* inv_norm, const float* image, double* sums,
                              int B, int H, int W, void* stream);
+/* L1-only photometric loss (ssim_loss_weight == 0) with the 'min' reduce op and / or clip_loss > 0: the reference then reduces and
+ * clips per-CHANNEL candidate maps (multiview_photometric_loss.py:205-219, 238-246).  loss_mean: float[1]; rec: int32[B,H,W] for
+ * backward ('min': (candidate*3 + channel) | clamped << 7; 'mean': bit mask of clamped (candidate, channel) pairs).
+ * (ssim_loss_weight == 0 with 'mean' and no clipping coincides with the SSIM kernels' channel mean: pnsfm_photometric_forward.) */
+int pnsfm_photometric_l1_forward(const float* warped, const float* ref, const float* target, float* loss_mean, int* rec,
+                                 int J, int B, int H, int W, int automask, int reduce_op, float clip_loss, void* stream);
+int pnsfm_photometric_l1_backward(const float* warped, const float* target, const int* rec, float* d_warped, float grad_scale,
+                                  const float* upstream /*nullable*/, int J, int B, int H, int W, int automask, int reduce_op,
+                                  void* stream);
 /* The same with the mean normalisation of the inverse depth fused (multiview_photometric_loss.py:269-271: inv /
  * inv.mean(2, True).mean(3, True).clamp(min=1e-6)): inv_depth:[B,1,H,W] RAW inverse depth.  loss: float[1] = mean|Sx| + mean|Sy|,
  * mean: float[B] = the clamped per-sample means (kept for backward).  Backward overwrites d_inv_depth with upstream[0] (device

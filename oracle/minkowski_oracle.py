@@ -64,7 +64,7 @@ def batchnorm(feats, weight, bias, eps=1e-5):
 
 def densify(coords, feats, shape, ts):
     B, _, H, W = shape
-    dense = feats.new_zeros(B, H // ts, W // ts, feats.shape[1])
+    dense = feats.new_zeros(B, -(-H // ts), -(-W // ts), feats.shape[1])        # ceil: floor(c / ts) of the last coordinate + 1
     dense[coords[:, 0], coords[:, 1] // ts, coords[:, 2] // ts] = feats
     return dense.permute(0, 3, 1, 2).contiguous()
 

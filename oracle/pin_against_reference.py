@@ -577,6 +577,21 @@ def main():
         torch.save(fx, os.path.join(GOLD, 'nrs.pt'))
         print('  wrote nrs.pt (%.1f KB)' % (os.path.getsize(os.path.join(GOLD, 'nrs.pt')) / 1024))
         return
+    if only == ['loss_l1']:   # round 4: the L1-only photometric loss with the 'min' reduce op and / or clipping (per-CHANNEL maps,
+        # multiview_photometric_loss.py:205-219,238-246); own generator and file, the other fixtures stay untouched
+        fx = case_loss(torch.Generator().manual_seed(20260926), cases=(
+            ('loss_l1_min', dict(num_scales=4, ssim_loss_weight=0.0, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                                 automask_loss=True, clip_loss=0.0), True),
+            ('loss_l1_clip_min', dict(num_scales=4, ssim_loss_weight=0.0, smooth_loss_weight=0.001, photometric_reduce_op='min',
+                                      automask_loss=True, clip_loss=0.5), True),
+            ('loss_l1_clip_mean', dict(num_scales=4, ssim_loss_weight=0.0, smooth_loss_weight=0.01, photometric_reduce_op='mean',
+                                       automask_loss=False, clip_loss=0.5), False),
+            ('loss_l1_min_noauto', dict(num_scales=4, ssim_loss_weight=0.0, smooth_loss_weight=0.05, photometric_reduce_op='min',
+                                        automask_loss=False, clip_loss=0.0), False)), keep_clip=True)
+        path = os.path.join(GOLD, 'loss_l1.pt')
+        torch.save(fx, path)
+        print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+        return
     if only == ['slim']:      # added later: own generator, leaves the four original fixture files untouched
         fx = case_slim(torch.Generator().manual_seed(20260924))
         path = os.path.join(GOLD, 'slim.pt')

@@ -580,6 +580,103 @@ __global__ void __launch_bounds__(256) smoothness_bwd_kernel(const float* __rest
   d_inv[(size_t)b * HW + pix] = g;
 }
 
+// ---- L1-only photometric loss (ssim_loss_weight == 0) with the 'min' reduce op and / or clipping (round 4).  Without the SSIM term
+// the reference keeps every candidate as a THREE-channel map (multiview_photometric_loss.py:205-213): clipping takes mean / std over
+// B*3*H*W elements of each candidate (:214-219) and 'min' runs over the concatenated channels of all candidates (:243-244), i.e. over
+// (candidate, channel) pairs -- not what the SSIM kernels' per-pixel channel mean computes.  No 3x3 window is involved, so these are
+// plain per-pixel kernels.  Candidate order as in the reference: for each context j: warped_j, then (automask) the unwarped ref_j.
+//   stats != null : statistics pre-pass of clip_loss -- per-block partials [block][ncand][2] of (sum, sum of squares), nothing else
+//   rec           : per pixel, 'min': index (candidate * 3 + channel) | clamped << 7; 'mean': bit mask of the clamped pairs
+__global__ void __launch_bounds__(256) l1cand_fwd_kernel(const float* __restrict__ warped, const float* __restrict__ ref,
+                                                          const float* __restrict__ target, const float* __restrict__ thr,
+                                                          double* __restrict__ part, int* __restrict__ rec, double* __restrict__ stats,
+                                                          int J, int B, int H, int W, int automask, int reduce_op) {
+  __shared__ double red[4];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const bool valid = pix < HW;
+  const int ncand = J * (automask ? 2 : 1);
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  float t[3] = {0.f, 0.f, 0.f};
+  if (valid)
+    for (int ch = 0; ch < 3; ++ch) t[ch] = target[((size_t)b * 3 + ch) * HW + pix];
+  float best = 0.f, sum = 0.f;
+  int best_i = 0, best_clamped = 0, mask = 0;
+  for (int c = 0; c < ncand; ++c) {
+    const int j = automask ? c >> 1 : c;
+    const float* img = ((automask && (c & 1)) ? ref : warped) + ((size_t)j * B + b) * 3 * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = 0; ch < 3; ++ch) {
+      float v = valid ? fabsf(img[(size_t)ch * HW + pix] - t[ch]) : 0.f;
+      if (stats != nullptr) { s1 += (double)v; s2 += (double)v * (double)v; continue; }
+      int cl = 0;
+      if (thr != nullptr && v > thr[c]) { v = thr[c]; cl = 1; }
+      const int idx = c * 3 + ch;
+      if (idx == 0 || v < best) { best = v; best_i = idx; best_clamped = cl; }
+      sum += v;
+      mask |= cl << idx;
+    }
+    if (stats != nullptr) {
+      const double a = block_sum_256d(s1, red);
+      const double q = block_sum_256d(s2, red);
+      if (threadIdx.x == 0) { stats[(blk * ncand + c) * 2] = a; stats[(blk * ncand + c) * 2 + 1] = q; }
+    }
+  }
+  if (stats != nullptr) return;
+  float contrib = 0.f;
+  if (valid) {
+    contrib = reduce_op == 0 ? best : sum / (float)(3 * ncand);
+    rec[(size_t)b * HW + pix] = reduce_op == 0 ? (best_i | (best_clamped << 7)) : mask;
+  }
+  const double sblk = block_sum_256d((double)contrib, red);
+  if (threadIdx.x == 0) part[blk] = sblk;
+}
+
+// thresholds of the clipped candidates from the per-block statistics: thr[c] = mean + clip * std (unbiased) over n elements
+__global__ void __launch_bounds__(256) l1cand_thr_kernel(const double* __restrict__ stats, int nblk, int ncand, double n, float clip,
+                                                          float* __restrict__ thr) {
+  __shared__ double red[4];
+  for (int c = 0; c < ncand; ++c) {
+    double a = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += stats[((size_t)i * ncand + c) * 2]; q += stats[((size_t)i * ncand + c) * 2 + 1]; }
+    const double s1 = block_sum_256d(a, red);
+    const double s2 = block_sum_256d(q, red);
+    if (threadIdx.x == 0) {
+      const double mean = s1 / n;
+      double var = (s2 - n * mean * mean) / (n - 1.0);
+      if (var < 0.0) var = 0.0;
+      thr[c] = (float)(mean + (double)clip * sqrt(var));
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) l1cand_bwd_kernel(const float* __restrict__ warped, const float* __restrict__ target,
+                                                          const int* __restrict__ rec, float* __restrict__ d_warped, float grad_scale,
+                                                          const float* __restrict__ gdev, int J, int B, int H, int W, int automask,
+                                                          int reduce_op) {
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= HW) return;
+  if (gdev) grad_scale *= gdev[0];
+  const int ncand = J * (automask ? 2 : 1);
+  const int r = rec[(size_t)b * HW + pix];
+  for (int j = 0; j < J; ++j) {
+    const int c = automask ? 2 * j : j;
+    for (int ch = 0; ch < 3; ++ch) {
+      const size_t o = (((size_t)j * B + b) * 3 + ch) * HW + pix;
+      const float diff = warped[o] - target[((size_t)b * 3 + ch) * HW + pix];
+      const int idx = c * 3 + ch;
+      float g;
+      if (reduce_op == 0) g = ((r & 127) == idx && !(r >> 7)) ? grad_scale : 0.f;
+      else g = ((r >> idx) & 1) ? 0.f : grad_scale / (float)(3 * ncand);
+      d_warped[o] = g * sgnf(diff);
+    }
+  }
+}
+
 // ---- smoothness of the MEAN-NORMALISED inverse depth, normalisation fused (round 4).  The reference normalises on the host side of
 // the kernel boundary: inv / inv.mean(2, True).mean(3, True).clamp(min=1e-6) (multiview_photometric_loss.py:269-271) -- four ATen
 // launches forward and ~eight backward per scale around two tiny kernels.  Here:
@@ -853,6 +950,42 @@ int pnsfm_photometric_backward_dev(const float* warped, const float* target, con
                                    float C2, int automask, int reduce_op, int clip, void* stream) {
   return photometric_backward_impl(warped, target, argmin, d_warped, grad_scale, J, B, H, W, ssim_weight, C1, C2, automask,
                                    reduce_op, clip ? 1 : 0, stream, upstream);
+}
+
+int pnsfm_photometric_l1_forward(const float* warped, const float* ref, const float* target, float* loss_mean, int* rec, int J, int B,
+                                 int H, int W, int automask, int reduce_op, float clip_loss, void* stream) {
+  if (J < 1 || J > 3 || H < 1 || W < 1 || B < 1) { set_error("photometric_l1_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
+  if (automask && reduce_op != 0) { set_error("photometric_l1_forward: automask requires the 'min' reduce op"); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const int ncand = J * (automask ? 2 : 1);
+  dim3 grid(ceil_div(H * W, 256), B);
+  const int nblk = (int)(grid.x * grid.y);
+  // scratch: [nblk] loss partials | [nblk][ncand][2] statistics | thresholds
+  const size_t nd = (size_t)nblk + (size_t)nblk * ncand * 2 + 8;
+  ScratchLease lease(s, nd * sizeof(double));
+  double* part = lease.as<double>();
+  if (!part) return -1;
+  double* stats = part + nblk;
+  float* thr = reinterpret_cast<float*>(stats + (size_t)nblk * ncand * 2);
+  const bool clip = clip_loss > 0.f;
+  if (clip) {
+    PNSFM_LAUNCH(l1cand_fwd_kernel, grid, dim3(256), 0, s, warped, ref, target, (const float*)nullptr, part, (int*)nullptr, stats, J, B, H, W,
+                 automask, reduce_op);
+    PNSFM_LAUNCH(l1cand_thr_kernel, dim3(1), dim3(256), 0, s, (const double*)stats, nblk, ncand, (double)B * 3.0 * H * W, clip_loss, thr);
+  }
+  PNSFM_LAUNCH(l1cand_fwd_kernel, grid, dim3(256), 0, s, warped, ref, target, clip ? (const float*)thr : (const float*)nullptr, part, rec,
+               (double*)nullptr, J, B, H, W, automask, reduce_op);
+  PNSFM_LAUNCH(sum_partials_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, 1.0 / ((double)B * H * W), 0.0,
+               (double*)nullptr, loss_mean);
+  return check_launch("photometric_l1_forward");
+}
+
+int pnsfm_photometric_l1_backward(const float* warped, const float* target, const int* rec, float* d_warped, float grad_scale,
+                                  const float* upstream, int J, int B, int H, int W, int automask, int reduce_op, void* stream) {
+  if (J < 1 || J > 3 || H < 1 || W < 1 || B < 1) { set_error("photometric_l1_backward: bad shape"); return -1; }
+  PNSFM_LAUNCH(l1cand_bwd_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, warped, target, rec, d_warped, grad_scale,
+               upstream, J, B, H, W, automask, reduce_op);
+  return check_launch("photometric_l1_backward");
 }
 
 int pnsfm_smoothness_norm_forward(const float* inv_depth, const float* image, float* loss, float* mean, int B, int H, int W,

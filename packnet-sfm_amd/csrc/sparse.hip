@@ -102,15 +102,18 @@ __global__ void __launch_bounds__(256) sp_write_kernel(const float* __restrict__
 }
 
 // stride-2 coordinate rule: coarse cell (Y, X) is active iff one of the fine cells (2Y..2Y+1, 2X..2X+1) is
+// (odd h / w: the coarse grid has ceil(h / 2) x ceil(w / 2) cells -- MinkowskiEngine's floor(c / 2) coordinates of the last odd row /
+// column; the children outside the fine grid do not exist)
 __global__ void __launch_bounds__(256) sp_pool_cells_kernel(const int* __restrict__ imap, int B, int h, int w, float* __restrict__ mask_out) {
-  const int h2 = h / 2, w2 = w / 2;
+  const int h2 = (h + 1) / 2, w2 = (w + 1) / 2;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * h2 * w2) return;
   const int b = i / (h2 * w2), rem = i - b * h2 * w2;
   const int Y = rem / w2, X = rem - Y * w2;
   const int* m = imap + (size_t)b * h * w;
-  const bool any = m[(2 * Y) * w + 2 * X] >= 0 || m[(2 * Y) * w + 2 * X + 1] >= 0 || m[(2 * Y + 1) * w + 2 * X] >= 0 ||
-                   m[(2 * Y + 1) * w + 2 * X + 1] >= 0;
+  const bool y1 = 2 * Y + 1 < h, x1 = 2 * X + 1 < w;
+  const bool any = m[(2 * Y) * w + 2 * X] >= 0 || (x1 && m[(2 * Y) * w + 2 * X + 1] >= 0) || (y1 && m[(2 * Y + 1) * w + 2 * X] >= 0) ||
+                   (y1 && x1 && m[(2 * Y + 1) * w + 2 * X + 1] >= 0);
   mask_out[i] = any ? 1.f : 0.f;
 }
 
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(256) sp_maxpool_fwd_kernel(const float* __rest
   float best = 0.f;
   int barg = -1;
   if (m < count_out[0]) {
-    const int h2 = h / 2, w2 = w / 2;
+    const int h2 = (h + 1) / 2, w2 = (w + 1) / 2;
     const int cell = sites_out[m];
     const int b = cell / (h2 * w2), rem = cell - b * h2 * w2;
     const int Y = rem / w2, X = rem - Y * w2;
@@ -394,8 +397,8 @@ int pnsfm_sparse_compact(const float* src, int ncell, int* imap, int* sites, int
 }
 
 int pnsfm_sparse_pool_cells(const int* imap, int B, int h, int w, float* mask_out, void* stream) {
-  if (h % 2 || w % 2 || B <= 0) { set_error("sparse_pool_cells: the grid must be even (h=%d w=%d)", h, w); return -1; }
-  const int n = B * (h / 2) * (w / 2);
+  if (h < 1 || w < 1 || B <= 0) { set_error("sparse_pool_cells: bad grid (h=%d w=%d)", h, w); return -1; }
+  const int n = B * ((h + 1) / 2) * ((w + 1) / 2);
   PNSFM_LAUNCH(sp_pool_cells_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, imap, B, h, w, mask_out);
   return check_launch("sparse_pool_cells");
 }

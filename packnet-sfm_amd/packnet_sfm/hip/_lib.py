@@ -70,6 +70,8 @@ SIGNATURES = {
     "pnsfm_smoothness_norm_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_smoothness_norm_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_region_ops": (_i, [_p, _i, _p]),
+    "pnsfm_photometric_l1_forward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "pnsfm_photometric_l1_backward": (_i, [_p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_smoothness_forward": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_smoothness_backward": (_i, [_p, _p, _p, _f, _f, _i, _i, _i, _p]),
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),

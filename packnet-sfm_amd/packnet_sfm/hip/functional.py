@@ -1045,7 +1045,31 @@ class PhotometricFn(Function):
         return d, None, None, None, None, None, None, None, None
 
 
+class PhotometricL1Fn(Function):
+    """L1-only photometric loss (ssim_loss_weight == 0) with the 'min' reduce op and / or clipping: the reference reduces and clips
+    per-CHANNEL candidate maps then (multiview_photometric_loss.py:205-219, 238-246); csrc/loss.hip: l1cand_*_kernel."""
+
+    @staticmethod
+    def forward(ctx, warped, ref, target, automask, reduce_op, clip_loss):
+        warped, ref, target = warped.contiguous(), ref.contiguous(), target.contiguous()
+        J, B, _, H, W = warped.shape
+        loss, rec = ops.photometric_l1_forward(warped, ref, target, automask, reduce_op, clip_loss)
+        ctx.save_for_backward(warped, target, rec)
+        ctx.meta = (automask, reduce_op, B * H * W)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        warped, target, rec = ctx.saved_tensors
+        automask, reduce_op, n = ctx.meta
+        up = g.reshape(1).to(torch.float32).contiguous()
+        return ops.photometric_l1_backward(warped, target, rec, 1.0 / n, up, automask, reduce_op), None, None, None, None, None
+
+
 def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):
+    if ssim_w == 0.0 and (reduce_op == REDUCE_MIN or clip_loss > 0.0):
+        return PhotometricL1Fn.apply(warped, ref, target, automask, reduce_op, clip_loss)
     return PhotometricFn.apply(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
 
 

@@ -446,6 +446,30 @@ def photometric_backward_dev(warped, target, argmin, grad_scale, upstream, ssim_
     return d_warped
 
 
+def photometric_l1_forward(warped, ref, target, automask, reduce_op, clip_loss):
+    """L1-only photometric loss on per-channel candidate maps -> (loss float32[1], rec int32[B,H,W])."""
+    _chk(warped, ref, target); _f32(warped, ref, target)
+    J, B, _, H, W = warped.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=warped.device)
+    rec = torch.empty((B, H, W), dtype=torch.int32, device=warped.device)
+    _lib.check(_lib.get().pnsfm_photometric_l1_forward(_ptr(warped), _ptr(ref), _ptr(target), _ptr(loss), _ptr(rec), J, B, H, W,
+                                                       int(automask), int(reduce_op), float(clip_loss), _stream(warped)),
+               "photometric_l1_forward")
+    return loss, rec
+
+
+def photometric_l1_backward(warped, target, rec, grad_scale, upstream, automask, reduce_op):
+    _chk(warped, target, rec); _f32(warped, target)
+    if upstream is not None:
+        _chk(upstream); _f32(upstream)
+    J, B, _, H, W = warped.shape
+    d_warped = torch.empty_like(warped)
+    _lib.check(_lib.get().pnsfm_photometric_l1_backward(_ptr(warped), _ptr(target), _ptr(rec), _ptr(d_warped), float(grad_scale),
+                                                        _ptr(upstream), J, B, H, W, int(automask), int(reduce_op), _stream(warped)),
+               "photometric_l1_backward")
+    return d_warped
+
+
 def smoothness_norm_forward(inv_depth, image):
     """-> (loss float32[1], mean float32[B]): smoothness of inv_depth / clamp(mean_hw(inv_depth), 1e-6)."""
     _chk(inv_depth, image); _f32(inv_depth, image)
@@ -587,7 +611,7 @@ def sparse_compact(src, cap=None):
 
 def sparse_pool_cells(imap, B, h, w):
     _chk(imap); _i32(imap)
-    mask = torch.empty((B * (h // 2) * (w // 2),), dtype=torch.float32, device=imap.device)
+    mask = torch.empty((B * ((h + 1) // 2) * ((w + 1) // 2),), dtype=torch.float32, device=imap.device)     # odd grids: ceil
     _lib.check(_lib.get().pnsfm_sparse_pool_cells(_ptr(imap), B, h, w, _ptr(mask), _stream(imap)), "sparse_pool_cells")
     return mask
 

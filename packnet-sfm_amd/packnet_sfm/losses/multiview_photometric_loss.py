@@ -54,11 +54,8 @@ class MultiViewPhotometricLoss(LossBase):
             raise ValueError('Unknown padding_mode {}'.format(padding_mode))
         if ssim_loss_weight < 0.0:
             raise ValueError('ssim_loss_weight must be >= 0')
-        if ssim_loss_weight == 0.0 and (photometric_reduce_op == 'min' or clip_loss > 0.0):
-            # L1-only: the reference then reduces / clips per-CHANNEL maps (:205-219, :238-246), which only coincides
-            # with the kernel's channel mean under the plain 'mean' reduce
-            raise NotImplementedError("ssim_loss_weight == 0 is supported with photometric_reduce_op='mean' and "
-                                      "clip_loss == 0 only")
+        # (ssim_loss_weight == 0 with 'min' / clipping: the reference works on per-channel maps then (:205-219, :238-246) -- HF.photometric
+        # routes those configurations to the L1 candidate kernels)
 
     @property
     def logs(self):

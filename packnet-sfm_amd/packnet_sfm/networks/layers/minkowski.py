@@ -86,7 +86,7 @@ def sparsify_features(x):
 def pool_coordinates(x):
     """Coordinates of ME.MinkowskiMaxPooling(3, 2) on `x`: the cells floor(c / 2) of the twice coarser grid (no features yet)."""
     mask = ops.sparse_pool_cells(x.imap, x.B, x.h, x.w)
-    h2, w2 = x.h // 2, x.w // 2
+    h2, w2 = (x.h + 1) // 2, (x.w + 1) // 2                      # odd grids: ceil, as floor(c / 2) of the last row / column needs
     cap = min(x.cap, _round_cap(x.B * h2 * w2))                # a coarse cell has at least one fine site: never more rows than before
     imap, sites, count = ops.sparse_compact(mask, cap=cap)
     return SparseGrid(x.B, h2, w2, x.tensor_stride * 2, sites, imap, count, None)
@@ -96,7 +96,7 @@ def densify_features(x, shape):
     """SparseGrid -> dense [B,C,H/stride,W/stride], zeros where nothing is stored (reference :60-83)."""
     B, _, H, W = shape
     s = x.tensor_stride
-    assert (x.h, x.w) == (H // s, W // s), ((x.h, x.w), shape, s)
+    assert (x.h, x.w) == (-(-H // s), -(-W // s)), ((x.h, x.w), shape, s)
     return HF.sparse_densify(x.F, x.imap, x.sites, x.count, x.B, x.h, x.w)
 
 

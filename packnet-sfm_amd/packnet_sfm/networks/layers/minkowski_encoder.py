@@ -2,7 +2,8 @@
 
 Drop-in for the reference's packnet_sfm/networks/layers/minkowski_encoder.py (`MinkConv2D`, `MinkowskiEncoder`: same
 constructor arguments, same `prep(depth)` / `forward(x)` protocol, same parameter names -- `layer3.0.kernel`
-[k*k, in, out] like ME.MinkowskiConvolution, `layer3.1.bn.*` like ME.MinkowskiBatchNorm -- so checkpoints map one to one).
+[k*k, in, out] like ME.MinkowskiConvolution, `layer3.1.bn.*` like ME.MinkowskiBatchNorm -- so checkpoint KEYS and shapes map one to
+one; whether the VALUES mean the same depends on the tap order below, which is unpinned: loading warns).
 
 The reference runs this branch on MinkowskiEngine (third-party, NOT vendored in the reference and not installed here; the
 Dockerfile builds it from git master, i.e. un-versioned).  Its operations are restated from the MinkowskiEngine 0.5
@@ -27,6 +28,21 @@ from packnet_sfm.networks.layers.minkowski import (SparseGrid, densify_features,
                                                     sparsify_depth)
 
 
+_WARNED = [False]
+
+
+def _warn_unpinned_checkpoint(prefix):
+    """a reference PackNet-SAN checkpoint loads into these modules without error, but the tap order of `kernel[i]` and
+    the pooling window rule were never checked against MinkowskiEngine itself (it cannot be run here) -- say so, loudly, once."""
+    if not _WARNED[0]:
+        _WARNED[0] = True
+        import warnings
+        warnings.warn('packnet_sfm (MI355X): loading MinkowskiEngine-layout weights into %s*: the kernel tap order (i = (dy + k//2) + k * '
+                      '(dx + k//2)) and the MaxPooling(3, 2) window rule are restated from the MinkowskiEngine documentation and pinned '
+                      'by hand-computed vectors only -- parity against MinkowskiEngine itself is UNPINNED.  Validate the sparse branch '
+                      'of a checkpoint trained with the reference before relying on it.' % prefix, RuntimeWarning, stacklevel=3)
+
+
 class MinkowskiConvolution(nn.Module):
     """`kernel` [k*k, in, out] (MinkowskiEngine's layout), no bias; the sparse convolution kernel of csrc/sparse.hip."""
 
@@ -38,6 +54,11 @@ class MinkowskiConvolution(nn.Module):
         self.kernel = nn.Parameter(torch.empty(kernel_size * kernel_size, in_channels, out_channels))
         with torch.no_grad():               # ME default: ME.utils.kaiming_normal_(kernel, mode='fan_out', nonlinearity='relu')
             self.kernel.normal_(0, (2.0 / (out_channels * kernel_size * kernel_size)) ** 0.5)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if prefix + 'kernel' in state_dict:
+            _warn_unpinned_checkpoint(prefix)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x):
         return x.with_features(HF.sparse_conv(x.F, self.kernel, x.neighbors(self.kernel_size), x.count, self.kernel_size))

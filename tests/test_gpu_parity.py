@@ -94,7 +94,8 @@ def test_unpack_golden():
 
 
 @pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
-                                  'loss_reflection', 'loss_l1_only'])
+                                  'loss_reflection', 'loss_l1_only', 'loss_l1_min', 'loss_l1_clip_min', 'loss_l1_clip_mean',
+                                  'loss_l1_min_noauto'])
 def test_loss_golden(name):
     P.case_loss(name, DEV)
 

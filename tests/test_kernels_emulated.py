@@ -96,7 +96,8 @@ def test_compose_pack_weight(emulated_kernels):
 
 
 @pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_clip_min', 'loss_clip_mean', 'loss_border',
-                                  'loss_reflection', 'loss_l1_only'])
+                                  'loss_reflection', 'loss_l1_only', 'loss_l1_min', 'loss_l1_clip_min', 'loss_l1_clip_mean',
+                                  'loss_l1_min_noauto'])
 def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 

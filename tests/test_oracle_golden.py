@@ -63,7 +63,7 @@ def test_oracle_supervised_loss():
 
 def test_oracle_loss_and_grads():
     for name, fx in (list(P.golden('loss').items()) + list(P.golden('slim')['loss_clip'].items()) +
-                     list(P.golden('slim')['loss_padding'].items())):
+                     list(P.golden('slim')['loss_padding'].items()) + list(P.golden('loss_l1').items())):
         inv = [t.clone().requires_grad_(True) for t in fx['inv_depths']]
         pv = fx['pose_vec'].clone().requires_grad_(True)
         mats = [O.pose_vec2mat44(pv[:, i]) for i in range(2)]

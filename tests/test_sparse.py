@@ -144,7 +144,8 @@ def _check_conv_and_pool(device, B, H, W, density, Cin, Cout, ks, seed):
     pc, pf, ts = MO.maxpool3s2(coords, f0.clone().requires_grad_(True), 1)
     m = len(pc)
     assert int(p.count) == m and ts == 2
-    assert torch.equal(p.sites[:m].cpu().long(), pc[:, 0] * (H // 2) * (W // 2) + (pc[:, 1] // 2) * (W // 2) + pc[:, 2] // 2)
+    hc, wc = (H + 1) // 2, (W + 1) // 2                          # odd grids: the last odd row / column is a coarse cell of its own
+    assert torch.equal(p.sites[:m].cpu().long(), pc[:, 0] * hc * wc + (pc[:, 1] // 2) * wc + pc[:, 2] // 2)
     P.check(_rows_of(p, p.F), pf, 0.0, 'max pooling values')
     fr2 = f0.clone().requires_grad_(True)
     _, pf2, _ = MO.maxpool3s2(coords, fr2, 1)
@@ -165,6 +166,7 @@ CASES = [  # B, H, W, density, Cin, Cout, k, seed
     (2, 8, 8, 1.0, 8, 96, 3, 2),         # fully occupied grid: must equal a dense zero-padded convolution
     (1, 12, 16, 0.05, 16, 16, 3, 3),     # LiDAR-like occupancy: most offsets have no neighbour (skipped)
     (1, 4, 6, 0.0, 4, 4, 3, 4),          # no return at all
+    (2, 5, 7, 0.6, 8, 16, 3, 8),         # odd grid: coarse size ceil(h / 2) x ceil(w / 2), children outside the grid do not exist
 ]
 
 

@@ -161,25 +161,34 @@ static int grid_for(size_t total) {
 struct RegionOp {
   const float* src;      // null for zero
   float* dst;
-  int n[4];
+  unsigned n[4];         // extents (n[3] in float4 units when vec)
   long long ss[4], ds[4];
   int op;                // 0 copy, 1 add (dst += src), 2 zero
+  int vec;               // innermost dimension contiguous, 16-byte aligned and a multiple of 4 on both sides: float4 accesses
 };
 struct RegionOps { RegionOp o[PNSFM_MAX_REGION_OPS]; };
 
 __global__ void __launch_bounds__(256) region_ops_kernel(RegionOps ops) {
   const RegionOp& r = ops.o[blockIdx.y];
-  const long long total = (long long)r.n[0] * r.n[1] * r.n[2] * r.n[3];
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    long long t = e;
-    const int i3 = (int)(t % r.n[3]); t /= r.n[3];
-    const int i2 = (int)(t % r.n[2]); t /= r.n[2];
-    const int i1 = (int)(t % r.n[1]);
-    const int i0 = (int)(t / r.n[1]);
-    float* d = r.dst + i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
-    if (r.op == 2) { *d = 0.f; continue; }
-    const float v = r.src[i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3]];
-    *d = r.op == 1 ? *d + v : v;
+  const unsigned total = r.n[0] * r.n[1] * r.n[2] * r.n[3];        // (the entry point refuses windows of >= 2^31 elements)
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    unsigned t = e;
+    const unsigned i3 = t % r.n[3]; t /= r.n[3];
+    const unsigned i2 = t % r.n[2]; t /= r.n[2];
+    const unsigned i1 = t % r.n[1];
+    const unsigned i0 = t / r.n[1];
+    if (r.vec) {
+      float4* d = reinterpret_cast<float4*>(r.dst + i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2]) + i3;
+      if (r.op == 2) { *d = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+      const float4 v = reinterpret_cast<const float4*>(r.src + i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2])[i3];
+      if (r.op == 1) { float4 o = *d; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; *d = o; }
+      else *d = v;
+    } else {
+      float* d = r.dst + i0 * r.ds[0] + i1 * r.ds[1] + i2 * r.ds[2] + i3 * r.ds[3];
+      if (r.op == 2) { *d = 0.f; continue; }
+      const float v = r.src[i0 * r.ss[0] + i1 * r.ss[1] + i2 * r.ss[2] + i3 * r.ss[3]];
+      *d = r.op == 1 ? *d + v : v;
+    }
   }
 }
 
@@ -244,11 +253,21 @@ int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream) {
     r.src = in[i].src; r.dst = in[i].dst; r.op = in[i].op;
     long long total = 1;
     for (int k = 0; k < 4; ++k) {
-      r.n[k] = in[i].n[k]; r.ss[k] = in[i].src_stride[k]; r.ds[k] = in[i].dst_stride[k];
-      if (r.n[k] < 1) { set_error("region_ops: empty extent in operation %d", i); return -1; }
-      total *= r.n[k];
+      if (in[i].n[k] < 1) { set_error("region_ops: empty extent in operation %d", i); return -1; }
+      r.n[k] = (unsigned)in[i].n[k]; r.ss[k] = in[i].src_stride[k]; r.ds[k] = in[i].dst_stride[k];
+      total *= in[i].n[k];
     }
+    if (total >= (1LL << 31)) { set_error("region_ops: window of operation %d has >= 2^31 elements", i); return -1; }
     if (r.op < 0 || r.op > 2 || !r.dst || (r.op != 2 && !r.src)) { set_error("region_ops: bad operation %d", i); return -1; }
+    // float4 path: unit innermost strides, extent and every outer stride a multiple of 4, 16-byte aligned bases
+    bool vec = (r.n[3] % 4 == 0) && r.ds[3] == 1 && (((uintptr_t)r.dst) & 15) == 0;
+    for (int k = 0; k < 3 && vec; ++k) vec = r.ds[k] % 4 == 0;
+    if (r.op != 2) {
+      vec = vec && r.ss[3] == 1 && (((uintptr_t)r.src) & 15) == 0;
+      for (int k = 0; k < 3 && vec; ++k) vec = r.ss[k] % 4 == 0;
+    }
+    r.vec = vec ? 1 : 0;
+    if (vec) { r.n[3] /= 4; total /= 4; }
     if (total > most) most = total;
   }
   long long gx = (most + 255) / 256;

@@ -566,10 +566,15 @@ def main():
         }
         if ddp:
             red = optimizer._reducer
+            sizes = [b.flat.numel() * b.flat.element_size() for b in red.buckets]
             result['config']['allreduce'] = {
                 'buckets': len(red.buckets), 'bytes_per_step': red.total_bytes,
-                'largest_bucket_bytes': max(b.flat.numel() * b.flat.element_size() for b in red.buckets),
+                'largest_bucket_bytes': max(sizes), 'bucket_bytes': sizes,
+                # a bucket larger than chunk_bytes (one huge parameter: pack5's 302 MB weight) is reduced in slices of <= chunk_bytes
+                'chunk_bytes': red.chunk_bytes,
+                'collectives_per_step': sum(max(1, -(-sz // red.chunk_bytes)) for sz in sizes),
                 'in_place_on_optimizer_arena': args.optimizer == 'flat',
+                'overlap_with_backward': bool(red.overlap),
                 # time the compute stream spent waiting for the communication stream at the end-of-backward join
                 'exposed_ms_per_step': m['exposed_allreduce_ms_per_step']}
         if world > ndev:

@@ -77,8 +77,11 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   // tiles that read the same input patch are neighbours -- and a contiguous range of that order per XCD (pnsfm_common.h)
   unsigned bx, by, bz;
   {
-    const unsigned Lb = a.bmap == 2 ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
-    if (a.bmap == 0) { bx = Lb % (unsigned)a.gx; const unsigned q = Lb / (unsigned)a.gx; by = q % (unsigned)a.gy; bz = q / (unsigned)a.gy; }
+    // (bmap 3, round 4: weight-heavy layers -- 512 -> 512 @ 12x40: 14 MB of split weights against 4 MB of input -- put the PIXEL tile
+    // fastest inside an XCD's range instead, so that the weights of an (output-channel tile, K split) stay in that XCD's 4 MB L2 for all
+    // the pixel tiles; with the output-channel tile fastest every pixel tile re-fetched the whole weight stream from memory)
+    const unsigned Lb = a.bmap >= 2 ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (a.bmap == 0 || a.bmap == 3) { bx = Lb % (unsigned)a.gx; const unsigned q = Lb / (unsigned)a.gx; by = q % (unsigned)a.gy; bz = q / (unsigned)a.gy; }
     else { by = Lb % (unsigned)a.gy; const unsigned q = Lb / (unsigned)a.gy; bx = q % (unsigned)a.gx; bz = q / (unsigned)a.gx; }
   }
   const int b = (int)bx / a.tiles_per_img;

@@ -1,7 +1,7 @@
 """FlatAdam: torch.optim.Adam semantics on flat fp32 arenas -- parameters, gradients, exp_avg, exp_avg_sq of a parameter
 group are each ONE buffer, updated by ONE launch of the gfx950 `adam_flat_kernel` (csrc/elementwise.hip: float4 accesses,
-28 B/parameter of HBM traffic, step counter and hyper-parameters read from device memory so the launch replays inside a
-hipGraph) instead of ~250 per-tensor updates.
+28 B/parameter of HBM traffic, step counter and hyper-parameters read from device memory: nothing the launch needs is a host
+value that changes from step to step) instead of ~250 per-tensor updates.
 
 SURVEY.md 8(f) N1: the optimizer CONSUMES THE ALL-REDUCE BUCKETS IN PLACE.  The gradient arena is laid out in reverse
 registration order (the order backward produces gradients) and `grad_buckets()` cuts it into the contiguous <=32 MiB
@@ -105,8 +105,7 @@ class FlatAdam:
             g['_hp'][1:9].copy_(torch.tensor(host, dtype=torch.float32), non_blocking=True)
 
     def sync_hyperparams(self):
-        """Push lr / betas / eps / weight decay / grad_scale to the device if they changed (call OUTSIDE a hipGraph replay
-        after an LR-scheduler step; eager `step()` does it itself)."""
+        """Push lr / betas / eps / weight decay / grad_scale to the device if they changed (`step()` does it itself)."""
         for g in self.param_groups:
             self._sync_group(g)
 
@@ -141,17 +140,14 @@ class FlatAdam:
         A parameter whose .grad is None is SKIPPED like torch.optim.Adam does (parameter, exp_avg and exp_avg_sq keep their
         values: they are saved around the flat launch and restored -- three small multi-tensor copies, only on steps that
         have such parameters; e.g. PackNetSAN01's sparse-depth branch on batches without input_depth).  One deviation
-        remains and is deliberate: the step counter is per GROUP (a device-resident scalar, which is what makes the launch
-        hipGraph-replayable), so a parameter that skipped k steps uses the group's step in its bias corrections where torch
+        remains and is deliberate: the step counter is per GROUP (one device-resident scalar per flat launch), so a parameter that skipped k steps uses the group's step in its bias corrections where torch
         would use its own, k smaller; `state_dict()` reports the group's step for every parameter.  Under
         hvd.DistributedOptimizer unused parameters arrive with ZERO gradients (the reducer fills their bucket slice, as
         horovod's synchronize() does for the reference) and are therefore updated, exactly like the reference's DDP path."""
         loss = closure() if closure is not None else None
-        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         for g in self.param_groups:
             missing = self._gather_grads(g)
-            if not capturing:
-                self._sync_group(g)
+            self._sync_group(g)
             keep = None
             if missing:
                 views = [g[k][g['_offs'][id(p)]:g['_offs'][id(p)] + p.numel()] for p in missing for k in ('_flat', '_m', '_v')]

@@ -100,3 +100,9 @@ def test_conv2d_split_k_two_stage_vs_fp64(shape, split):
         assert torch.equal(dx, ops.conv2d_backward_data(dy, wb, Cin, ks))
     finally:
         lib.pnsfm_set_conv_variant(3)      # clears the pinned entries
+
+
+def test_region_ops_batched_windows_gpu():
+    """pnsfm_region_ops on the device (the collapsed packing block's strip plumbing, one launch per autograd Function)."""
+    P.case_region_ops(DEV)
+

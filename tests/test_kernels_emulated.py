@@ -102,6 +102,10 @@ def test_loss(emulated_kernels, name):
     P.case_loss(name, 'cpu')
 
 
+def test_region_ops_batched_windows(emulated_kernels):
+    P.case_region_ops('cpu')
+
+
 @pytest.mark.parametrize('scale', [1.0, 1e-7])
 def test_smoothness_norm_fused(emulated_kernels, scale):
     """hip.functional.smoothness_norm (mean normalisation of the inverse depth fused into the smoothness kernels, round 4) against

@@ -912,8 +912,10 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
   if (a.bmap == 2 && g.DMA >= 3) {
     // weight-heavy launch (the packed split weights outweigh the input tensor): pixel tile fastest inside an XCD's range (conv2d_bx3.h)
-    static const int wmap = [] { const char* e = getenv("PNSFM_BLOCK_MAP_WEIGHTS"); return (e && e[0] == '0') ? 0 : 1; }();
-    const double wbytes = 6.0 * Cout * (double)Cin * ks * ks, xbytes = 4.0 * B * (double)Cin * Hi * Wi;
+    // PNSFM_BLOCK_MAP_WEIGHTS = 0 (off) | r: pixel tile fastest when weights > r x input (default 1)
+    static const double wratio = [] { const char* e = getenv("PNSFM_BLOCK_MAP_WEIGHTS"); return e && e[0] ? atof(e) : 1.0; }();
+    const bool wmap = wratio > 0.0;
+    const double wbytes = 6.0 * Cout * (double)Cin * ks * ks, xbytes = 4.0 * B * (double)Cin * Hi * Wi * wratio;
     if (wmap && wbytes > xbytes && grid.x > 1) a.bmap = 3;
   }
   { static const int pl = [] { const char* e = getenv("PNSFM_PATCH_LAYOUT"); return (e && e[0] == '0') ? 0 : 1; }(); a.playout = pl; }

@@ -4,6 +4,8 @@ These Functions are what the drop-in modules (networks/layers/packnet/layers01.p
 losses/multiview_photometric_loss.py) are made of.  Autograd only sequences the launches; every derivative
 is computed by a HIP kernel of libpnsfm_hip.so.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -343,10 +345,41 @@ def _slots_for(weight, bias, usable):
 
 
 def join_wgrad_stream(device):
-    """Make the current stream of `device` wait for every weight gradient launched so far (no-op when unused).
-    The gradient all-reduce calls this before it gathers a bucket in the middle of the backward pass."""
-    if device.type == 'cuda' and device in _WgradStream._streams:
-        torch.cuda.current_stream(device).wait_stream(_WgradStream._streams[device])
+    """Make the current stream of `device` wait for every weight gradient launched so far (no-op when unused) and for the
+    independent-branch stream (branch_stream) -- the gradient all-reduce calls this before it gathers a bucket in the middle
+    of the backward pass, and a bucket may hold parameters of both networks."""
+    if device.type != 'cuda':
+        return
+    cur = torch.cuda.current_stream(device)
+    for st in (_WgradStream._streams.get(device), _BRANCH_STREAMS.get(device)):
+        if st is not None and st != cur:
+            cur.wait_stream(st)
+
+
+# Independent-branch stream: the pose network shares nothing with the depth network until the loss, and its kernels are tiny
+# (a few workgroups each, latency-bound), so models/SfmModel.py enqueues it on a second HIP stream where it fills the launch gaps
+# and tail rounds of the depth network's kernels.  Autograd replays every node on the stream its forward ran on and orders the
+# two streams with events, so the pose network's backward pass overlaps the depth decoder's backward pass the same way.
+# OFF by default (PNSFM_BRANCH_STREAM=1 / set_branch_stream switch it on): measured +0.85 % images/s, but kernels that share the
+# GPU stretch each other, and the bench line's per-kernel roofline is measured as-run (profiles/r04_ab_branch_stream.txt) -- the
+# same trade as PNSFM_WGRAD_STREAM.
+_BRANCH_STREAMS = {}
+_BRANCH_ON = os.environ.get('PNSFM_BRANCH_STREAM', '0') == '1'
+
+
+def set_branch_stream(on):
+    global _BRANCH_ON
+    _BRANCH_ON = bool(on)
+
+
+def branch_stream(t):
+    """The second compute stream of t's device, or None (CPU tensors, switched off)."""
+    if not (_BRANCH_ON and torch.is_tensor(t) and t.is_cuda):
+        return None
+    st = _BRANCH_STREAMS.get(t.device)
+    if st is None:
+        st = _BRANCH_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
+    return st
 
 
 class Conv2dFn(Function):

@@ -3,10 +3,17 @@ packnet_sfm/models/SfmModel.py: `add_depth_net`, `add_pose_net`, `compute_depth_
 `depth_net_flipping`, output dict {'inv_depths', 'poses'})."""
 import random
 
+import torch
+
 from packnet_sfm.geometry.pose import Pose
 from packnet_sfm.models.base_model import BaseModel
 from packnet_sfm.models.model_utils import flip_batch_input, flip_output, upsample_output
 from packnet_sfm.utils.misc import filter_dict
+
+
+def _branch_stream(t):
+    from packnet_sfm.hip.functional import branch_stream
+    return branch_stream(t)
 
 
 class SfmModel(BaseModel):
@@ -64,9 +71,30 @@ class SfmModel(BaseModel):
         return [Pose.from_vec(v, self.rotation_mode) for v in vectors.unbind(1)]
 
     def forward(self, batch, return_logs=False, force_flip=False):
-        output = dict(self.compute_depth_net(batch, force_flip=force_flip))
         has_contexts = 'rgb_context' in batch and self.pose_net is not None
-        output['poses'] = self.compute_pose_net(batch['rgb'], batch['rgb_context']) if has_contexts else None
+        side = _branch_stream(batch['rgb']) if has_contexts else None
+        if side is not None:
+            main = torch.cuda.current_stream(batch['rgb'].device)
+            inputs_ready = main.record_event()           # the pose network only needs the batch, not the depth network
+        output = dict(self.compute_depth_net(batch, force_flip=force_flip))
+        if not has_contexts:
+            output['poses'] = None
+        elif side is None:
+            output['poses'] = self.compute_pose_net(batch['rgb'], batch['rgb_context'])
+        else:
+            # The pose network on the second compute stream (hip/functional.py: branch_stream).  It is enqueued AFTER the depth
+            # network on purpose: autograd runs the nodes created last first, so its backward pass starts together with the
+            # depth decoder's, and in the forward pass the host runs far enough ahead of the device for it to overlap the
+            # depth network's tail.  Same kernels, same order within each stream: results are bit-identical either way.
+            side.wait_event(inputs_ready)
+            with torch.cuda.stream(side):
+                poses = self.compute_pose_net(batch['rgb'], batch['rgb_context'])
+            for t in [batch['rgb']] + list(batch['rgb_context']):
+                t.record_stream(side)                    # allocated on the compute stream, read on the side stream
+            main.wait_stream(side)
+            for pose in poses:
+                pose.mat.record_stream(main)             # and the other way round
+            output['poses'] = poses
         return output
 
 

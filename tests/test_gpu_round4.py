@@ -106,3 +106,26 @@ def test_region_ops_batched_windows_gpu():
     """pnsfm_region_ops on the device (the collapsed packing block's strip plumbing, one launch per autograd Function)."""
     P.case_region_ops(DEV)
 
+
+def test_branch_stream_is_bit_identical():
+    """The pose network on the second compute stream (models/SfmModel.py, hip/functional.py: branch_stream) against everything on
+    one stream: the same kernels in the same per-stream order, so loss and every gradient must agree bit for bit -- anything else
+    is a missing stream dependency."""
+    from packnet_sfm.hip import functional as HF
+    from test_gpu_parity import _selfsup, _step_batch
+    fx = dict(P.golden('step')['step_flip0'])
+    model, dn, pn = _selfsup(DEV, fx)
+    batch = _step_batch(fx)
+    _grads_of_one_step(model, batch, False)             # autotuning
+    try:
+        HF.set_branch_stream(False)
+        l0, g0 = _grads_of_one_step(model, batch, False)
+        HF.set_branch_stream(True)
+        assert HF.branch_stream(batch['rgb']) is not None
+        for rep in range(3):
+            l1, g1 = _grads_of_one_step(model, batch, False)
+            assert torch.equal(l0, l1), (l0.item(), l1.item())
+            bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+            assert not bad and g0.keys() == g1.keys(), bad[:3]
+    finally:
+        HF.set_branch_stream(False)

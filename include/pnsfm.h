@@ -202,7 +202,7 @@ int pnsfm_conv3d_1to8_backward_weight(const float* p, const float* dout, float* 
                                       int B, int D, int H, int W, void* stream);
 /* The same three with NF = 4 or 8 feature maps (`d=num_3d_feat` of PackLayerConv3d / UnpackLayerConv3d,
  * layers01.py:213-232,250-268: 8 in PackNet01, 4 in PackNetSlim01.py:39 and PackNetSAN01.py).  out / dout:[B,NF*D,H,W],
- * w3:[NF][27], b3:[NF]; ws stays double[8*28]. */
+ * w3:[NF][27], b3:[NF] (forward: NULL = no bias); ws stays double[8*28]. */
 int pnsfm_conv3d_forward(const float* p, const float* w3, const float* b3, float* out,
                          int B, int D, int H, int W, int NF, void* stream);
 int pnsfm_conv3d_backward_data(const float* dout, const float* w3, float* dp,
@@ -344,6 +344,34 @@ typedef struct {
   int op;
 } pnsfm_region_op;
 int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream);
+
+/* ---- nearest-neighbour up-sampling by an integer factor -------------------------------------
+ * replaces F.interpolate(mode='nearest') where the reference brings every predicted scale to full resolution
+ * (models/model_utils.py:163-180 -> utils/image.py:148-176) and nn.Upsample(scale_factor=2, mode='nearest')
+ * (networks/depth/PackNet01.py:87-89,150,159,168).  x: [N, h, w] planes -> y: [N, h*s, w*s], y[n,oy,ox] = x[n,oy/s,ox/s];
+ * backward: dx = s x s block sums of dy (rows, then columns, ascending).  w*s must be a multiple of 4. */
+int pnsfm_upsample_nearest_forward(const float* x, float* y, int N, int h, int w, int s, void* stream);
+int pnsfm_upsample_nearest_backward(const float* dy, float* dx, int N, int h, int w, int s, void* stream);
+
+/* ---- scalar tail of the multi-view photometric loss -----------------------------------------
+ * replaces the Python-level sums of losses/multiview_photometric_loss.py:248-252 (mean over scales of the reduced photometric
+ * terms), :275-280 (smoothness terms / 2^i, mean, weight) and :337-338 (their sum), in the reference's operation order.
+ * photometric / smoothness: HOST arrays of n / ns DEVICE scalar pointers.  out3 = {loss, weighted smoothness, photometric}.
+ * backward: g = device scalar d(loss); dout16[i] = d/dP[i] (i < n), dout16[8 + i] = d/dS[i] (i < ns). */
+int pnsfm_loss_combine_forward(const float* const* photometric, int n, const float* const* smoothness, int ns, float weight,
+                               float* out3, void* stream);
+int pnsfm_loss_combine_backward(const float* g, int n, int ns, float weight, float* dout16, void* stream);
+
+/* ---- bias of the composed packing convolution -------------------------------------------------
+ * PackLayerConv3d (networks/layers/packnet/layers01.py:243-246) runs Conv3d(1->d) then Conv2d with nothing in between; where this
+ * package composes the two the bias of the composed convolution is
+ *   bias_eff[co] = b2[co] + sum_f b3[f] * Ssum[co][f],   Ssum[co][f] = sum of block f (blk = D*k*k floats) of row co of W2.
+ * forward writes Ssum [C,d] and bias_eff [C].  backward: db3[f] = sum_co g[co]*Ssum[co][f] (db3 may be NULL) and
+ * dW2[C, d*D, k, k] = dWeff_full[C, d*D, k+2, k+2] cropped by one tap on every side + g[co]*b3[f] (dW2 may be NULL). */
+int pnsfm_pack_bias_eff_forward(const float* W2, const float* b2, const float* b3, float* Ssum, float* bias_eff, int C, int d,
+                                int blk, void* stream);
+int pnsfm_pack_bias_eff_backward(const float* g, const float* Ssum, const float* b3, const float* dWeff_full, float* db3, float* dW2,
+                                 int C, int d, int D, int k, void* stream);
 
 /* ---- Adam over a flat fp32 parameter buffer (torch.optim.Adam semantics, no amsgrad) -------
  * replaces the optimizer.step() of models/model_wrapper.py:128-149 / trainers/horovod_trainer.py:93

@@ -866,8 +866,9 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
 }
 
 #ifdef PNSFM_BX3_ABLATE
-static int g_ablate = 0;
+static int g_ablate = 0, g_smem_pad = 0;
 extern "C" int pnsfm_debug_set_ablate(int f) { g_ablate = f; return 0; }
+extern "C" int pnsfm_debug_set_smem_pad(int bytes) { g_smem_pad = bytes; return 0; }   // extra LDS per workgroup: fewer workgroups per CU
 #endif
 #ifdef PNSFM_PIPE_TRACE
 static long long* g_trace_buf = nullptr;
@@ -1067,6 +1068,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
         g = t;
     }
   }
+#ifdef PNSFM_BX3_ABLATE
+  if (g.DMA >= 3 && g.smem_bytes + (size_t)g_smem_pad <= kMaxSmemPipe) g.smem_bytes += (size_t)g_smem_pad;
+#endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
   prof_begin(0, flops, stream, meta);

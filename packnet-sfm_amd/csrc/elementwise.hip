@@ -192,6 +192,131 @@ __global__ void __launch_bounds__(256) region_ops_kernel(RegionOps ops) {
   }
 }
 
+// ---- nearest-neighbour up-sampling by an integer factor s (the reference's F.interpolate(mode='nearest'): every predicted scale
+// brought to full resolution, models/model_utils.py:163-180 via utils/image.py:148-176, and the inverse depth handed to the next
+// iconv block, nn.Upsample in networks/depth/PackNet01.py:87-89,150,159,168): y[n, oy, ox] = x[n, oy / s, ox / s].  One thread per FOUR output columns
+// (the host only takes maps whose output width is a multiple of 4).
+__global__ void __launch_bounds__(256) upsample_nearest_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w,
+                                                                   int s, unsigned total4) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total4) return;
+  const unsigned W4 = (unsigned)(w * s) >> 2, Ho = (unsigned)(h * s);
+  const unsigned q = i % W4, t = i / W4;
+  const unsigned oy = t % Ho, n = t / Ho;
+  const float* row = x + ((size_t)n * h + oy / s) * w;
+  const unsigned ox = 4u * q;
+  float4 v;
+  v.x = row[ox / s]; v.y = row[(ox + 1) / s]; v.z = row[(ox + 2) / s]; v.w = row[(ox + 3) / s];
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+
+// its gradient: dx[n, iy, ix] = sum of the s x s block of dy, rows then columns in ascending order (one thread per input element)
+__global__ void __launch_bounds__(256) upsample_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w,
+                                                                   int s, unsigned total) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned ix = i % (unsigned)w, t = i / (unsigned)w;
+  const unsigned iy = t % (unsigned)h, n = t / (unsigned)h;
+  const size_t Wo = (size_t)w * s;
+  const float* p = dy + ((size_t)n * h * s + (size_t)iy * s) * Wo + (size_t)ix * s;
+  float acc = 0.f;
+  for (int a = 0; a < s; ++a, p += Wo) {
+    if (s == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      acc += v.x; acc += v.y;
+    } else if ((s & 3) == 0) {
+      for (int b = 0; b < s; b += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + b);
+        acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+      }
+    } else {
+      for (int b = 0; b < s; ++b) acc += p[b];
+    }
+  }
+  dx[i] = acc;
+}
+
+// ---- the scalar tail of MultiViewPhotometricLoss.forward (reference losses/multiview_photometric_loss.py: reduce_photometric_loss
+// :248-252, calc_smoothness_loss :275-280, the in-place sum :337-338): per-scale
+// photometric means P[i] and smoothness terms S[i] -> out[0] = loss = mean_i P[i] + weight * mean_i (S[i] / 2^i), out[1] = the
+// weighted smoothness term, out[2] = the photometric term, in the reference's operation order (one thread; 2n values).
+struct LossTerms {
+  const float* p[8];
+  const float* s[8];
+};
+
+__global__ void loss_combine_fwd_kernel(LossTerms t, int n, int ns, float weight, float* __restrict__ out) {
+  float photo = 0.f;
+  for (int i = 0; i < n; ++i) photo = photo + t.p[i][0];
+  photo = photo / (float)n;
+  float smooth = 0.f;
+  for (int i = 0; i < ns; ++i) smooth = smooth + t.s[i][0] / (float)(1 << i);
+  if (ns > 0) smooth = weight * (smooth / (float)ns);
+  out[0] = ns > 0 ? photo + smooth : photo;
+  out[1] = smooth;
+  out[2] = photo;
+}
+
+// d(loss)/dP[i] = g / n -> dout[i]; d(loss)/dS[i] = ((g * weight) / ns) / 2^i -> dout[8 + i]   (g: device scalar)
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, int n, int ns, float weight, float* __restrict__ dout) {
+  const int i = threadIdx.x;
+  if (i < n) dout[i] = g[0] / (float)n;
+  if (i < ns) dout[8 + i] = ((g[0] * weight) / (float)ns) / (float)(1 << i);
+}
+
+// ---- bias of the composed packing convolution (networks/layers/packnet/layers01.py of this package: _conv_collapsed; the reference
+// runs Conv3d then Conv2d, layers01.py:243-246): bias_eff[co] = b2[co] + sum_f b3[f] * Ssum[co][f], Ssum[co][f] = sum of the
+// f-th block (blk contiguous floats) of row co of the Conv2d weight.  One workgroup per co; Ssum is kept for the gradient.
+__global__ void __launch_bounds__(256) pack_bias_eff_kernel(const float* __restrict__ W2, const float* __restrict__ b2,
+                                                            const float* __restrict__ b3, float* __restrict__ Ssum,
+                                                            float* __restrict__ bias_eff, int d, int blk) {
+  __shared__ float part[4];
+  __shared__ float sums[8];
+  const int co = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int f = 0; f < d; ++f) {
+    const float* p = W2 + ((size_t)co * d + f) * blk;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < blk; e += 256) acc += p[e];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[f] = ((part[0] + part[1]) + part[2]) + part[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int f = 0; f < d; ++f) {
+      Ssum[(size_t)co * d + f] = sums[f];
+      acc += sums[f] * b3[f];
+    }
+    bias_eff[co] = (b2 ? b2[co] : 0.f) + acc;
+  }
+}
+
+// gradients of that bias: db3[f] = sum_co g[co] * Ssum[co][f] (one wave per f, ascending co per lane, fixed-order lane tree)
+__global__ void __launch_bounds__(64) pack_bias_eff_db3_kernel(const float* __restrict__ g, const float* __restrict__ Ssum,
+                                                               float* __restrict__ db3, int C, int d) {
+  const int f = blockIdx.x;
+  float acc = 0.f;
+  for (int co = threadIdx.x; co < C; co += 64) acc += g[co] * Ssum[(size_t)co * d + f];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (threadIdx.x == 0) db3[f] = acc;
+}
+
+// ... and the Conv2d weight's: dW2[co][f-block][ky][kx] = full[co][f-block][ky + 1][kx + 1] (the composition's gradient, computed on
+// the zero-ring-padded (k+2)^2 taps) + g[co] * b3[f] (the bias path).  rows = C * d * D tap planes of k x k.
+__global__ void __launch_bounds__(256) pack_dw2_finish_kernel(const float* __restrict__ full, const float* __restrict__ g,
+                                                              const float* __restrict__ b3, float* __restrict__ dW2, int d, int D,
+                                                              int k, unsigned total) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned kk = (unsigned)(k * k), plane = i / kk, tap = i - plane * kk;
+  const unsigned ky = tap / (unsigned)k, kx = tap - ky * (unsigned)k;
+  const unsigned co = plane / (unsigned)(d * D), f = (plane / (unsigned)D) % (unsigned)d;
+  const unsigned k2 = (unsigned)(k + 2);
+  dW2[i] = full[((size_t)plane * k2 + ky + 1) * k2 + kx + 1] + g[co] * b3[f];
+}
+
 }  // namespace pnsfm
 
 using namespace pnsfm;
@@ -274,6 +399,63 @@ int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream) {
   if (gx > 2048) gx = 2048;
   PNSFM_LAUNCH(region_ops_kernel, dim3((unsigned)gx, (unsigned)n_ops), dim3(256), 0, (hipStream_t)stream, ops);
   return check_launch("region_ops");
+}
+
+int pnsfm_upsample_nearest_forward(const float* x, float* y, int N, int h, int w, int s, void* stream) {
+  if (N < 1 || h < 1 || w < 1 || s < 1 || (w * s) % 4 != 0) { set_error("upsample_nearest_forward: output width must be a multiple of 4 (N=%d h=%d w=%d s=%d)", N, h, w, s); return -1; }
+  const size_t total = (size_t)N * h * s * w * s;
+  if (total >= (1ull << 32)) { set_error("upsample_nearest_forward: >= 2^32 output elements"); return -1; }
+  const unsigned total4 = (unsigned)(total / 4);
+  PNSFM_LAUNCH(upsample_nearest_fwd_kernel, dim3((total4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, h, w, s, total4);
+  return check_launch("upsample_nearest_forward");
+}
+
+int pnsfm_upsample_nearest_backward(const float* dy, float* dx, int N, int h, int w, int s, void* stream) {
+  if (N < 1 || h < 1 || w < 1 || s < 1 || (w * s) % 4 != 0) { set_error("upsample_nearest_backward: output width must be a multiple of 4 (N=%d h=%d w=%d s=%d)", N, h, w, s); return -1; }
+  if ((size_t)N * h * s * w * s >= (1ull << 32)) { set_error("upsample_nearest_backward: >= 2^32 output elements"); return -1; }
+  const unsigned total = (unsigned)((size_t)N * h * w);
+  PNSFM_LAUNCH(upsample_nearest_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, dx, h, w, s, total);
+  return check_launch("upsample_nearest_backward");
+}
+
+int pnsfm_loss_combine_forward(const float* const* photometric, int n, const float* const* smoothness, int ns, float weight,
+                               float* out3, void* stream) {
+  if (n < 1 || n > 8 || ns < 0 || ns > 8 || !photometric || (ns > 0 && !smoothness)) { set_error("loss_combine_forward: 1..8 photometric and 0..8 smoothness terms (got %d, %d)", n, ns); return -1; }
+  LossTerms t = {};
+  for (int i = 0; i < n; ++i) t.p[i] = photometric[i];
+  for (int i = 0; i < ns; ++i) t.s[i] = smoothness[i];
+  PNSFM_LAUNCH(loss_combine_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t, n, ns, weight, out3);
+  return check_launch("loss_combine_forward");
+}
+
+int pnsfm_loss_combine_backward(const float* g, int n, int ns, float weight, float* dout16, void* stream) {
+  if (n < 1 || n > 8 || ns < 0 || ns > 8) { set_error("loss_combine_backward: 1..8 photometric and 0..8 smoothness terms (got %d, %d)", n, ns); return -1; }
+  PNSFM_LAUNCH(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, n, ns, weight, dout16);
+  return check_launch("loss_combine_backward");
+}
+
+int pnsfm_pack_bias_eff_forward(const float* W2, const float* b2, const float* b3, float* Ssum, float* bias_eff, int C, int d,
+                                int blk, void* stream) {
+  if (C < 1 || d < 1 || d > 8 || blk < 1) { set_error("pack_bias_eff_forward: bad sizes (C=%d d=%d blk=%d)", C, d, blk); return -1; }
+  PNSFM_LAUNCH(pack_bias_eff_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, W2, b2, b3, Ssum, bias_eff, d, blk);
+  return check_launch("pack_bias_eff_forward");
+}
+
+int pnsfm_pack_bias_eff_backward(const float* g, const float* Ssum, const float* b3, const float* dWeff_full, float* db3, float* dW2,
+                                 int C, int d, int D, int k, void* stream) {
+  if (C < 1 || d < 1 || d > 8 || D < 1 || k < 1) { set_error("pack_bias_eff_backward: bad sizes (C=%d d=%d D=%d k=%d)", C, d, D, k); return -1; }
+  if (db3) {
+    PNSFM_LAUNCH(pack_bias_eff_db3_kernel, dim3(d), dim3(64), 0, (hipStream_t)stream, g, Ssum, db3, C, d);
+    if (int rc = check_launch("pack_bias_eff_backward (db3)")) return rc;
+  }
+  if (dW2) {
+    const size_t total = (size_t)C * d * D * k * k;
+    if (total >= (1ull << 32)) { set_error("pack_bias_eff_backward: >= 2^32 weight elements"); return -1; }
+    PNSFM_LAUNCH(pack_dw2_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dWeff_full, g, b3,
+                 dW2, d, D, k, (unsigned)total);
+    if (int rc = check_launch("pack_bias_eff_backward (dW2)")) return rc;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) conv3d_fwd_kernel(const float* __restrict
                                                           const float* __restrict__ b3, float* __restrict__ out,
                                                           int D, int H, int W) {
   __shared__ float ws[NF * 27 + NF];
-  for (int i = threadIdx.x; i < NF * 27 + NF; i += 256) ws[i] = i < NF * 27 ? w3[i] : b3[i - NF * 27];
+  for (int i = threadIdx.x; i < NF * 27 + NF; i += 256) ws[i] = i < NF * 27 ? w3[i] : (b3 ? b3[i - NF * 27] : 0.f);
   __syncthreads();
   const int HW = H * W, DHW = D * HW;
   const int vox = blockIdx.x * 256 + threadIdx.x;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) conv3d_fwd_x4_kernel(const float* __restr
   __shared__ __attribute__((aligned(16))) float wt[28][NF];      // [tap][feature]; row 27 = bias
   for (int i = threadIdx.x; i < 28 * NF; i += 256) {
     const int tap = i / NF, f = i - tap * NF;
-    wt[tap][f] = tap < 27 ? w3[f * 27 + tap] : b3[f];
+    wt[tap][f] = tap < 27 ? w3[f * 27 + tap] : (b3 ? b3[f] : 0.f);
   }
   __syncthreads();
   const int HW = H * W, DHW = D * HW, Wq = W >> 2, HWq = H * Wq;

@@ -52,6 +52,12 @@ SIGNATURES = {
     "pnsfm_invdepth_act_forward": (_i, [_p, _p, _sz, _f, _p]),
     "pnsfm_invdepth_act_backward": (_i, [_p, _p, _p, _sz, _f, _p]),
     "pnsfm_pose_vec2mat_forward": (_i, [_p, _p, _i, _p]),
+    "pnsfm_upsample_nearest_forward": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_upsample_nearest_backward": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "pnsfm_loss_combine_forward": (_i, [_p, _i, _p, _i, _f, _p, _p]),
+    "pnsfm_loss_combine_backward": (_i, [_p, _i, _i, _f, _p, _p]),
+    "pnsfm_pack_bias_eff_forward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "pnsfm_pack_bias_eff_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_pose_vec2mat_backward": (_i, [_p, _p, _p, _i, _p]),
     "pnsfm_supervised_loss_forward": (_i, [_p, _p, _p, _p, _sz, _i, _i, _p]),
     "pnsfm_supervised_loss_backward": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _p]),

@@ -689,6 +689,53 @@ def compose_pack_weight(W2, W3):
     return ComposePackWeightFn.apply(W2, W3, torch.is_grad_enabled())
 
 
+class ComposePackParamsFn(Function):
+    """(W_eff, bias_eff) of the composed packing convolution in one node: ComposePackWeightFn's composition plus
+
+        bias_eff[co] = b2[co] + sum_f b3[f] * sum_{ci,taps} W2[co, f*D + ci, taps]
+
+    (a Conv3d bias is a constant plane, which the Conv2d turns into a per-channel constant away from the border).  One node instead
+    of two plus a chain of reshape / sum / mul / add: forward = pad, composition stencil, one bias kernel; backward = the two
+    stencils and two small kernels that also fold the bias path's rank-one term into dW2 (no second gradient to accumulate)."""
+
+    @staticmethod
+    def forward(ctx, W2, b2, W3, b3, recording=True):
+        W2d, w3, b3d = W2.detach().contiguous(), W3.detach().contiguous(), b3.detach().contiguous()
+        W2pad = torch.nn.functional.pad(W2d, (1, 1, 1, 1))                            # [C, d*D, k+2, k+2]
+        Weff = ops.conv3d_backward_data(W2pad, w3)                                    # [C, D, k+2, k+2]
+        bias_eff, Ssum = ops.pack_bias_eff_forward(W2d, None if b2 is None else b2.detach().contiguous(), b3d)
+        ctx.save_for_backward(W2pad, w3, b3d, Ssum)
+        ctx.params = (W2, W3)
+        ctx.k = W2.shape[-1]
+        _WgradStream.note_use(recording, W2, W3)
+        return Weff, bias_eff
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gW, gb):
+        W2pad, w3, b3, Ssum = ctx.saved_tensors
+        _WgradStream.side_ok(*ctx.params)            # bookkeeping only: this node always runs on the compute stream
+        need_W2, need_b2, need_W3, need_b3 = ctx.needs_input_grad[:4]
+        C = W2pad.shape[0]
+        if gW is None:
+            gW = W2pad.new_zeros((C, W2pad.shape[1] // w3.shape[0], ctx.k + 2, ctx.k + 2))
+        if gb is None:
+            gb = W2pad.new_zeros((C,))
+        gW, gb = gW.contiguous(), gb.contiguous()
+        dW2 = dW3 = db3 = None
+        if need_W2 or need_b3:
+            # the composition's gradient on the padded taps; cropped and completed by the bias path's term in the same kernel
+            full = ops.conv3d_forward(gW, w3, None) if need_W2 else W2pad       # (W2pad: right shape, not read when dW2 is not wanted)
+            db3, dW2 = ops.pack_bias_eff_backward(gb, Ssum, b3, full, ctx.k, want_db3=need_b3, want_dW2=need_W2)
+        if need_W3:
+            dW3, _ = ops.conv3d_backward_weight(gW, W2pad)
+        return dW2, (gb if need_b2 else None), dW3, db3, None
+
+
+def compose_pack_params(W2, b2, W3, b3):
+    return ComposePackParamsFn.apply(W2, b2, W3, b3, torch.is_grad_enabled())
+
+
 def _R(op, dst, src=None):
     return (op, dst, src)
 
@@ -877,6 +924,68 @@ class PoseVec2MatFn(Function):
 
 def pose_vec2mat44(vec):
     return PoseVec2MatFn.apply(vec)
+
+
+class UpsampleNearestFn(Function):
+    """Nearest-neighbour up-sampling by an integer factor (F.interpolate(mode='nearest') / nn.Upsample of the reference:
+    models/model_utils.py:163-180, networks/depth/PackNet01.py:87-89); backward = s x s block sums."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return ops.upsample_nearest_forward(x.contiguous(), s)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.upsample_nearest_backward(dy.contiguous(), ctx.s), None
+
+
+def upsample_nearest(x, size=None, scale_factor=None):
+    """x [B,C,h,w] up-sampled (nearest) to `size` = (H, W) or by `scale_factor`.  Integer factors of fp32 device maps run the gfx950
+    kernel (factor 1: the tensor itself); anything else is torch's interpolate (same index rule for integer factors)."""
+    h, w = x.shape[-2:]
+    if size is not None:
+        H, W = int(size[-2]), int(size[-1])
+    else:
+        H, W = int(h * scale_factor), int(w * scale_factor)
+    s = H // h if h else 0
+    from . import _lib
+    if s >= 1 and (H, W) == (h * s, w * s) and (x.is_cuda or not _lib.REQUIRE_CUDA) and ops.upsample_nearest_ok(x, s):
+        return x if s == 1 else UpsampleNearestFn.apply(x, s)
+    if size is not None:
+        return torch.nn.functional.interpolate(x, size=(H, W), mode='nearest')
+    return torch.nn.functional.interpolate(x, scale_factor=scale_factor, mode='nearest')
+
+
+class LossCombineFn(Function):
+    """loss = mean_i P[i] + weight * mean_i (S[i] / 2^i) from the per-scale device scalars, one launch each way (the reference does
+    this with Python sums of 0-dim tensors: losses/multiview_photometric_loss.py:248-252, 275-280, 337-338; same operation order).
+    Returns the 3-vector (loss, weighted smoothness, photometric); only [0] carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, weight, n, *terms):
+        ctx.meta = (float(weight), n, len(terms) - n)
+        ctx.set_materialize_grads(False)
+        out = ops.loss_combine_forward([t.detach().reshape(()) for t in terms[:n]], [t.detach().reshape(()) for t in terms[n:]],
+                                       weight)
+        smooth, photo = out[1], out[2]
+        ctx.mark_non_differentiable(smooth, photo)
+        return out[0], smooth, photo
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gs, _gp):
+        weight, n, ns = ctx.meta
+        if g is None:
+            return (None,) * (2 + n + ns)
+        d = ops.loss_combine_backward(g.contiguous(), n, ns, weight)
+        return (None, None) + tuple(d[i] for i in range(n)) + tuple(d[8 + i] for i in range(ns))
+
+
+def loss_combine(photometric, smoothness, weight):
+    """(loss, weighted smoothness term, photometric term): 0-dim tensors, the last two without gradient (metrics)."""
+    return LossCombineFn.apply(float(weight), len(photometric), *photometric, *smoothness)
 
 
 class SupervisedLossFn(Function):

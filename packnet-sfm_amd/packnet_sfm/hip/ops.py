@@ -272,7 +272,7 @@ def _nf_of(w3):
 
 
 def conv3d_forward(p, w3, b3):
-    """p [B,D,H,W] -> [B,NF*D,H,W] (channel f*D+d), NF = w3.shape[0] in {4, 8}."""
+    """p [B,D,H,W] -> [B,NF*D,H,W] (channel f*D+d), NF = w3.shape[0] in {4, 8}.  b3 None = no bias."""
     _chk(p, w3, b3); _f32(p, w3, b3)
     B, D, H, W = p.shape
     nf = _nf_of(w3)
@@ -303,6 +303,76 @@ def conv3d_backward_weight(p, dout):
     _lib.check(_lib.get().pnsfm_conv3d_backward_weight(_ptr(p), _ptr(dout), _ptr(dw3), _ptr(db3), _ptr(ws), B, D, H, W, nf,
                                                        _stream(p)), "conv3d_backward_weight")
     return dw3, db3
+
+
+# ------------------------------------------------------------------- composed packing convolution: bias
+def pack_bias_eff_forward(W2, b2, b3):
+    """(bias_eff [C], Ssum [C,d]) of the composed packing convolution: include/pnsfm.h, pnsfm_pack_bias_eff_forward."""
+    _chk(W2, b2, b3); _f32(W2, b2, b3)
+    C, d = W2.shape[0], b3.numel()
+    blk = W2[0].numel() // d
+    Ssum = torch.empty((C, d), dtype=torch.float32, device=W2.device)
+    bias = torch.empty((C,), dtype=torch.float32, device=W2.device)
+    _lib.check(_lib.get().pnsfm_pack_bias_eff_forward(_ptr(W2), _ptr(b2), _ptr(b3), _ptr(Ssum), _ptr(bias), C, d, blk, _stream(W2)),
+               "pack_bias_eff_forward")
+    return bias, Ssum
+
+
+def pack_bias_eff_backward(g, Ssum, b3, dWeff_full, k, want_db3=True, want_dW2=True):
+    """g [C] = d(bias_eff); dWeff_full [C, d*D, k+2, k+2] = the composition's gradient on the padded taps.
+    Returns (db3 [d] or None, dW2 [C, d*D, k, k] or None)."""
+    _chk(g, Ssum, b3, dWeff_full); _f32(g, Ssum, b3, dWeff_full)
+    C, d = Ssum.shape
+    D = dWeff_full.shape[1] // d
+    assert tuple(dWeff_full.shape) == (C, d * D, k + 2, k + 2) and g.numel() == C
+    db3 = torch.empty((d,), dtype=torch.float32, device=g.device) if want_db3 else None
+    dW2 = torch.empty((C, d * D, k, k), dtype=torch.float32, device=g.device) if want_dW2 else None
+    _lib.check(_lib.get().pnsfm_pack_bias_eff_backward(_ptr(g), _ptr(Ssum), _ptr(b3), _ptr(dWeff_full), _ptr(db3), _ptr(dW2), C, d, D,
+                                                       k, _stream(g)), "pack_bias_eff_backward")
+    return db3, dW2
+
+
+# --------------------------------------------------------------------------------- nearest up-sampling
+def upsample_nearest_ok(x, s):
+    return x.dim() == 4 and x.dtype == torch.float32 and s >= 1 and (x.shape[3] * s) % 4 == 0 and x.numel() * s * s < 2 ** 32
+
+
+def upsample_nearest_forward(x, s):
+    _chk(x); _f32(x)
+    B, C, h, w = x.shape
+    y = torch.empty((B, C, h * s, w * s), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.get().pnsfm_upsample_nearest_forward(_ptr(x), _ptr(y), B * C, h, w, s, _stream(x)), "upsample_nearest_forward")
+    return y
+
+
+def upsample_nearest_backward(dy, s):
+    _chk(dy); _f32(dy)
+    B, C, Ho, Wo = dy.shape
+    h, w = Ho // s, Wo // s
+    dx = torch.empty((B, C, h, w), dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.get().pnsfm_upsample_nearest_backward(_ptr(dy), _ptr(dx), B * C, h, w, s, _stream(dy)), "upsample_nearest_backward")
+    return dx
+
+
+# ------------------------------------------------------------------------------- scalar tail of the loss
+def loss_combine_forward(photometric, smoothness, weight):
+    """photometric / smoothness: lists of 0-dim device tensors -> out3 = (loss, weighted smoothness, photometric)."""
+    n, ns = len(photometric), len(smoothness)
+    ts = list(photometric) + list(smoothness)
+    _chk(*ts); _f32(*ts)
+    P = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in photometric])
+    S = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in smoothness])
+    out = torch.empty((3,), dtype=torch.float32, device=ts[0].device)
+    _lib.check(_lib.get().pnsfm_loss_combine_forward(ctypes.byref(P), n, ctypes.byref(S), ns, float(weight), _ptr(out), _stream(out)), "loss_combine_forward")
+    return out
+
+
+def loss_combine_backward(g, n, ns, weight):
+    """g: 0-dim device tensor -> [16]: entries i < n = d/dP[i], 8 + i (i < ns) = d/dS[i]."""
+    _chk(g); _f32(g)
+    dout = torch.empty((16,), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.get().pnsfm_loss_combine_backward(_ptr(g), n, ns, float(weight), _ptr(dout), _stream(g)), "loss_combine_backward")
+    return dout
 
 
 # ------------------------------------------------------------------------------------------ invdepth

@@ -74,7 +74,7 @@ class MultiViewPhotometricLoss(LossBase):
         K32, rK32 = K.float(), ref_K.float()
         reduce_op = HF.REDUCE_MIN if self.photometric_reduce_op == 'min' else HF.REDUCE_MEAN
 
-        photometric_loss = 0.0
+        photometric, smoothness = [], []
         for i in range(n):
             h, w = inv_depths[i].shape[-2:]
             if (h, w) == (H, W):
@@ -84,23 +84,20 @@ class MultiViewPhotometricLoss(LossBase):
                 s = w / float(W)
                 Ki, rKi = scale_intrinsics(K32.clone(), s, s), scale_intrinsics(rK32.clone(), s, s)
             warped = HF.view_synthesis(inv_depths[i], refs_i, Ki.contiguous(), rKi.contiguous(), T, self.padding_mode)
-            photometric_loss = photometric_loss + HF.photometric(
+            photometric.append(HF.photometric(
                 warped, refs_i, images[i], self.ssim_loss_weight, self.C1, self.C2, bool(self.automask_loss), reduce_op,
-                float(self.clip_loss))
-        photometric_loss = photometric_loss / n
-        self.add_metric('photometric_loss', photometric_loss)
-        loss = photometric_loss
-
+                float(self.clip_loss)))
         if self.smooth_loss_weight > 0.0:
-            smoothness_loss = 0.0
-            for i in range(n):
-                # (mean normalisation of the inverse depth, reference :269-271, fused into the kernels)
-                smoothness_loss = smoothness_loss + HF.smoothness_norm(inv_depths[i], images[i]) / 2 ** i
-            smoothness_loss = self.smooth_loss_weight * (smoothness_loss / n)
+            # (mean normalisation of the inverse depth, reference :269-271, fused into the kernels)
+            smoothness = [HF.smoothness_norm(inv_depths[i], images[i]) for i in range(n)]
+        # loss = mean_i photometric[i] + weight * mean_i (smoothness[i] / 2^i): the reference's Python sums of 0-dim tensors
+        # (:248-252, :275-280, :337-338) as one launch over the 2n device scalars, same operation order
+        loss, smoothness_loss, _photometric_only = HF.loss_combine(photometric, smoothness, self.smooth_loss_weight)
+        # the reference adds the smoothness term IN PLACE (:337-338) into the tensor its 'photometric_loss' metric aliases, so
+        # that metric reports the TOTAL loss once smoothness is enabled; kept for identical logs
+        self.add_metric('photometric_loss', loss)
+        if self.smooth_loss_weight > 0.0:
             self.add_metric('smoothness_loss', smoothness_loss)
-            # in place, as the reference does (:338-339): its 'photometric_loss' metric is a detached alias of this
-            # tensor and therefore reports the TOTAL loss once smoothness is enabled; kept for identical logs
-            loss += smoothness_loss
 
         return {'loss': loss.unsqueeze(0), 'metrics': self.metrics}
 

@@ -7,8 +7,8 @@ called as `net(rgb=...)`, returns {'inv_depths': [4 scales]} in training and {'i
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from packnet_sfm.hip import functional as HF
 from packnet_sfm.networks.layers.packnet.layers01 import Conv2D, InvDepth, PackLayerConv3d, ResidualBlock, UnpackLayerConv3d
 
 
@@ -75,7 +75,7 @@ class PackNet01(nn.Module):
         the TUPLE of its parts: Conv2D folds the concatenation into its K loop (reference :138-174 materialises it)."""
         parts = (up, skip) if self.version == 'A' else (up + skip,)
         if disp is not None:
-            parts = parts + (F.interpolate(disp, scale_factor=2, mode='nearest'),)
+            parts = parts + (HF.upsample_nearest(disp, scale_factor=2),)
         return parts if len(parts) > 1 else parts[0]
 
     def forward(self, rgb):

@@ -8,8 +8,8 @@ unpacking kernels that already serve PackNetSlim01; the sparse branch is network
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from packnet_sfm.hip import functional as HF
 from packnet_sfm.networks.layers.minkowski_encoder import MinkowskiEncoder
 from packnet_sfm.networks.layers.packnet.layers01 import Conv2D, InvDepth, PackLayerConv3d, ResidualBlock, UnpackLayerConv3d
 
@@ -57,7 +57,7 @@ class Decoder(nn.Module):
     def _merge(self, up, skip, disp=None):
         parts = (up, skip) if self.version == 'A' else (up + skip,)        # Conv2D folds the concatenation into its K loop
         if disp is not None:
-            parts = parts + (F.interpolate(disp, scale_factor=2, mode='nearest'),)
+            parts = parts + (HF.upsample_nearest(disp, scale_factor=2),)
         return parts if len(parts) > 1 else parts[0]
 
     def forward(self, x5p, skips):

@@ -181,13 +181,11 @@ class PackLayerConv3d(nn.Module):
     def _conv_collapsed(self, P):
         base = self.conv.conv_base
         W2, b2, W3, b3 = base.weight, base.bias, self.conv3d.weight, self.conv3d.bias
-        C = W2.shape[0]
         k = self.conv.kernel_size
         r, S = k // 2, 2 * (k // 2) + 1
         B, _, h, w = P.shape
         # interior: one (k+2)x(k+2) conv with the composed kernel; its bias is b2 + sum over ALL taps of W2 * b3
-        W_eff = HF.compose_pack_weight(W2, W3)
-        bias_eff = b2 + (W2.reshape(C, self.d, -1).sum(2) * b3.view(1, self.d)).sum(1)
+        W_eff, bias_eff = HF.compose_pack_params(W2, b2, W3, b3)
         # border frame (r pixels): original formula on strips of 2r+1 packed rows / columns (top+bottom and left+right
         # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept.  The three
         # helper Functions do the strip gather / select / paste without full-size zero-fills and adds in backward.

@@ -35,6 +35,11 @@ def interpolate_scales(images, shape=None, mode='bilinear', align_corners=False)
         shape = images[0].shape
     if len(shape) > 2:
         shape = shape[-2:]
+    if mode == 'nearest':
+        # integer up-sampling factors of device maps (every predicted scale brought to full resolution): the gfx950 kernel, and the
+        # full-resolution map itself instead of a copy of it
+        from packnet_sfm.hip.functional import upsample_nearest
+        return [upsample_nearest(image, size=shape) for image in images]
     return [funct.interpolate(image, shape, mode=mode, align_corners=align_corners) for image in images]
 
 

@@ -129,3 +129,19 @@ def test_branch_stream_is_bit_identical():
             assert not bad and g0.keys() == g1.keys(), bad[:3]
     finally:
         HF.set_branch_stream(False)
+
+
+def test_upsample_nearest_gpu():
+    """Nearest up-sampling kernels (every predicted scale brought to full resolution; the inverse depth handed to the next iconv
+    block) vs torch's interpolate and its gradient."""
+    P.case_upsample_nearest(DEV)
+
+
+def test_loss_combine_gpu():
+    """The scalar tail of the multi-view photometric loss as one launch each way: bit-equal to the Python sums of 0-dim tensors."""
+    P.case_loss_combine(DEV)
+
+
+def test_compose_pack_params_gpu():
+    """Composed packing convolution: kernel, bias and all four parameter gradients from one node vs the oracle's formula."""
+    P.case_compose_pack_params(DEV)

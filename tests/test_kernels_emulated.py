@@ -106,6 +106,18 @@ def test_region_ops_batched_windows(emulated_kernels):
     P.case_region_ops('cpu')
 
 
+def test_upsample_nearest(emulated_kernels):
+    P.case_upsample_nearest('cpu')
+
+
+def test_loss_combine(emulated_kernels):
+    P.case_loss_combine('cpu')
+
+
+def test_compose_pack_params(emulated_kernels):
+    P.case_compose_pack_params('cpu')
+
+
 @pytest.mark.parametrize('scale', [1.0, 1e-7])
 def test_smoothness_norm_fused(emulated_kernels, scale):
     """hip.functional.smoothness_norm (mean normalisation of the inverse depth fused into the smoothness kernels, round 4) against

@@ -28,6 +28,12 @@ if not args:
                (4, 64, 129, 192, 640, 3)):
         args += list(sh) + [-1, 0, 0, 0, 0]
 MODES = [0, 1, 2, 3, 4, 8, 16, 32, 1 | 2 | 4, 1 | 2 | 4 | 8, 1 | 2 | 4 | 8 | 32, 16 | 32]
+PAD = 0
+if '--one-wg' in sys.argv:
+    # one workgroup per CU (LDS padded to > half a CU's): what ONE wave per SIMD sustains with and without the producer work --
+    # the ceiling of a design that gives the loads / split / DMA to separate producer waves
+    MODES = [0, 1 | 2 | 4, 1 | 2 | 4 | 32, 1 | 2 | 4 | 8 | 32]
+    PAD = 40 * 1024
 for i in range(0, len(args), 11):
     B, Cin, Cout, H, W, ks, NT, variant, narrow, tm, split = args[i:i + 11]
     n = lib.pnsfm_conv2d_packed_elems_fwd(Cin, Cout, ks)
@@ -40,6 +46,7 @@ for i in range(0, len(args), 11):
     fwd = lambda: lib.pnsfm_conv2d_forward(vp(x.data_ptr()), vp(wp.data_ptr()), vp(0), vp(y.data_ptr()), B, Cin, Cout, H, W, ks, vp(0))
     fl = 2.0 * B * Cin * Cout * ks * ks * H * W
     out = []
+    lib.pnsfm_debug_set_smem_pad(PAD)
     for mode in MODES:
         lib.pnsfm_debug_set_ablate(mode)
         for _ in range(3):

@@ -397,46 +397,53 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 }
 
 // second stage of a pixel-split launch: dW[co][ci][ky][kx] = sum over the Z partial tensors, in a fixed order (deterministic).
-// One workgroup per (co, 128 input channels).  The partials are [z][ky][COP][kx][CIP] with ci fastest, so for a fixed (z, tap, co)
-// the block's 128 channels are 512 contiguous bytes: thread (g = tid >> 5, j = tid & 31) owns channels 4j..4j+3 (one 16-byte
-// load per partial) of the taps g, g + 8, ... and adds their Z partials in ascending z, four loads in flight -- no cross-thread
+// One workgroup per (co, CIB input channels), CIB = 4 << lshift chosen by the host so that the (tap, 4-channel column) items of a
+// block fit its 256 threads in one pass where they can (3x3: 64 channels = 144 items, 5x5: 32, 7x7: 16; 1x1: 128).  The partials
+// are [z][ky][COP][kx][CIP] with ci fastest: an item is one 16-byte load per partial, added in ascending z with EIGHT loads in
+// flight (the kernel is latency-bound: the partials were written a moment ago and mostly sit in the MALL) -- no cross-thread
 // reduction at all; the sums go through an LDS tile [ci][tap] so that dW leaves as one contiguous (ci, tap) run per block.
-// (Round 2's version read 128-byte runs with 4-byte loads and met in LDS per tap: 0.39 TB/s, 0.72 ms per step.)
+// (Round 2: 128-byte runs with 4-byte loads, meeting in LDS per tap: 0.39 TB/s, 0.72 ms per step.  Round 3: 128 channels per block,
+// thread group g owned taps g, g + 8, ...: a 3x3 layer's ninth tap doubled the time of 32 threads, four loads in flight.)
 __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_bias,
                                                             float* __restrict__ dw, float* __restrict__ dbias, int Z, int KS,
-                                                            int COP, int CIP, int Cin, int Cout) {
+                                                            int COP, int CIP, int Cin, int Cout, int lshift) {
   __shared__ float tile[128 * 49 + 4];
-  const int co = blockIdx.x, ci0 = blockIdx.y * 128, KK = KS * KS;
-  const int g = threadIdx.x >> 5, j = threadIdx.x & 31;
-  const int ci = ci0 + 4 * j;
+  const int LPT = 1 << lshift, CIB = 4 * LPT;              // lanes per tap, input channels per block
+  const int co = blockIdx.x, ci0 = blockIdx.y * CIB, KK = KS * KS;
   const size_t zstride = (size_t)KS * COP * KS * CIP;
-  if (ci < CIP) {
-    for (int tap = g; tap < KK; tap += 8) {
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const float* p = ws + (((size_t)ky * COP + co) * KS + kx) * CIP + ci;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int z = 0;
-      for (; z + 4 <= Z; z += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * zstride);
-        const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(z + 1) * zstride);
-        const float4 c = *reinterpret_cast<const float4*>(p + (size_t)(z + 2) * zstride);
-        const float4 d = *reinterpret_cast<const float4*>(p + (size_t)(z + 3) * zstride);
-        s0 = (((s0 + a.x) + b.x) + c.x) + d.x;
-        s1 = (((s1 + a.y) + b.y) + c.y) + d.y;
-        s2 = (((s2 + a.z) + b.z) + c.z) + d.z;
-        s3 = (((s3 + a.w) + b.w) + c.w) + d.w;
-      }
-      for (; z < Z; ++z) {
-        const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * zstride);
-        s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
-      }
-      float* t = tile + (4 * j) * KK + tap;
-      t[0] = s0; t[KK] = s1; t[2 * KK] = s2; t[3 * KK] = s3;
+  for (int item = threadIdx.x; item < KK * LPT; item += 256) {
+    const int tap = item >> lshift, j = item & (LPT - 1);
+    const int ci = ci0 + 4 * j;
+    if (ci >= CIP) continue;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    const float* p = ws + (((size_t)ky * COP + co) * KS + kx) * CIP + ci;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 8 <= Z; z += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u) * zstride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
     }
+    if (z + 4 <= Z) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u) * zstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+      z += 4;
+    }
+    for (; z < Z; ++z) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * zstride);
+      s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
+    }
+    float* t = tile + (4 * j) * KK + tap;
+    t[0] = s0; t[KK] = s1; t[2 * KK] = s2; t[3 * KK] = s3;
   }
   __syncthreads();
   int nci = Cin - ci0;
-  if (nci > 128) nci = 128;
+  if (nci > CIB) nci = CIB;
   float* out = dw + ((size_t)co * Cin + ci0) * KK;
   for (int e = threadIdx.x; e < nci * KK; e += 256) out[e] = tile[e];
   if (dbias && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -449,8 +456,11 @@ __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restr
 // the second stage on its own (conv2d_wgrad4.hip writes the same partial-tensor layout)
 int launch_wgrad3_reduce(const float* ws, const float* ws_bias, float* dw, float* dbias, int Z, int KS, int COP, int CIP, int Cin,
                          int Cout, hipStream_t s) {
-  PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 128)), dim3(256), 0, s, ws, ws_bias, dw, dbias, Z, KS, COP, CIP, Cin,
-               Cout);
+  // channels per block: the (tap, 4-channel column) items of a block in one pass of its 256 threads where possible
+  int lshift = 5;                                            // 128 channels (1x1)
+  while (lshift > 2 && KS * KS * (1 << lshift) > 256) --lshift;
+  PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 4 << lshift)), dim3(256), 0, s, ws, ws_bias, dw, dbias, Z, KS, COP, CIP,
+               Cin, Cout, lshift);
   return check_launch("conv2d_backward_weight (split-bf16, reduction)");
 }
 

@@ -220,11 +220,14 @@ __global__ void __launch_bounds__(256) conv3d_fwd_x4_kernel(const float* __restr
 // executed under divergence.
 template <int NF>
 __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
-                                                            float* __restrict__ dp, int D, int H, int W, int len) {
+                                                            float* __restrict__ dp, int D, int H, int W, int len, int xmap) {
   const int HW = H * W, DHW = D * HW;
   const int nchunk = (D + len - 1) / len;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long lin = ((long)blockIdx.x * 4 + wave) * 62 + lane - 1;      // flattened (chunk, pixel) index of this lane
+  // rows y - 1 / y + 1 of a block's pixels are the centre rows of the blocks a few places before / after it: an XCD gets a
+  // contiguous range of the block order (pnsfm_common.h) so that those rows are found in ITS L2 instead of being fetched by three
+  const unsigned bx = xmap ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long lin = ((long)bx * 4 + wave) * 62 + lane - 1;      // flattened (chunk, pixel) index of this lane
   const bool inr = lin >= 0 && lin < (long)nchunk * HW;
   const bool active = inr && lane >= 1 && lane <= 62;
   const int chunk = inr ? (int)(lin / HW) : 0;
@@ -281,6 +284,83 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const float* __restri
     a_mid = a_hi;
     a_hi = 0.f;
   }
+}
+
+// The same stencil for runs of LEN = 8 / 4 / 2 planes (every volume on the training step): the kernel above needs all NF * 27 = 216
+// weights as scalar operands in every plane step, the SGPR file holds ~100, and hipcc parks the rest in VGPR lanes -- 353
+// v_readlane (+ wait states) per plane step against 144 FMA instructions.  Here a thread keeps the LEN outputs of its column in
+// registers and walks the run once per FEATURE: that feature's 27 weights stay in SGPRs across the fully unrolled plane loop (the
+// accumulator a plane feeds is a compile-time index, every FMA is half of a v_pk_fma_f32), nothing is parked or re-loaded, one
+// buffer descriptor instead of eight, 94 VGPRs.  Loads and wave shifts per output are unchanged.  unpack1's volume (4 x 32 x 96 x
+// 320): 107 -> 64 us; the step's nine volumes 417 -> 265 us (profiles/r04_ab_conv3d_dgrad_column.txt).
+template <int NF, int LEN>
+__global__ void __launch_bounds__(256) conv3d_dgrad_col_kernel(const float* __restrict__ dout, const float* __restrict__ w3,
+                                                                float* __restrict__ dp, int D, int H, int W, int xmap) {
+  constexpr int FG = 1;                    // features per pass (2: 54 weights + the plane masks overflow the SGPR file again, 76 vs 64 us)
+  const int HW = H * W, DHW = D * HW;
+  const int nchunk = (D + LEN - 1) / LEN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned bx = xmap ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long lin = ((long)bx * 4 + wave) * 62 + lane - 1;      // flattened (chunk, pixel) index of this lane
+  const bool inr = lin >= 0 && lin < (long)nchunk * HW;
+  const bool active = inr && lane >= 1 && lane <= 62;
+  const int chunk = inr ? (int)(lin / HW) : 0;
+  const int pix = inr ? (int)(lin - (long)chunk * HW) : 0;
+  const int y = pix / W, x = pix - y * W;
+  const int d0 = chunk * LEN;
+  const int dend = (d0 + LEN < D) ? d0 + LEN : D;
+  const bool has_l = x > 0, has_r = x + 1 < W;
+  const unsigned kOut = 0x7fffffffu;       // out-of-range byte offset -> the load returns 0
+  unsigned off[3];                         // in-plane byte offsets of the centre column in rows y + 1, y, y - 1 (kOut outside the image)
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y - dy + 1;
+    off[dy] = (inr && yy >= 0 && yy < H) ? (unsigned)(yy * W + x) * 4u : kOut;
+  }
+  float acc[LEN];
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) acc[i] = 0.f;
+#pragma unroll 1
+  for (int f0 = 0; f0 < NF; f0 += FG) {
+    pnsfm_buf gbuf[FG];
+#pragma unroll
+    for (int u = 0; u < FG; ++u) gbuf[u] = pnsfm_make_buf(dout + ((size_t)blockIdx.z * NF + f0 + u) * DHW, (unsigned)DHW * 4u);
+    const float* wf = w3 + f0 * 27;
+#pragma unroll
+    for (int t = 0; t < LEN + 2; ++t) {
+      const int dd = d0 - 1 + t;           // this plane feeds the outputs d0 + t - 2 (dz = 0), d0 + t - 1 (dz = 1), d0 + t (dz = 2)
+      const bool dok = dd >= 0 && dd < D && dd <= dend;
+      const unsigned plane = dok ? (unsigned)dd * (unsigned)HW * 4u : 0u;
+      float g[FG][9];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned vo = (dok && off[dy] != kOut) ? plane + off[dy] : kOut;
+#pragma unroll
+        for (int u = 0; u < FG; ++u) g[u][dy * 3 + 1] = pnsfm_buf_load(gbuf[u], vo, 0u);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int u = 0; u < FG; ++u) {
+          const float c = g[u][dy * 3 + 1];
+          const float r = __shfl_down(c, 1), l = __shfl_up(c, 1);
+          g[u][dy * 3 + 0] = has_r ? r : 0.f;       // dx = 0: xx = x + 1
+          g[u][dy * 3 + 2] = has_l ? l : 0.f;       // dx = 2: xx = x - 1
+        }
+#pragma unroll
+      for (int u = 0; u < FG; ++u)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          if (t >= 2) acc[t >= 2 ? t - 2 : 0] = fmaf(wf[u * 27 + tp], g[u][tp], acc[t >= 2 ? t - 2 : 0]);
+          if (t >= 1 && t <= LEN) acc[(t >= 1 && t <= LEN) ? t - 1 : 0] = fmaf(wf[u * 27 + 9 + tp], g[u][tp], acc[(t >= 1 && t <= LEN) ? t - 1 : 0]);
+          if (t < LEN) acc[t < LEN ? t : 0] = fmaf(wf[u * 27 + 18 + tp], g[u][tp], acc[t < LEN ? t : 0]);
+        }
+    }
+  }
+  float* ob = dp + (size_t)blockIdx.z * DHW + pix;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i)
+    if (active && d0 + i < dend) ob[(size_t)(d0 + i) * HW] = acc[i];
 }
 
 // dw3[f][tap] = sum_{b,d,y,x} dout[b][f*D+d][y][x] * p[b][d+dz-1][y+dy-1][x+dx-1];  db3[f] = sum dout[b][f*D+d][y][x]
@@ -474,9 +554,26 @@ int pnsfm_conv3d_backward_data(const float* dout, const float* w3, float* dp, in
   // run length along d: 8 (25 % halo planes) when that still gives every CU a few blocks, shorter for small volumes
   int len = D < 8 ? D : 8;
   while (len > 2 && (long)B * ceil_div(D, len) * H * W < 2L * 256 * 256) len = ceil_div(len, 2);
+  if (const char* e = getenv("PNSFM_CONV3D_LEN")) {          // tests: pin the run length (small volumes on the 8- / 4-plane kernels)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8) len = v;
+  }
   const dim3 grid(ceil_div(ceil_div(ceil_div(D, len) * H * W, 62), 4), 1, B);      // 62 outputs per wave (two halo lanes)
-  if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
-  else PNSFM_LAUNCH((conv3d_dgrad_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len);
+  static const int xm = [] { const char* e = getenv("PNSFM_STENCIL_XCD_MAP"); return (e && e[0] == '0') ? 0 : 1; }();      // A/B switch
+  const int xmap = (block_map_mode() >= 2 && xm) ? 1 : 0;
+  static const int col = [] { const char* e = getenv("PNSFM_CONV3D_DGRAD_COL"); return (e && e[0] == '0') ? 0 : 1; }();      // A/B switch
+  if (col && len == 8) {
+    if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_col_kernel<8, 8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+    else PNSFM_LAUNCH((conv3d_dgrad_col_kernel<4, 8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+  } else if (col && len == 4) {
+    if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_col_kernel<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+    else PNSFM_LAUNCH((conv3d_dgrad_col_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+  } else if (col && len == 2) {
+    if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_col_kernel<8, 2>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+    else PNSFM_LAUNCH((conv3d_dgrad_col_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, xmap);
+  }
+  else if (NF == 8) PNSFM_LAUNCH((conv3d_dgrad_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len, xmap);
+  else PNSFM_LAUNCH((conv3d_dgrad_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, dout, w3, dp, D, H, W, len, xmap);
   return check_launch("conv3d_backward_data");
 }
 

@@ -390,6 +390,26 @@ def test_conv3d_raw(emulated_kernels, shape, nf):
     P.check(bd.grad, br.grad, 1e-5, 'conv3d dbias')
 
 
+@pytest.mark.parametrize('nf', [8, 4])
+@pytest.mark.parametrize('run', [8, 4, 2])
+@pytest.mark.parametrize('shape', [(1, 19, 3, 5), (2, 8, 2, 70), (1, 33, 4, 6), (1, 3, 5, 7)])
+def test_conv3d_dgrad_column_kernel(emulated_kernels, monkeypatch, shape, run, nf):
+    """Data gradient of the 3x3x3 stencil on the 8- / 4- / 2-plane column kernel (conv3d_dgrad_col_kernel: the outputs of a run stay
+    in registers, one pass per feature) -- what every volume of the training step runs; small volumes reach it through
+    PNSFM_CONV3D_LEN.  Ragged last runs, several runs per column, rows that end inside a wave, D < run."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.hip import ops
+    monkeypatch.setenv('PNSFM_CONV3D_LEN', str(run))
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + run)
+    p = torch.randn(B, D, H, W, generator=g).requires_grad_(True)
+    w3 = 0.3 * torch.randn(nf, 1, 3, 3, 3, generator=g)
+    yr = O.conv3d_1to8(p, w3, torch.zeros(nf))
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    P.check(ops.conv3d_backward_data(dy, w3), p.grad, 1e-5, 'conv3d dgrad (run %d)' % run)
+
+
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (1, 19, 4, 70), (1, 64, 3, 5)])
 def test_invdepth_conv_raw(emulated_kernels, shape):
     """Fused InvDepth head (one output channel): ragged channel quarters / channel groups, pixel tails, vs torch."""

@@ -372,7 +372,37 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_col_kernel(const float* __re
 // unrolled loop instead of moves), loads 9 new p values + 4 dout values per step, and accumulates 4 x 27 products (+ 4
 // bias sums) in registers.  Lanes run along x, so every load is coalesced.  The 112 per-thread partials are reduced
 // through LDS 16 at a time (conflict-free padded rows, then a 16-lane shuffle), one partial slot per value per block.
+// block reduction of a thread's 4 x 28 partials (27 taps + bias per feature), kW3Pass values per pass; one slot per (block, value):
+// plain stores, no zero-fill; conv3d_wgrad_finish_kernel adds the blocks in a fixed order (round 3: fp64 atomics)
 constexpr int kW3Pass = 16, kW3Row = 256 + 16;
+template <int FPB>
+__device__ __forceinline__ void conv3d_wgrad_block_reduce(const float (&acc)[FPB][27], const float (&bs)[FPB], float* red,
+                                                          float* __restrict__ part, int fg) {
+  const int tid = threadIdx.x;
+  const int rv = tid >> 4, rj = tid & 15;
+  constexpr int NV = FPB * 28;
+#pragma unroll
+  for (int pass = 0; pass < (NV + kW3Pass - 1) / kW3Pass; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kW3Pass; ++u) {
+      const int v = pass * kW3Pass + u;      // v = f*28 + t  (t = 27: bias)
+      const int f = v < NV ? v / 28 : 0, t = v < NV ? v - f * 28 : 0;
+      red[u * kW3Row + tid] = (t < 27) ? acc[f][t < 27 ? t : 0] : bs[f];
+    }
+    __syncthreads();
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += red[rv * kW3Row + rj + 16 * i];
+    sacc += __shfl_xor(sacc, 8);
+    sacc += __shfl_xor(sacc, 4);
+    sacc += __shfl_xor(sacc, 2);
+    sacc += __shfl_xor(sacc, 1);
+    if (rj == 0 && pass * kW3Pass + rv < NV)
+      part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + fg) * NV + pass * kW3Pass + rv] = sacc;
+  }
+}
+
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restrict__ p, const float* __restrict__ dout,
                                                             float* __restrict__ part, int D, int H, int W, int len, int NF) {
   __shared__ float red[kW3Pass * kW3Row];
@@ -443,44 +473,148 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const float* __restri
     load_plane(pc, d + 3);
     step(d + 2, pd, pa, pc);
   }
-  // ---- block reduction of the 4 x 28 partials, kW3Pass values per pass
-  const int rv = tid >> 4, rj = tid & 15;
+  conv3d_wgrad_block_reduce<4>(acc, bs, red, part, fg);
+}
+
+// Round 4: the kernel above uses every load in the step that issues it, computes thirteen 64-bit addresses (and their zero-page
+// selects) per step, spends two v_mov per v_pk_fma_f32 on building operand pairs (27 taps per feature: the pairs straddle planes
+// and features) and sits at 246 VGPRs: two waves per SIMD, each waiting out a full memory latency per plane of the dout stream
+// (unpack1: 83 us against ~22 us of FMAs).  Same arithmetic here with the data gradient's addressing: lanes run along the flattened
+// (chunk, pixel) index, 62 outputs per wave, buffer loads through wave-uniform descriptors (zero padding = an out-of-range
+// offset), a thread LOADS only the centre column of the three rows of a p plane and takes x - 1 / x + 1 from its neighbour lanes
+// (halo lanes 0 and 63 read dout as zero and therefore add nothing).  A plane's nine values are held as FIVE register pairs -- the
+// tenth element is 1 in the dz = 0 plane, 0 elsewhere -- and so are a feature's accumulators (3 x 5 pairs): every FMA is one half
+// of a v_pk_fma_f32 on naturally aligned pairs, and the tenth accumulator of the dz = 0 row is the bias gradient.  The centre
+// triples of the next PF planes and the dout values of the next PF steps are in flight in rings whose slots are compile-time (PF
+// steps per trip, PF a multiple of 3: the three expanded planes d - 1, d, d + 1 rotate with the same period).
+typedef float c3d_f32x2 __attribute__((ext_vector_type(2)));
+template <int PF, int FPB>      // planes / steps in flight; features per workgroup (the grid's y extent is NF / FPB)
+__global__ void __launch_bounds__(256, 2) conv3d_wgrad_ring_kernel(const float* __restrict__ p, const float* __restrict__ dout,
+                                                                    float* __restrict__ part, int D, int H, int W, int len, int NF,
+                                                                    int xmap) {
+  __shared__ float red[kW3Pass * kW3Row];
+  const int HW = H * W, DHW = D * HW;
+  const int nchunk = (D + len - 1) / len;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned bx = xmap ? pnsfm_xcd_logical_block(blockIdx.x, gridDim.x) : blockIdx.x;
+  const long lin = ((long)bx * 4 + wave) * 62 + lane - 1;      // flattened (chunk, pixel) index of this lane
+  const bool inr = lin >= 0 && lin < (long)nchunk * HW;
+  const bool active = inr && lane >= 1 && lane <= 62;
+  const int chunk = inr ? (int)(lin / HW) : 0;
+  const int pix = inr ? (int)(lin - (long)chunk * HW) : 0;
+  const int y = pix / W, x = pix - y * W;
+  const int fg = blockIdx.y, b = blockIdx.z;
+  const int d0 = chunk * len;
+  const int dend = (d0 + len < D) ? d0 + len : D;
+  const bool has_l = x > 0, has_r = x + 1 < W;
+  const unsigned kOut = 0x7fffffffu;       // out-of-range byte offset -> the load returns 0
+  const pnsfm_buf pbuf = pnsfm_make_buf(p + (size_t)b * DHW, (unsigned)DHW * 4u);
+  pnsfm_buf gbuf[FPB];
 #pragma unroll
-  for (int pass = 0; pass < 7; ++pass) {
-    __syncthreads();
+  for (int f = 0; f < FPB; ++f) gbuf[f] = pnsfm_make_buf(dout + ((size_t)b * NF + fg * FPB + f) * DHW, (unsigned)DHW * 4u);
+  unsigned off[3];                         // in-plane byte offsets of the centre column in rows y - 1, y, y + 1 (kOut outside the image)
 #pragma unroll
-    for (int u = 0; u < kW3Pass; ++u) {
-      const int v = pass * kW3Pass + u;      // 0..111: v = f*28 + t  (t = 27: bias)
-      const int f = v / 28, t = v - f * 28;
-      red[u * kW3Row + tid] = (t < 27) ? acc[f][t < 27 ? t : 0] : bs[f];
+  for (int r = 0; r < 3; ++r) {
+    const int yy = y + r - 1;
+    off[r] = (inr && yy >= 0 && yy < H) ? (unsigned)(yy * W + x) * 4u : kOut;
+  }
+  const unsigned goff = active ? (unsigned)pix * 4u : kOut;
+  // plane k of this thread's run is dd = d0 - 1 + k; step s is d = d0 + s and uses the planes s, s + 1, s + 2
+  auto load_centres = [&](float (&c)[3], int k) {
+    const int dd = d0 - 1 + k;
+    const bool dok = dd >= 0 && dd < D;
+    const unsigned plane = dok ? (unsigned)dd * (unsigned)HW * 4u : 0u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) c[r] = pnsfm_buf_load(pbuf, (dok && off[r] != kOut) ? plane + off[r] : kOut, 0u);
+  };
+  // nine taps t = 3 * row + dx (dx = 0: x - 1) as pairs (t0,t1) (t2,t3) (t4,t5) (t6,t7) (t8, pad)
+  auto expand = [&](c3d_f32x2 (&q)[5], const float (&c)[3]) {
+    float v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float lft = __shfl_up(c[r], 1), rgt = __shfl_down(c[r], 1);
+      v[r * 3 + 0] = has_l ? lft : 0.f;
+      v[r * 3 + 1] = c[r];
+      v[r * 3 + 2] = has_r ? rgt : 0.f;
     }
-    __syncthreads();
-    float sacc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sacc += red[rv * kW3Row + rj + 16 * i];
-    sacc += __shfl_xor(sacc, 8);
-    sacc += __shfl_xor(sacc, 4);
-    sacc += __shfl_xor(sacc, 2);
-    sacc += __shfl_xor(sacc, 1);
-    if (rj == 0) {
-      const int v = pass * kW3Pass + rv;
-      const int f = v / 28, t = v - f * 28;
-      // one slot per (block, value): plain stores, no zero-fill; conv3d_wgrad_finish_kernel adds the blocks in a fixed order
-      // (round 3: fp64 atomics)
-      (void)f; (void)t;
-      part[(((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + fg) * 112 + v] = sacc;
+    for (int i = 0; i < 4; ++i) { q[i].x = v[2 * i]; q[i].y = v[2 * i + 1]; }
+    q[4].x = v[8];
+    q[4].y = 0.f;
+  };
+  auto load_g = [&](float (&g)[FPB], int sidx) {
+    const int d = d0 + sidx;
+    const unsigned vo = (goff != kOut && d < dend) ? (unsigned)d * (unsigned)HW * 4u + goff : kOut;
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) g[f] = pnsfm_buf_load(gbuf[f], vo, 0u);
+  };
+  c3d_f32x2 acc[FPB][3][5];                  // [feature][dz][pair]; acc[f][0][4].y collects the bias gradient
+#pragma unroll
+  for (int f = 0; f < FPB; ++f)
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[f][z][i] = (c3d_f32x2)(0.f);
+  c3d_f32x2 Q[3][5];
+  float C[PF][3], G[PF][FPB];
+  {
+    float c0[3], c1[3], c2[3];
+    load_centres(c0, 0);
+    load_centres(c1, 1);
+    load_centres(c2, 2);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_centres(C[u], 3 + u);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_g(G[u], u);
+    expand(Q[0], c0);
+    expand(Q[1], c1);
+    expand(Q[2], c2);
+  }
+#pragma unroll 1
+  for (int s0 = 0; s0 < len; s0 += PF) {        // len is a multiple of PF (host); steps past the run's end read dout as zero
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      c3d_f32x2 q0[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) q0[i] = Q[u % 3][i];
+      q0[4].y = 1.f;                            // the dz = 0 row's tenth column sums dout: the bias gradient
+      const c3d_f32x2 (&q1)[5] = Q[(u + 1) % 3];
+      const c3d_f32x2 (&q2)[5] = Q[(u + 2) % 3];
+#pragma unroll
+      for (int f = 0; f < FPB; ++f) {
+        const c3d_f32x2 g = (c3d_f32x2)(G[u][f]);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          acc[f][0][i] = g * q0[i] + acc[f][0][i];
+          acc[f][1][i] = g * q1[i] + acc[f][1][i];
+          acc[f][2][i] = g * q2[i] + acc[f][2][i];
+        }
+      }
+      expand(Q[u % 3], C[u]);                   // plane s + 3 replaces plane s
+      load_centres(C[u], s0 + u + 3 + PF);
+      load_g(G[u], s0 + u + PF);
     }
   }
+  float accf[FPB][27], bs[FPB];
+#pragma unroll
+  for (int f = 0; f < FPB; ++f) {
+    bs[f] = acc[f][0][4].y;
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) accf[f][z * 9 + t] = (t & 1) ? acc[f][z][t >> 1].y : acc[f][z][t >> 1].x;
+  }
+  conv3d_wgrad_block_reduce<FPB>(accf, bs, red, part, fg);
 }
 
 // dw3 / db3 entry (f, t) = sum over the blocks' partials (fp64), one wave per entry: lane l adds blocks l, l + 64, ... in order, the
 // lane sums meet in a fixed shuffle tree -- bit-reproducible
 __global__ void __launch_bounds__(64) conv3d_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw3,
-                                                                 float* __restrict__ db3, int nblk, int ngroups) {
-  const int i = blockIdx.x, lane = threadIdx.x;             // i = f * 28 + t over all NF features
-  const int f = i / 28, t = i - f * 28, fg = f >> 2, v = (f & 3) * 28 + t;
+                                                                 float* __restrict__ db3, int nblk, int ngroups, int fpb) {
+  const int i = blockIdx.x, lane = threadIdx.x;             // i = f * 28 + t over all NF features; fpb features per group
+  const int f = i / 28, t = i - f * 28, fg = f / fpb, v = (f - fg * fpb) * 28 + t;
   double s = 0.0;
-  for (int p = lane; p < nblk; p += 64) s += (double)part[((size_t)p * ngroups + fg) * 112 + v];
+  for (int p = lane; p < nblk; p += 64) s += (double)part[((size_t)p * ngroups + fg) * (fpb * 28) + v];
   for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
   if (lane == 0) { if (t < 27) dw3[f * 27 + t] = (float)s; else db3[f] = (float)s; }
 }
@@ -586,16 +720,24 @@ int pnsfm_conv3d_backward_weight(const float* p, const float* dout, float* dw3, 
   // CU a few blocks
   int len = D;
   while (len > 12 && (long)B * (NF / 4) * ceil_div(D, len) * H * W < 4L * 256 * 256) len = ceil_div(len, 2);
-  len = ceil_div(len, 3) * 3;
-  const dim3 grid(ceil_div(ceil_div(D, len) * H * W, 256), NF / 4, B);
-  ScratchLease lease(s, (size_t)grid.x * grid.y * grid.z * 112 * sizeof(float));
+  // A/B switch: PNSFM_CONV3D_WGRAD_RING=0 = round 3's kernel.  (Measured and dropped, profiles/r04_ab_conv3d_wgrad_ring.txt: two
+  // features per workgroup with rings of 3 / 6 -- 154 / 209 VGPRs -- are slower, 340 / 375 us over the step's volumes against 323:
+  // the per-plane work is shared by half as many FMAs.)
+  const int ring = [] { const char* e = getenv("PNSFM_CONV3D_WGRAD_RING"); return (e && e[0] == '0') ? 0 : 34; }();
+  const int pf = ring / 10, fpb = ring ? ring % 10 : 4;
+  if (ring && (size_t)D * H * W * 4 >= 0x7fffffffull) { set_error("conv3d_backward_weight: feature slab exceeds the 2 GiB buffer window"); return -1; }
+  len = ring ? ceil_div(len, pf) * pf : ceil_div(len, 3) * 3;       // whole trips of the unrolled loop
+  const dim3 grid(ring ? ceil_div(ceil_div(ceil_div(D, len) * H * W, 62), 4) : ceil_div(ceil_div(D, len) * H * W, 256), NF / fpb, B);
+  ScratchLease lease(s, (size_t)grid.x * grid.y * grid.z * fpb * 28 * sizeof(float));
   float* const part = lease.as<float>();
   if (!part) return -1;
-  PNSFM_LAUNCH(conv3d_wgrad_kernel, grid, dim3(256), 0, s, p, dout, part, D, H, W, len, NF);
+  const int xmap = block_map_mode() >= 2 ? 1 : 0;
+  if (ring == 34) PNSFM_LAUNCH((conv3d_wgrad_ring_kernel<3, 4>), grid, dim3(256), 0, s, p, dout, part, D, H, W, len, NF, xmap);
+  else PNSFM_LAUNCH(conv3d_wgrad_kernel, grid, dim3(256), 0, s, p, dout, part, D, H, W, len, NF);
   int e = check_launch("conv3d_backward_weight");
   if (e) return e;
   PNSFM_LAUNCH(conv3d_wgrad_finish_kernel, dim3(NF * 28), dim3(64), 0, s, (const float*)part, dw3, db3, (int)(grid.x * grid.z),
-               (int)grid.y);
+               (int)grid.y, fpb);
   return check_launch("conv3d_backward_weight_finish");
 }
 

@@ -410,6 +410,29 @@ def test_conv3d_dgrad_column_kernel(emulated_kernels, monkeypatch, shape, run, n
     P.check(ops.conv3d_backward_data(dy, w3), p.grad, 1e-5, 'conv3d dgrad (run %d)' % run)
 
 
+@pytest.mark.parametrize('nf', [8, 4])
+@pytest.mark.parametrize('variant', ['0', '34'])
+@pytest.mark.parametrize('shape', [(1, 40, 2, 3), (2, 13, 3, 70), (1, 5, 4, 6)])
+def test_conv3d_wgrad_variants(emulated_kernels, monkeypatch, shape, variant, nf):
+    """Weight / bias gradient of the 3x3x3 stencil on both builds of the kernel (PNSFM_CONV3D_WGRAD_RING: 0 = round 3's, default =
+    three planes in flight, centre loads + lane exchange, packed register pairs): several runs per column with a ragged last one,
+    rows that end inside a wave, two images."""
+    from oracle import packnet_oracle as O
+    from packnet_sfm.hip import ops
+    monkeypatch.setenv('PNSFM_CONV3D_WGRAD_RING', variant)
+    B, D, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(variant))
+    p = torch.randn(B, D, H, W, generator=g)
+    w3 = (0.3 * torch.randn(nf, 1, 3, 3, 3, generator=g)).requires_grad_(True)
+    b3 = torch.randn(nf, generator=g).requires_grad_(True)
+    yr = O.conv3d_1to8(p, w3, b3)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dw, db = ops.conv3d_backward_weight(p, dy)
+    P.check(dw, w3.grad, 1e-5, 'conv3d wgrad (variant %s)' % variant)
+    P.check(db, b3.grad, 1e-5, 'conv3d dbias (variant %s)' % variant)
+
+
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (1, 19, 4, 70), (1, 64, 3, 5)])
 def test_invdepth_conv_raw(emulated_kernels, shape):
     """Fused InvDepth head (one output channel): ragged channel quarters / channel groups, pixel tails, vs torch."""

@@ -13,7 +13,9 @@
  *   - outputs and named workspaces are caller-allocated.  The ONE exception: the two-stage reductions (pixel-split weight
  *     gradients, the loss scalars) keep their partial sums in a grow-only scratch buffer the library hipMalloc's itself, one per
  *     (device, stream), outside the caller's allocator (csrc/api.hip: a few KB .. tens of MB; a buffer that has to grow is
- *     replaced and the old one freed once the stream has passed it).  Entry points that need this scratch fail with an
+ *     replaced and the old one freed once the stream has passed it).  Worst case per stream: the K-split slabs of the largest
+ *     forward / backward-data launch (splits x output bytes; <= 64 MB on PackNet01's shapes) or, under PNSFM_CONV_MATH=f32, the
+ *     pixel-split [dw | dbias] slabs of a weight gradient, which the library caps at 128 MB per launch.  Entry points that need this scratch fail with an
  *     error while `stream` is being captured into a hipGraph (no capture path since round 4);
  *   - return value: 0 on success, non-zero on error (pnsfm_last_error() has the message).
  */
@@ -144,7 +146,9 @@ int pnsfm_tune_set(const int* key7, int v0, int v1);
  *   by the host exactly as Resample.c precompute_coeffs / normalize_coeffs_8bpc (packnet_sfm/datasets/device_transforms.py).
  * pnsfm_jitter_totensor: per image the <= 4 colour operations in the drawn order, then ToTensor; img NHWC uint8 [N][H][W][3],
  *   ops = N records {int op[4] (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none); float factor[4]; int hue_add
- *   (= uint8(hue_factor*255)); int enabled}, lsum_ws: N x uint64 scratch; out / out_orig (nullable): NCHW float32 [N][3][H][W]. */
+ *   (= uint8(hue_factor*255)); int enabled; float color[3]; int has_color} (56 bytes; color = the diagonal of the 3x4 matrix of
+ *   jittering[4], augmentations.py:266-277, applied last like Image.convert('RGB', matrix)), lsum_ws: N x uint64 scratch;
+ *   out / out_orig (nullable): NCHW float32 [N][3][H][W]. */
 int pnsfm_resample8(const uint8_t* in, uint8_t* out, const int* kk, const int* bounds, int ksize, int N, int inH, int inW,
                     int outH, int outW, int C, int axis, void* stream);
 int pnsfm_jitter_totensor(const uint8_t* img, const void* ops, unsigned long long* lsum_ws, float* out, float* out_orig /*nullable*/,

@@ -108,8 +108,17 @@ def train_transforms(sample, image_shape, jittering, crop_train_borders=()):
     sample['rgb_context_original'] = [k.copy() for k in sample['rgb_context']]
     if len(jittering) > 0 and random.random() < 1.0:
         t = random_color_jitter_transform(jittering[:4])
+        # augmentations.py:266-277: the optional 3x4 'color' matrix, drawn after the jitter transform, applied after it
+        matrix = None
+        if len(jittering) > 4 and jittering[4] > 0:
+            matrix = (random.uniform(1. - jittering[4], 1 + jittering[4]), 0, 0, 0,
+                      0, random.uniform(1. - jittering[4], 1 + jittering[4]), 0, 0,
+                      0, 0, random.uniform(1. - jittering[4], 1 + jittering[4]), 0)
         sample['rgb'] = t(sample['rgb'])
         sample['rgb_context'] = [t(k) for k in sample['rgb_context']]
+        if matrix is not None:
+            sample['rgb'] = sample['rgb'].convert('RGB', matrix)
+            sample['rgb_context'] = [k.convert('RGB', matrix) for k in sample['rgb_context']]
     for key in ('rgb', 'rgb_original'):
         sample[key] = to_tensor(sample[key])
     for key in ('rgb_context', 'rgb_context_original'):

@@ -58,6 +58,8 @@ struct JitterOps {      // per image
   float factor[4];      // blend factor (brightness / contrast / saturation)
   int hue_add;          // uint8(hue_factor * 255), added to H modulo 256
   int enabled;          // 0: this image is not jittered at all (colorjitter_sample's `prob` draw failed)
+  float color[3];       // round 5: diagonal of the 3x4 'color' matrix of jittering[4] (augmentations.py:266-277), applied last through
+  int has_color;        //          PIL's Image.convert('RGB', matrix) arithmetic (Matrix.c): CLIPF((float)((double)(m * in) + 0.5))
 };
 
 __device__ __forceinline__ int lum(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
@@ -123,6 +125,14 @@ __device__ __forceinline__ void apply_ops(const JitterOps& j, int first, int las
   }
 }
 
+// Pillow Matrix.c, RGB -> RGB with a 12-tuple whose off-diagonal entries and offsets are 0 (the only form the reference builds):
+//   float v = m * in + 0 + 0 + 0 + 0.5 (the 0.5 is a double literal: float product, double add, rounded back to float);
+//   out = v <= 0 ? 0 : v >= 255.0F ? 255 : (UINT8)v.     Checked against Pillow 12.2 itself (tests/test_input_pipeline.py).
+__device__ __forceinline__ int color_scale8(int in, float m) {
+  const float v = (float)((double)(m * (float)in) + 0.5);
+  return v <= 0.f ? 0 : (v >= 255.f ? 255 : (int)v);
+}
+
 __device__ __forceinline__ int contrast_pos(const JitterOps& j) {
   for (int s = 0; s < 4; ++s)
     if (j.op[s] == 1) return s;
@@ -170,7 +180,10 @@ __global__ void __launch_bounds__(256) jitter_totensor_kernel(const uint8_t* __r
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     int r = p[3 * i], g = p[3 * i + 1], b = p[3 * i + 2];
     if (oo) { oo[i] = (float)r / 255.f; oo[HW + i] = (float)g / 255.f; oo[2 * HW + i] = (float)b / 255.f; }
-    if (j.enabled) apply_ops(j, 0, 4, mean, r, g, b);
+    if (j.enabled) {
+      apply_ops(j, 0, 4, mean, r, g, b);
+      if (j.has_color) { r = color_scale8(r, j.color[0]); g = color_scale8(g, j.color[1]); b = color_scale8(b, j.color[2]); }
+    }
     o[i] = (float)r / 255.f;
     o[HW + i] = (float)g / 255.f;
     o[2 * HW + i] = (float)b / 255.f;

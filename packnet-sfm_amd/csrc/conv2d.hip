@@ -21,6 +21,7 @@
 #include <cstring>
 #include "../../include/pnsfm.h"
 
+#include <algorithm>
 #include <array>
 #include <dlfcn.h>
 #include <cstdlib>
@@ -1585,7 +1586,13 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
       if (base * split > 64 * slots) break;
     }
   }
+  //  a pixel split keeps `split` whole [dw | dbias] slabs in the stream's grow-only scratch (api.hip), which torch's
+  // allocator cannot see or reuse: 75 MB per slab for the pack5 weight.  Splits are capped so that the slabs of one launch stay under
+  // kWgradScratchBudget (the split-bf16 kernels, the default arithmetic, keep far smaller partial tensors and are not affected).
+  const size_t kWgradScratchBudget = (size_t)128 << 20;
+  const int max_split_f32 = (int)std::max<size_t>(1, kWgradScratchBudget / (((size_t)Cout * N + Cout) * sizeof(float)));
   auto enqueue = [&](int split) -> int {
+    if (split > max_split_f32) split = max_split_f32;
     WgradArgs c = a;
     c.tiles_per_split = ceil_div(a.total_tiles, split);
     c.splitP = ceil_div(a.total_tiles, c.tiles_per_split);
@@ -1649,8 +1656,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
         if (tps == prev_tps) continue;
         prev_tps = tps;
         const int split = ceil_div(a.total_tiles, tps);
-        if (base * split < 192 && split < a.total_tiles) continue;   // cannot fill the chip: not worth timing
-        if (base * split > 40L * 256 && split > 1) break;
+        if (base * split < 192 && split < a.total_tiles && split < max_split_f32) continue;   // cannot fill the chip: not worth timing
+        if ((base * split > 40L * 256 || split > max_split_f32) && split > 1) break;
         const float ms = time_on_stream(s, 2, [&]() { return enqueue(split); });
         tune_log(2, key, 0, split, ms);
         if (ms > 0.f && ms < best_ms) { best_ms = ms; best_split = split; }

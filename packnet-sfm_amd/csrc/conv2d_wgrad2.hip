@@ -292,12 +292,17 @@ int enqueue_wgrad2(const float* x, const float* dy, float* dw, float* dbias, int
   a.tiles_x = W / fc;
   a.tiles_per_img = a.tiles_x * ceil_div(H, 64 / fc);
   a.total_tiles = B * a.tiles_per_img;
+  const size_t N = (size_t)Cin * ks * ks;
+  {
+    // whole [dw | dbias] slabs per split in the grow-only scratch: at most 128 MB of them per launch (see conv2d.hip: wgrad_impl)
+    const size_t max_split = ((size_t)128 << 20) / (((size_t)Cout * N + Cout) * sizeof(float));
+    if (max_split >= 1 && (size_t)split > max_split) split = (int)max_split;
+  }
   if (split < 1) split = 1;
   if (split > a.total_tiles) split = a.total_tiles;
   a.tiles_per_split = ceil_div(a.total_tiles, split);
   a.splitP = ceil_div(a.total_tiles, a.tiles_per_split);
   a.ci_tiles = ceil_div(Cin, 64);
-  const size_t N = (size_t)Cin * ks * ks;
   // pixel-split launch: partial [dw | dbias] slabs in the stream's scratch buffer, added in split order by sum_slabs_kernel
   const size_t slab = (size_t)Cout * N + Cout;
   ScratchLease lease(s, a.splitP > 1 ? (size_t)a.splitP * slab * sizeof(float) : 0);

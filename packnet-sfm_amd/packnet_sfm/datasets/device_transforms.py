@@ -89,9 +89,7 @@ def draw_jitter(parameters, prob=1.0):
     """One sample's colour-jitter decision, consuming Python's RNG exactly like colorjitter_sample +
     random_color_jitter_transform (augmentations.py:254-337) -> packed 40-byte record for the kernel."""
     if not (random.random() < prob):
-        return struct.pack('4i4f2i', -1, -1, -1, -1, 1.0, 1.0, 1.0, 1.0, 0, 0)
-    if len(parameters) > 4 and parameters[4] > 0:
-        raise NotImplementedError("the 3x4 'color' matrix of jittering[4] is not implemented on the device")
+        return ops.jitter_record()
     brightness, contrast, saturation, hue = parameters[:4]
     factors = [random.uniform(max(0, 1 - brightness), 1 + brightness),
                random.uniform(max(0, 1 - contrast), 1 + contrast),
@@ -105,7 +103,12 @@ def draw_jitter(parameters, prob=1.0):
     # torchvision F_pil.adjust_hue: np_h (uint8) += np.uint8(hue_factor * 255), wrapping
     hue_add = int(np.array(hue_factor * 255).astype(np.uint8))
     fac = [np.float32(factors[o]) if o < 3 else np.float32(0.0) for o in order]
-    return struct.pack('4i4f2i', *order, *[float(f) for f in fac], hue_add, 1)
+    # the 3x4 'color' matrix of jittering[4] (augmentations.py:266-270): three more uniform draws AFTER the jitter transform's own,
+    # a per-channel gain applied last with PIL's Image.convert('RGB', matrix) arithmetic (csrc/augment.hip: color_scale8)
+    color = None
+    if len(parameters) > 4 and parameters[4] > 0:
+        color = [random.uniform(1. - parameters[4], 1 + parameters[4]) for _ in range(3)]
+    return ops.jitter_record(order, [float(f) for f in fac], hue_add, 1, color)
 
 
 class DeviceTrainTransform:
@@ -113,7 +116,7 @@ class DeviceTrainTransform:
     Parameters (as `get_transforms('train', ...)` of the reference)
     ----------
     image_shape : (H, W) or ()        output resolution
-    jittering : (brightness, contrast, saturation, hue) or ()
+    jittering : (brightness, contrast, saturation, hue[, color]) or ()
     crop_train_borders : the reference's config value -- (y, height, x, width) or (y, x), negative / float forms included --
                          resolved against every incoming frame size by utils.misc.parse_crop_borders exactly like
                          train_transforms does (datasets/transforms.py:26-29), or ()
@@ -159,7 +162,7 @@ class DeviceTrainTransform:
         if self.jittering:
             recs = [draw_jitter(self.jittering, self.jitter_prob) for _ in range(B)]
         else:
-            recs = [struct.pack('4i4f2i', -1, -1, -1, -1, 1.0, 1.0, 1.0, 1.0, 0, 0)] * B
+            recs = [ops.jitter_record()] * B
         rec_all = b''.join(recs * (1 + len(ctx)))
         records = torch.frombuffer(bytearray(rec_all), dtype=torch.uint8).to(allf.device)
         jit, orig = ops.jitter_totensor(allf, records, want_original=True)

@@ -159,10 +159,13 @@ class _nullctx:
 
 
 class _WgradStream:
-    """Weight gradients on a side HIP stream (PNSFM_WGRAD_STREAM=1; OFF by default since the split-bf16 kernels: with every conv
-    kernel filling the chip on its own, co-scheduling weight- and data-gradient kernels measured 116.6 img/s against 123.8
-    in-line -- the two contend for the same matrix pipes and LDS, and the event traffic costs launches.  It paid with the
-    f32-MFMA kernels of round 1 (+4 %), whose low-resolution layers left CUs idle.)
+    """Weight gradients on a side HIP stream.  ON by default since round 5 (PNSFM_WGRAD_STREAM=0 switches it off): most launches of
+    the backward pass are resident in ONE round of workgroups (tools/bx3_ablate.py: prologue -> matrix work -> store burst, all
+    workgroups in step), so a second stream's kernel fills the ramp-up and the store tail of the first: +1.8 .. +2.2 % images/s in
+    three same-box A/Bs on the atomics-free kernels (profiles/r04_ab_wgrad_side_stream.txt, profiles/r05_ab_streams.txt).  History:
+    +4 % with the f32-MFMA kernels of round 1, a LOSS in round 2 (116.6 vs 123.8 img/s: the zero-fills and atomics of the then
+    split-K / pixel-split kernels doubled the memset and event traffic), off from round 2 to round 4 -- in round 4 only because the
+    bench's per-launch roofline is event-timed as-run; bench.py now prices the kernels in a separate pass with the side streams off.
 
     Within a layer's backward the data gradient is on the critical path (the next layer waits for it) while the weight
     gradient is only needed by the optimizer / the gradient all-reduce.  With a second stream the GPU can co-schedule
@@ -179,7 +182,7 @@ class _WgradStream:
     side stream next to the node's own data gradient, but the compute stream waits for it before the node returns.
     """
     import os as _os
-    _env = _os.environ.get('PNSFM_WGRAD_STREAM', '0')
+    _env = _os.environ.get('PNSFM_WGRAD_STREAM', '1')
     enabled = _env not in ('0', '')
     # PNSFM_WGRAD_STREAM=<n> with n > 1: only layers whose gradient map has at most n pixels (batch x H x W) go to the side stream --
     # the low-resolution layers, whose launches are resident in one round and latency-bound (tools/bx3_ablate.py), overlap well;
@@ -360,11 +363,11 @@ def join_wgrad_stream(device):
 # (a few workgroups each, latency-bound), so models/SfmModel.py enqueues it on a second HIP stream where it fills the launch gaps
 # and tail rounds of the depth network's kernels.  Autograd replays every node on the stream its forward ran on and orders the
 # two streams with events, so the pose network's backward pass overlaps the depth decoder's backward pass the same way.
-# OFF by default (PNSFM_BRANCH_STREAM=1 / set_branch_stream switch it on): measured +0.85 % images/s, but kernels that share the
-# GPU stretch each other, and the bench line's per-kernel roofline is measured as-run (profiles/r04_ab_branch_stream.txt) -- the
-# same trade as PNSFM_WGRAD_STREAM.
+# ON by default since round 5 (PNSFM_BRANCH_STREAM=0 / set_branch_stream(False) switch it off): +0.85 % images/s
+# (profiles/r04_ab_branch_stream.txt), bit-identical results (tests/test_gpu_round4.py::test_branch_stream_is_bit_identical).
+# Kernels that share the GPU stretch each other, so bench.py measures the per-kernel roofline in a pass with both side streams off.
 _BRANCH_STREAMS = {}
-_BRANCH_ON = os.environ.get('PNSFM_BRANCH_STREAM', '0') == '1'
+_BRANCH_ON = os.environ.get('PNSFM_BRANCH_STREAM', '1') == '1'
 
 
 def set_branch_stream(on):
@@ -464,7 +467,9 @@ class Conv2dCatFn(Function):
         want_w = ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1])
 
         def wgrad():
-            if ctx.cat_wgrad:
+            # (the envelope was decided at forward time under the arithmetic mode in force THEN; a set_conv_math('f32') between
+            # forward and backward takes the multi-source kernel away -- ADVICE r04 -- so the mode is re-checked here)
+            if ctx.cat_wgrad and get_conv_math() == 'bx3':
                 return ops.conv2d_backward_weight_cat(xs, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
             # outside the multi-source weight-gradient kernel's envelope (decided once, in conv2d_cat): concatenate for this kernel
             return ops.conv2d_backward_weight(torch.cat(xs, 1), dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
@@ -765,12 +770,20 @@ class PackBorderSplitFn(Function):
         dP = dP.contiguous()        # the interior conv's freshly written backward-data buffer: accumulate in place
         B, h, w = dP.shape[0], dP.shape[2], dP.shape[3]
         # (the row strips and the column strips overlap in the corners: two launches keep every destination single-writer per launch)
+        # (... and when the map is smaller than two strips -- S <= h < 2S -- the leading and the trailing strip overlap too: the
+        # operations of ONE region_ops launch must not share destinations (include/pnsfm.h), so those run as separate launches)
+        def add_pair(a, b, overlap):
+            if overlap:
+                ops.region_ops([a])
+                ops.region_ops([b])
+            else:
+                ops.region_ops([a, b])
         if d_tb is not None:
             d_tb = d_tb.contiguous()
-            ops.region_ops([_R(ops.REGION_ADD, dP[:, :, :S], d_tb[:B]), _R(ops.REGION_ADD, dP[:, :, h - S:], d_tb[B:])])
+            add_pair(_R(ops.REGION_ADD, dP[:, :, :S], d_tb[:B]), _R(ops.REGION_ADD, dP[:, :, h - S:], d_tb[B:]), h < 2 * S)
         if d_lr is not None:
             d_lr = d_lr.contiguous()
-            ops.region_ops([_R(ops.REGION_ADD, dP[:, :, :, :S], d_lr[:B]), _R(ops.REGION_ADD, dP[:, :, :, w - S:], d_lr[B:])])
+            add_pair(_R(ops.REGION_ADD, dP[:, :, :, :S], d_lr[:B]), _R(ops.REGION_ADD, dP[:, :, :, w - S:], d_lr[B:]), w < 2 * S)
         return dP, None
 
 

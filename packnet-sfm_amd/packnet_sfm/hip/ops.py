@@ -641,13 +641,24 @@ def resample8(img, kk, bounds, out_size, axis):
     return out
 
 
+# struct JitterOps of csrc/augment.hip: 4 op codes, 4 blend factors, hue_add, enabled, 3 'color' matrix diagonal entries, has_color
+JITTER_RECORD = '4i4f2i3fi'
+JITTER_RECORD_BYTES = 56
+
+
+def jitter_record(order=(-1, -1, -1, -1), factors=(1.0, 1.0, 1.0, 1.0), hue_add=0, enabled=0, color=None):
+    import struct
+    c = tuple(float(v) for v in color) if color is not None else (1.0, 1.0, 1.0)
+    return struct.pack(JITTER_RECORD, *order, *[float(f) for f in factors], int(hue_add), int(enabled), *c, 1 if color is not None else 0)
+
+
 def jitter_totensor(img, ops_records, want_original=True):
-    """img: uint8 [N,H,W,3]; ops_records: uint8 tensor holding N packed 40-byte JitterOps records -> (jittered, original) float32
+    """img: uint8 [N,H,W,3]; ops_records: uint8 tensor holding N packed 56-byte JitterOps records (JITTER_RECORD) -> (jittered, original) float32
     [N,3,H,W] (original is None unless requested)."""
     _chk(img, ops_records)
     N, H, W, C = img.shape
-    if img.dtype != torch.uint8 or C != 3 or ops_records.dtype != torch.uint8 or ops_records.numel() != 40 * N:
-        raise RuntimeError("jitter_totensor: uint8 [N,H,W,3] image and N 40-byte operation records expected")
+    if img.dtype != torch.uint8 or C != 3 or ops_records.dtype != torch.uint8 or ops_records.numel() != JITTER_RECORD_BYTES * N:
+        raise RuntimeError("jitter_totensor: uint8 [N,H,W,3] image and N %d-byte operation records expected" % JITTER_RECORD_BYTES)
     out = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device)
     orig = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device) if want_original else None
     ws = torch.empty((N,), dtype=torch.int64, device=img.device)

@@ -665,6 +665,21 @@ def _full_size_step(B, H, W, ref_device=DEV):
         assert rel <= 2e-2, 'pose grad %s: relative L2 error %.3e' % (n, rel)
     print('worst per-tensor gradient relative L2 error: %.3e (%s)' % worst)
     assert torch.isfinite(out['loss']).all()
+    # keep the margins of this test visible (copied to profiles/rNN_full_size_parity.json by the GPU session)
+    import json
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        f = os.path.join(out_dir, 'full_size_parity.json')
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            rec = {}
+        rec['%dx%d_b%d_vs_%s' % (H, W, B, 'cpu_oracle' if ref_device == 'cpu' else 'same_device_eager')] = {
+            'loss': float(out['loss']), 'loss_reference': float(ref['loss'].sum()),
+            'depth_abs_rel_mean': abs_rel, 'depth_rel_worst_pixel': worst_rel, 'depth_bound': 1e-3,
+            'worst_per_tensor_grad_rel_l2': worst[0], 'worst_tensor': worst[1], 'grad_bound': 2e-2}
+        with open(f, 'w') as fh:
+            json.dump(rec, fh, indent=1)
     return model, batch, sdd, psdd, kw, abs_rel, worst_rel
 
 

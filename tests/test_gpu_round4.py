@@ -145,3 +145,32 @@ def test_loss_combine_gpu():
 def test_compose_pack_params_gpu():
     """Composed packing convolution: kernel, bias and all four parameter gradients from one node vs the oracle's formula."""
     P.case_compose_pack_params(DEV)
+
+
+@pytest.mark.parametrize('hw', [(8, 26), (6, 14)])
+def test_collapsed_pack_on_maps_smaller_than_two_strips(hw):
+    """ADVICE r04: for S <= h < 2S (S = 2(k//2)+1 packed rows) the leading and the trailing border strip of the collapsed packing
+    block overlap, so their gradient adds into dP must not share a region_ops launch (one launch = single-writer destinations).
+    collapse=True against the reference form (layers01.py:239-247) of the SAME module, forward and every gradient."""
+    from packnet_sfm.networks.layers.packnet.layers01 import PackLayerConv3d
+    torch.manual_seed(3)
+    for k in (3, 5):
+        m = PackLayerConv3d(16, k).to(DEV)
+        x = torch.randn(2, 16, hw[0], hw[1], device=DEV, requires_grad=True)    # packed map: hw / 2 (k=3: S=3, k=5: S=5)
+        if hw[0] // 2 < 2 * (k // 2) + 1:
+            continue
+        res = {}
+        for form in (False, True):
+            m.collapse = form
+            for p in m.parameters():
+                p.grad = None
+            x.grad = None
+            y = m(x)
+            (y * torch.linspace(0.5, 1.5, y.numel(), device=DEV).view_as(y)).sum().backward()
+            res[form] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+        y0, dx0, g0 = res[False]
+        y1, dx1, g1 = res[True]
+        assert float((y0 - y1).abs().max()) <= 1e-4 * float(y0.abs().max())
+        assert float((dx0 - dx1).abs().max()) <= 5e-4 * float(dx0.abs().max()), (k, hw)
+        for n in g0:
+            assert float((g0[n] - g1[n]).abs().max()) <= 5e-4 * float(g0[n].abs().max() + 1e-6), (k, hw, n)

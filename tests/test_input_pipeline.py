@@ -50,6 +50,8 @@ CASES = [  # B, H, W, image_shape, jittering, crop borders, seed
     (1, 41, 70, (16, 32), (0.2, 0.2, 0.2, 0.05), (-36, -4, 0.5, 40), 5),   # negative start / extent, float centre crop
     (1, 41, 70, (), (), (-5, 3), 6),                                # two-value form
     (1, 30, 50, (30, 25), (0.2, 0.2, 0.2, 0.05), (), 4),            # one axis only
+    (2, 37, 124, (19, 64), (0.2, 0.2, 0.2, 0.05, 0.3), (), 7),      # + the 3x4 'color' matrix of jittering[4] (augmentations.py:266-277)
+    (1, 24, 40, (), (0.0, 0.0, 0.0, 0.0, 0.9), (), 8),              # the colour gains alone, large enough to clip at 255
 ]
 
 
@@ -88,7 +90,7 @@ def test_hsv_round_trip_all_colours(emulated_kernels):
     g = np.arange(256, dtype=np.uint8)
     allrgb = np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(1, 4096, 4096, 3)[:, ::1, ::8]   # 2^21 colours on the emulator
     for hue_add in (0, 37):
-        rec = struct.pack('4i4f2i', 3, -1, -1, -1, 0.0, 1.0, 1.0, 1.0, hue_add, 1)
+        rec = ops.jitter_record((3, -1, -1, -1), (0.0, 1.0, 1.0, 1.0), hue_add, 1)
         out, _ = ops.jitter_totensor(torch.from_numpy(np.ascontiguousarray(allrgb)), torch.frombuffer(bytearray(rec), dtype=torch.uint8),
                                      want_original=False)
         h, s, v = Image.fromarray(allrgb[0]).convert('HSV').split()
@@ -105,7 +107,7 @@ def test_hsv_round_trip_all_colours_gpu():
     g = np.arange(256, dtype=np.uint8)
     allrgb = np.ascontiguousarray(np.stack(np.meshgrid(g, g, g, indexing='ij'), -1).reshape(1, 4096, 4096, 3))
     for hue_add in (0, 37, 200):
-        rec = struct.pack('4i4f2i', 3, -1, -1, -1, 0.0, 1.0, 1.0, 1.0, hue_add, 1)
+        rec = ops.jitter_record((3, -1, -1, -1), (0.0, 1.0, 1.0, 1.0), hue_add, 1)
         out, _ = ops.jitter_totensor(torch.from_numpy(allrgb).cuda(), torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda(),
                                      want_original=False)
         h, s, v = Image.fromarray(allrgb[0]).convert('HSV').split()

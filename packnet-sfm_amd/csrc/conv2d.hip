@@ -128,16 +128,37 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.CI = 16;
     g.KP = round_up(Cin, 16);
     g.nchunks = g.KP / 16;
-    g.PB = (DMA == 3 || DMA == 6) ? 1 : 2;
+    g.PB = (DMA == 3 || DMA == 6 || DMA == 7) ? 1 : 2;
     if (DMA == 6 && g.MT * NT > 2) return false;           // three workgroups per CU: <= 168 VGPRs only without the (2,2) tile
     const int KK = ks * ks;
     const size_t plane = (size_t)round_up(g.PH * g.PW * 32, 1024);
     const size_t patch = (size_t)g.PB * 3 * plane;
     // (+ 256 B: the M tile's 64 bias values, staged in the prologue for the epilogue)
-    auto smem_bx3 = [&](int G) -> size_t { return patch + 2 * (size_t)G * g.MT * 3072 + 256; };
+    auto smem_bx3 = [&](int G) -> size_t {
+      // 7 = ping-pong workgroup (conv2d_bx3pp.h): one patch buffer per group, a ring of three weight stages, one workgroup per CU
+      if (DMA == 7) return 2 * patch + 3 * (size_t)G * g.MT * 3072 + 256;
+      return patch + 2 * (size_t)G * g.MT * 3072 + 256;
+    };
     const int cand[6] = {KK <= 9 ? KK : ks, ks, 4, 3, 2, 1};
     g.G = 0;
-    if (DMA == 5) {
+    if (DMA == 7) {
+      // stages of <= 4 taps: the two groups alternate per stage, and a staging half-step (patch split + DMA issue) should not be
+      // much shorter than the compute half-step it hides under; PNSFM_PP_G overrides (lab)
+      // taps per stage: a compute half-step should not be shorter than the staging half-step it hides (patch split + DMA issue +
+      // loads: 1 000 - 2 000 cycles, tools/pp_trace.py) -- 2 300 cycles are 3 taps of the (2,2) tile, 6 of (2,1) / (1,2), 12 of (1,1).
+      // Built for G in {1, 2, 3, 4, 6, 9}; PNSFM_PP_G overrides the first choice (lab).
+      static const int ppG = [] { const char* e = getenv("PNSFM_PP_G"); return e && e[0] ? atoi(e) : 0; }();
+      const int per_tap = g.MT * NT;                     // 6 x this many MFMAs per tap and wave
+      // (the (2,2) tile takes 3: its G = 4 and G = 6 builds spill ~30 VGPRs -- hipcc -Rpass-analysis=kernel-resource-usage -- and are
+      // only reachable through PNSFM_PP_G)
+      const int want = ppG > 0 ? ppG : (per_tap >= 4 ? 3 : (per_tap == 2 ? 6 : 9));
+      const int cpp[6] = {9, 6, 4, 3, 2, 1};
+      for (int i = 0; i < 6 && !g.G; ++i) {
+        if (per_tap >= 4 && ppG <= 0 && (cpp[i] == 4 || cpp[i] == 6)) continue;
+        if (cpp[i] <= want && cpp[i] <= KK && smem_bx3(cpp[i]) <= kMaxSmemPipe) g.G = cpp[i];
+      }
+      if (!g.G) return false;
+    } else if (DMA == 5) {
       if (smem_bx3(cand[0]) <= kMaxSmemPipe) g.G = cand[0];
     } else if (DMA == 6) {
       for (int i = 0; i < 6 && !g.G; ++i)
@@ -442,6 +463,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
 }
 
 #include "conv2d_bx3.h"
+#include "conv2d_bx3pp.h"
 
 // DMA = 0: the halo patch of a channel chunk is staged through registers (8 loads in flight per thread) between two
 //          barriers;
@@ -910,7 +932,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     if (!lease.p) return -1;
     a.ws = lease.as<float>();
   }
-  dim3 grid(B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);
+  dim3 grid(g.DMA == 7 ? ceil_div(B * g.tiles_per_img, 2) : B * g.tiles_per_img, g.MP / (32 * g.MT), g.splitK);   // (7: pairs of pixel tiles)
   a.gx = (int)grid.x; a.gy = (int)grid.y; a.bmap = block_map_mode();
   if (a.bmap == 2 && g.DMA >= 3) {
     // weight-heavy launch (the packed split weights outweigh the input tensor): pixel tile fastest inside an XCD's range (conv2d_bx3.h)
@@ -944,7 +966,39 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
 #else
 #define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
 #endif
-    if (g.DMA == 6) {         // three workgroups per CU (<= 53 KB of LDS each: no opt-in needed)
+    if (g.DMA == 7) {         // ping-pong workgroup: 512 threads, up to 160 KB of LDS, taps per stage a template parameter (conv2d_bx3pp.h)
+#ifndef PNSFM_EMU
+#define PNSFM_PP_ATTR(MTv, NTv, Gv)                                                                                \
+      do {                                                                                                         \
+        static unsigned long long done = 0; /* one bit per device */                                               \
+        if (g.smem_bytes > 64 * 1024 &&                                                                            \
+            ensure_lds_limit(reinterpret_cast<const void*>(&conv2d_bx3pp_kernel<MTv, NTv, Gv>), &done, (int)kMaxSmemPipe, what)) \
+          return -1;                                                                                               \
+      } while (0)
+#else
+#define PNSFM_PP_ATTR(MTv, NTv, Gv) do {} while (0)
+#endif
+#define PNSFM_PP_LAUNCH(MTv, NTv, Gv) do { PNSFM_PP_ATTR(MTv, NTv, Gv); PNSFM_LAUNCH((conv2d_bx3pp_kernel<MTv, NTv, Gv>), grid1, dim3(512), g.smem_bytes, stream, a); } while (0)
+#define PNSFM_PP_G(MTv, NTv)                                                                                       \
+      do {                                                                                                         \
+        if (g.G == 9) PNSFM_PP_LAUNCH(MTv, NTv, 9);                                                                \
+        else if (g.G == 6) PNSFM_PP_LAUNCH(MTv, NTv, 6);                                                           \
+        else if (g.G == 4) PNSFM_PP_LAUNCH(MTv, NTv, 4);                                                           \
+        else if (g.G == 3) PNSFM_PP_LAUNCH(MTv, NTv, 3);                                                           \
+        else if (g.G == 2) PNSFM_PP_LAUNCH(MTv, NTv, 2);                                                           \
+        else PNSFM_PP_LAUNCH(MTv, NTv, 1);                                                                         \
+      } while (0)
+      if (a.playout == 0) { set_error("%s: the ping-pong kernel needs the half-plane patch layout", what); return -1; }
+      if (g.G != 1 && g.G != 2 && g.G != 3 && g.G != 4 && g.G != 6 && g.G != 9) { set_error("%s: the ping-pong kernel is built for 1, 2, 3, 4, 6 or 9 taps per stage", what); return -1; }
+      if (g.MT == 2 && g.NT == 2) PNSFM_PP_G(2, 2);
+      else if (g.MT == 2 && g.NT == 1) PNSFM_PP_G(2, 1);
+      else if (g.MT == 1 && g.NT == 2) PNSFM_PP_G(1, 2);
+      else PNSFM_PP_G(1, 1);
+#undef PNSFM_PP_G
+#undef PNSFM_PP_LAUNCH
+#undef PNSFM_PP_ATTR
+    }
+    else if (g.DMA == 6) {         // three workgroups per CU (<= 53 KB of LDS each: no opt-in needed)
       if (g.MT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<2, 1, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
       else if (g.NT == 2) PNSFM_LAUNCH((conv2d_bx3_kernel<1, 2, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
       else PNSFM_LAUNCH((conv2d_bx3_kernel<1, 1, 3>), grid1, dim3(256), g.smem_bytes, stream, a);
@@ -1040,7 +1094,8 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
       const int nTM = (bx3 && (W % 32 != 0 || ks >= 5)) ? (W % 32 != 0 ? 3 : 2) : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
-      const int nVar = bx3 ? 4 : 3;                       // LDS plans: f32 0..2, split-bf16 3..6 (6 = three workgroups per CU)
+      static const int pp_on = [] { const char* e = getenv("PNSFM_PP"); return (e && e[0] == '0') ? 0 : 1; }();
+      const int nVar = bx3 ? (pp_on ? 5 : 4) : 3;         // LDS plans: f32 0..2, split-bf16 3..7 (6 = three workgroups per CU, 7 = ping-pong workgroup)
       for (int cfgt = 0; cfgt < 2 * nVar * nMT * nTM; ++cfgt) {
         const int cfg = cfgt % (2 * nVar * nMT), tm = cfgt / (2 * nVar * nMT);
         const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % nVar + (bx3 ? 3 : 0), fMT = cfg / (2 * nVar);

@@ -51,6 +51,10 @@ static inline void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned voff, float* lds
 }
 #define PNSFM_UNIFORM(i) (i)
 static inline void pnsfm_dma_wait() {}
+// workgroup barriers with explicit counter waits (conv2d_bx3pp.h): the emulator's barrier is a full one either way
+#define PNSFM_BARRIER_ALL() __syncthreads()
+#define PNSFM_BARRIER_LDS() __syncthreads()
+#define PNSFM_SCHED_FENCE() do {} while (0)
 // buffer resource: loads whose per-lane byte offset is >= `bytes` return 0 (see the device version below)
 struct pnsfm_buf { const char* base; unsigned bytes; };
 static inline pnsfm_buf pnsfm_make_buf(const void* base, unsigned bytes) { return pnsfm_buf{(const char*)base, bytes}; }
@@ -125,6 +129,14 @@ __device__ __forceinline__ void pnsfm_dma16(const pnsfm_dma_buf& b, unsigned vof
 __device__ __forceinline__ void pnsfm_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt 0, expcnt 7, lgkmcnt 15
 // tell the compiler a value is wave-uniform (moves it to an SGPR)
 #define PNSFM_UNIFORM(i) __builtin_amdgcn_readfirstlane(i)
+// Workgroup barriers with EXPLICIT counter waits.  __syncthreads() drains vmcnt(0) -- every global load and LDS-DMA the wave has in
+// flight -- in front of s_barrier; a wave that has just ISSUED loads whose data nobody needs before a later barrier only has to
+// publish its LDS writes: PNSFM_BARRIER_LDS waits lgkmcnt(0) alone.  PNSFM_BARRIER_ALL is the full form (this wave's LDS-DMA has
+// landed too).  The "memory" clobber keeps the compiler from moving LDS / global accesses across the barrier.
+#define PNSFM_BARRIER_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PNSFM_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// nothing is scheduled across this point (hipcc otherwise sinks a batch of LDS reads into the MFMA batch that follows it)
+#define PNSFM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Raw buffer loads (buffer_load_dword v, v_off, s[rsrc], s_off offen): the address is base + s_off + v_off with a
 // wave-uniform base and s_off, so a stencil's 72 neighbour loads need 9 offset VGPRs instead of 72 64-bit pointers, and
 // the hardware range check (v_off + 4 > num_records -> returns 0, no memory access) implements zero padding: invalid

@@ -172,5 +172,6 @@ def test_collapsed_pack_on_maps_smaller_than_two_strips(hw):
         y1, dx1, g1 = res[True]
         assert float((y0 - y1).abs().max()) <= 1e-4 * float(y0.abs().max())
         assert float((dx0 - dx1).abs().max()) <= 5e-4 * float(dx0.abs().max()), (k, hw)
-        for n in g0:
-            assert float((g0[n] - g1[n]).abs().max()) <= 5e-4 * float(g0[n].abs().max() + 1e-6), (k, hw, n)
+        gmax = max(float(v.abs().max()) for v in g0.values())
+        for n in g0:    # (floor: the conv bias in front of the GroupNorm has a mathematically zero gradient -- round-off in both forms)
+            assert float((g0[n] - g1[n]).abs().max()) <= 5e-4 * max(float(g0[n].abs().max()), 1e-2 * gmax), (k, hw, n)

@@ -179,7 +179,8 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     P.check(db, br.grad, 1e-5, 'dbias')
 
 
-@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1), (1, 6, 0, 1), (2, 6, 1, 2)])
+@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1), (1, 6, 0, 1), (2, 6, 1, 2),
+                                 (2, 7, 0, 1), (1, 7, 0, 2), (2, 7, 1, 3), (1, 7, 1, 1)])       # 7: ping-pong workgroup (conv2d_bx3pp.h)
 @pytest.mark.parametrize('shape', [(1, 48, 64, 9, 32, 3), (1, 40, 64, 20, 24, 5), (1, 32, 40, 8, 32, 7)])
 def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     """Configurations the un-tuned heuristics never pick for small test shapes (two pixel tiles per wave, narrow M tiles,
@@ -209,7 +210,8 @@ def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
-@pytest.mark.parametrize('cfg', [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2)])
+@pytest.mark.parametrize('cfg', [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2),
+                                 (1, 7, 0, 1, 1), (2, 7, 1, 2, 1), (2, 7, 0, 1, 2)])
 @pytest.mark.parametrize('shape', [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7),
                                    (1, 16, 32, 18, 64, 7), (1, 32, 16, 10, 32, 5)])
 def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):

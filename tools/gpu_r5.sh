@@ -49,7 +49,8 @@ prof)
   tail -1 $O/r05_bench.log > $O/r05_bench.json; cut -c1-300 $O/r05_bench.json
   timeout 600 python bench.py --height 384 --width 1280 --batch 2 --steps 8 --warmup 2 $BARGS --layer-table $O/r05_conv_layer_table_384x1280.csv > $O/r05_bench_384.log 2>&1
   tail -1 $O/r05_bench_384.log > $O/r05_bench_384x1280.json; cut -c1-200 $O/r05_bench_384x1280.json
-  (cd /tmp && PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r05_rocprof.log 2>&1)
+  # (side streams OFF under the profiler: per-kernel durations of kernels that run alone, like the PMC passes)
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r05_rocprof.log 2>&1)
   f=$(find $O/prof_r05 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r05_bench_kernel_stats.csv && head -12 $f | cut -c1-140
   t=$(find $O/prof_r05 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r05_step_breakdown.txt 2>&1 && head -8 $O/r05_step_breakdown.txt
   rm -rf $O/prof_r05 ;;

@@ -388,6 +388,11 @@ int pnsfm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * size, float4 accesses): hp = float[12] {step, lr, beta1, beta2, eps, weight_decay, grad_scale, 1-beta1, 1-beta2, ...}; the call increments
  * hp[0] and then applies step hp[0].  All four buffers must be 16-byte aligned. */
 int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, void* stream);
+/* The same update on a SLICE of the arenas (16-byte aligned start, n floats): FlatAdam (packnet_sfm/rccl/flat_adam.py) updates a
+ * parameter group bucket by bucket while backward is still producing the gradients of the buckets behind it.  tick != 0: advance
+ * hp[0] (the group's step counter) first -- exactly one slice per group and step does that. */
+int pnsfm_adam_flat_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, int tick,
+                           void* stream);
 
 /* ---- live timing of the dominant kernels (used by bench.py's roofline block) ---------------
  * When enabled, every launch of kind k is bracketed by hipEvents on its own stream.

@@ -1094,7 +1094,9 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       std::array<int, 2> best = {g.NT | (g.DMA << 4), g.splitK};
       const int nMT = (conv_pick_MT(Cout) == 2) ? 2 : 1;
       const int nTM = (bx3 && (W % 32 != 0 || ks >= 5)) ? (W % 32 != 0 ? 3 : 2) : 1;       // tile modes (rectangles / row bands) exist for the split-bf16 kernels
-      static const int pp_on = [] { const char* e = getenv("PNSFM_PP"); return (e && e[0] == '0') ? 0 : 1; }();
+      // PNSFM_PP: which launches may take the ping-pong workgroup (variant 7): bit 0 forward, bit 1 backward-data (default 3: both)
+      static const int pp_mask = [] { const char* e = getenv("PNSFM_PP"); return (e && e[0]) ? atoi(e) : 3; }();
+      const bool pp_on = ((pp_mask >> (kind_tag & 1)) & 1) != 0;
       const int nVar = bx3 ? (pp_on ? 5 : 4) : 3;         // LDS plans: f32 0..2, split-bf16 3..7 (6 = three workgroups per CU, 7 = ping-pong workgroup)
       for (int cfgt = 0; cfgt < 2 * nVar * nMT * nTM; ++cfgt) {
         const int cfg = cfgt % (2 * nVar * nMT), tm = cfgt / (2 * nVar * nMT);

@@ -368,6 +368,20 @@ int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float*
   return check_launch("adam_flat_step");
 }
 
+// A slice of the arenas (round 5: FlatAdam updates bucket by bucket underneath the backward pass).  tick != 0 advances the group's
+// step counter first -- the FIRST slice of a step does that; the others read the same hp[0].
+int pnsfm_adam_flat_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, int tick,
+                           void* stream) {
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) {
+    set_error("adam_flat_update: buffers must be 16-byte aligned");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (tick) PNSFM_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, hp);
+  if (n) PNSFM_LAUNCH(adam_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, (const float*)hp);
+  return check_launch("adam_flat_update");
+}
+
 int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream) {
   if (n_ops < 1 || n_ops > PNSFM_MAX_REGION_OPS) { set_error("region_ops: 1..%d operations per launch (got %d)", PNSFM_MAX_REGION_OPS, n_ops); return -1; }
   RegionOps ops;

@@ -116,38 +116,74 @@ def _register_packed(cache, weight):
     cache._weight_ref = _PACK_REG[cid][1]
 
 
-def repack_all():
-    """Re-pack every registered conv weight whose forward AND backward-data buffers exist, one launch per device.  Returns the
-    number of weights packed.  No-op under PNSFM_PACK_BATCH=0 and while a stream is being captured."""
-    import os
-    if os.environ.get('PNSFM_PACK_BATCH', '1') == '0' or not _PACK_REG:
-        return 0
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        return 0
+def _pack_pairs(only=None, exclude=None):
+    """{device: [(cache, parameter)]} of the registered conv weights whose forward AND backward-data buffers exist; `only` /
+    `exclude`: sets of id(parameter)."""
     by_dev = {}
     for cref, wref in list(_PACK_REG.values()):
         c, w = cref(), wref()
         if c is None or w is None or c.wp_fwd is None or c.wp_bwd is None or c.wp_fwd.device != w.device:
             continue
-        by_dev.setdefault(w.device, []).append((c, w))
-    done = 0
-    for dev, pairs in by_dev.items():
-        # the table's coverage and layout follow from the arithmetic mode too (ADVICE r03: a table built under 'bx3' replayed after
-        # set_conv_math('f32') wrote split-bf16 bytes into f32-layout buffers and stamped them fresh)
-        sig = (get_conv_math(),) + tuple((w.data_ptr(), tuple(w.shape), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
-        tab = _PACK_TABLES.get(dev)
-        if tab is None or tab[0] != sig:
-            table, n, blocks, covered = ops.conv2d_pack_table_build([(w.detach(), c.wp_fwd, c.wp_bwd) for c, w in pairs], dev)
-            tab = _PACK_TABLES[dev] = [sig, table, n, blocks, covered]      # (indices into `pairs`: no strong references kept)
-        if not tab[2]:
+        if (only is not None and id(w) not in only) or (exclude is not None and id(w) in exclude):
             continue
-        with torch.cuda.device(dev) if dev.type == 'cuda' else _nullctx():
-            ops.conv2d_pack_table_run(tab[1], tab[2], tab[3])
-        for i in tab[4]:
-            c, w = pairs[i]
-            c.key_fwd = c.key_bwd = PackedConvWeight.key_of(w)
-        done += len(tab[4])
+        by_dev.setdefault(w.device, []).append((c, w))
+    return by_dev
+
+
+def _run_pack_table(slot, dev, pairs):
+    """One pnsfm_conv2d_pack_table launch over `pairs` on the CURRENT stream; the device table is cached under `slot` and rebuilt
+    when the set of (parameter, buffers) or the arithmetic mode changed.  Returns the pairs the table covers."""
+    # the table's coverage and layout follow from the arithmetic mode too (ADVICE r03: a table built under 'bx3' replayed after
+    # set_conv_math('f32') wrote split-bf16 bytes into f32-layout buffers and stamped them fresh)
+    sig = (get_conv_math(),) + tuple((w.data_ptr(), tuple(w.shape), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
+    tab = _PACK_TABLES.get(slot)
+    if tab is None or tab[0] != sig:
+        table, n, blocks, covered = ops.conv2d_pack_table_build([(w.detach(), c.wp_fwd, c.wp_bwd) for c, w in pairs], dev)
+        tab = _PACK_TABLES[slot] = [sig, table, n, blocks, covered]      # (indices into `pairs`: no strong references kept)
+    if not tab[2]:
+        return []
+    with torch.cuda.device(dev) if dev.type == 'cuda' else _nullctx():
+        ops.conv2d_pack_table_run(tab[1], tab[2], tab[3])
+    return [pairs[i] for i in tab[4]]
+
+
+def _pack_batch_on():
+    import os
+    if os.environ.get('PNSFM_PACK_BATCH', '1') == '0' or not _PACK_REG:
+        return False
+    return not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
+def repack_all(exclude=None):
+    """Re-pack every registered conv weight whose forward AND backward-data buffers exist, one launch per device, and stamp the
+    caches fresh.  `exclude`: ids of parameters already re-packed (repack_subset).  Returns the number of weights packed.  No-op
+    under PNSFM_PACK_BATCH=0 and while a stream is being captured."""
+    if not _pack_batch_on():
+        return 0
+    done = 0
+    for dev, pairs in _pack_pairs(exclude=exclude).items():
+        covered = _run_pack_table((dev, 'all' if not exclude else ('rest', len(exclude))), dev, pairs)
+        stamp_packed(covered)
+        done += len(covered)
     return done
+
+
+def repack_subset(slot, param_ids):
+    """Re-pack the registered conv weights among `param_ids` (ids of parameters) in one launch on the CURRENT stream WITHOUT stamping
+    their caches -- FlatAdam calls this for a bucket it has just updated in the middle of the backward pass, before the optimizer
+    epoch of the step is bumped; it stamps the returned (cache, parameter) pairs in step() (stamp_packed).  `slot`: cache key of
+    the device table (one per bucket)."""
+    if not _pack_batch_on():
+        return []
+    out = []
+    for dev, pairs in _pack_pairs(only=param_ids).items():
+        out += _run_pack_table((dev, slot), dev, pairs)
+    return out
+
+
+def stamp_packed(pairs):
+    for c, w in pairs:
+        c.key_fwd = c.key_bwd = PackedConvWeight.key_of(w)
 
 
 class _nullctx:
@@ -378,6 +414,26 @@ def set_branch_stream(on):
 def branch_stream(t):
     """The second compute stream of t's device, or None (CPU tensors, switched off)."""
     if not (_BRANCH_ON and torch.is_tensor(t) and t.is_cuda):
+        return None
+    st = _BRANCH_STREAMS.get(t.device)
+    if st is None:
+        st = _BRANCH_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
+    return st
+
+
+# Residual shortcuts (networks/layers/packnet/layers01.py: ResidualConv): the 1x1 convolution of the block input runs on the
+# independent-branch stream as well (one extra stream per device serves both uses; the pose network is enqueued behind the whole
+# depth network, so the two never queue behind each other for long).  PNSFM_SHORTCUT_STREAM=0 switches it off.
+_SHORTCUT_ON = os.environ.get('PNSFM_SHORTCUT_STREAM', '0') == '1'
+
+
+def set_shortcut_stream(on):
+    global _SHORTCUT_ON
+    _SHORTCUT_ON = bool(on)
+
+
+def shortcut_stream(t):
+    if not (_SHORTCUT_ON and torch.is_tensor(t) and t.is_cuda and torch.is_grad_enabled()):
         return None
     st = _BRANCH_STREAMS.get(t.device)
     if st is None:

@@ -803,6 +803,13 @@ def adam_flat_step(param, grad, exp_avg, exp_avg_sq, hp):
                                                _stream(param)), "adam_flat_step")
 
 
+def adam_flat_update(param, grad, exp_avg, exp_avg_sq, hp, tick):
+    """adam_flat_step on a slice of the arenas; tick: advance the group's step counter first (one slice per group and step)."""
+    _chk(param, grad, exp_avg, exp_avg_sq, hp); _f32(param, grad, exp_avg, exp_avg_sq, hp)
+    _lib.check(_lib.get().pnsfm_adam_flat_update(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(hp),
+                                                 1 if tick else 0, _stream(param)), "adam_flat_update")
+
+
 # ------------------------------------------------------------------------------- batched region ops
 class _RegionOp(ctypes.Structure):          # mirrors pnsfm_region_op (include/pnsfm.h)
     _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('n', ctypes.c_int * 4), ('src_stride', ctypes.c_longlong * 4),

@@ -78,8 +78,24 @@ class ResidualConv(nn.Module):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x):
-        main = self.conv2(self.conv1(x))
-        shortcut = self.conv3(x)
+        # The 1x1 shortcut depends on the block input only and is launch-latency-sized (240-512 workgroups of a few microseconds:
+        # tools/bx3_ablate.py puts its floor at 9-14 us whatever it computes), so it goes to the second compute stream
+        # (hip/functional.py: shortcut_stream) underneath conv1 -> GroupNorm -> conv2; autograd replays its backward-data and
+        # weight-gradient kernels on the same stream, underneath the main path's.  Same kernels and the same order of operations
+        # within each result: bit-identical to the single-stream form (PNSFM_SHORTCUT_STREAM=0).
+        side = HF.shortcut_stream(x)
+        if side is None:
+            main = self.conv2(self.conv1(x))
+            shortcut = self.conv3(x)
+        else:
+            cur = torch.cuda.current_stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                shortcut = self.conv3(x)
+            x.record_stream(side)
+            main = self.conv2(self.conv1(x))
+            cur.wait_stream(side)
+            shortcut.record_stream(cur)
         return HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
                                 res=shortcut)
 

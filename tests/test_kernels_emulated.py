@@ -654,6 +654,62 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     assert 3e-3 < moved <= 5e-3 * 1.2, moved     # ~lr * m/sqrt(v): the new lr (was 1e-2) took effect
 
 
+def test_flat_adam_update_underneath_backward(emulated_kernels):
+    """Round 5: FlatAdam updates a group bucket by bucket from post-accumulate hooks while backward is still running
+    (rccl/flat_adam.py: _update_chunk) and re-packs the bucket's conv weights right behind it.  Several small buckets, a parameter
+    that gets no gradient on some steps (its bucket is finished by step()), a step() without zero_grad() in front (no early update:
+    the hooks are armed by zero_grad only) -- parameters, moments and the packed weight copies must equal the overlap=False optimizer's
+    bit for bit, and the hooks must have done the work."""
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
+    from packnet_sfm.rccl.flat_adam import FlatAdam
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c = Conv2D(16, 32, 3, 1), Conv2D(32, 32, 3, 1), Conv2D(32, 16, 3, 1)
+            self.side = torch.nn.Linear(4, 4)          # no gradient on odd steps
+
+        def forward(self, x, use_side):
+            y = self.c(self.b(self.a(x))).pow(2).mean()
+            return y + self.side(x[:, 0, :4, :4]).sum() * 1e-3 if use_side else y
+
+    torch.manual_seed(7)
+    nets = [Net(), Net()]
+    nets[1].load_state_dict(nets[0].state_dict())
+    opts = [FlatAdam([{'params': list(nets[0].parameters()), 'lr': 1e-2}], overlap=False),
+            FlatAdam([{'params': list(nets[1].parameters()), 'lr': 1e-2}], overlap=True, bucket_bytes=8 << 10)]
+    assert len(opts[1].param_groups[0]['_chunks']) >= 3
+    x = torch.randn(2, 16, 6, 32)
+    early_total = 0
+    for step in range(5):
+        for net, opt in zip(nets, opts):
+            if step != 3:
+                opt.zero_grad()
+            else:                                       # step 3: gradients dropped by hand -> the hooks stay disarmed
+                for p in net.parameters():
+                    p.grad = None
+            net(x, step % 2 == 0).backward()
+            if opt is opts[1]:
+                done = sum(ch['done'] for ch in opt.param_groups[0]['_chunks'])
+                assert (done > 0) == (step != 3), (step, done)
+                early_total += done
+            opt.step()
+        for (n, pa), pb in zip(nets[0].named_parameters(), nets[1].parameters()):
+            assert torch.equal(pa.detach(), pb.detach()), 'step %d: %s differs between the overlapped and the plain update' % (step, n)
+    for k in ('_m', '_v', '_hp'):
+        assert torch.equal(opts[0].param_groups[0][k], opts[1].param_groups[0][k]), k
+    assert early_total >= 8
+    # the packed copies were refreshed by the early re-pack and stamped in step(): the next forward packs nothing and sees the new weights
+    for net in nets:
+        net.eval()
+    with torch.no_grad():
+        ya, yb = nets[0](x, False), nets[1](x, False)
+    assert torch.equal(ya, yb)
+    for opt in opts:
+        opt._slots.remove()
+
+
 def test_flat_adam_gradient_slots(emulated_kernels):
     """The conv weight-gradient kernel writes straight into FlatAdam's gradient arena (hip.functional.register_grad_slots):
     after backward the parameter's .grad IS the arena view (no gather copy), a parameter used twice falls back to the normal

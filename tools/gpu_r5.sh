@@ -36,6 +36,17 @@ ab_streams)
     PNSFM_WGRAD_STREAM=$v PNSFM_BRANCH_STREAM=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r05_st_$v.log 2>&1
     echo "side streams $v: $(tail -1 $O/r05_st_$v.log | python -c "$SUMMARY")"
   done; done | tee $O/r05_ab_streams.txt ;;
+ab_env)
+  # generic same-box A/B of one environment switch: AB_VAR=NAME (values 0 / 1), alternating, two rounds
+  for i in 1 2; do for v in 0 1; do
+    env $AB_VAR=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r05_abenv_$v.log 2>&1
+    echo "$AB_VAR=$v: $(tail -1 $O/r05_abenv_$v.log | python -c "$SUMMARY")"
+  done; done | tee $O/r05_ab_$AB_VAR.txt ;;
+ab_adam)
+  for i in 1 2; do for v in 0 1; do
+    PNSFM_ADAM_OVERLAP=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r05_ao_$v.log 2>&1
+    echo "adam underneath backward $v: $(tail -1 $O/r05_ao_$v.log | python -c "$SUMMARY")"
+  done; done | tee $O/r05_ab_adam_overlap.txt ;;
 lab)
   timeout 1500 python tools/conv_lab5.py $LAB_ARGS > $O/r05_lab.txt 2> $O/r05_lab.err; tail -70 $O/r05_lab.txt; tail -5 $O/r05_lab.err ;;
 tune)
@@ -50,14 +61,14 @@ prof)
   timeout 600 python bench.py --height 384 --width 1280 --batch 2 --steps 8 --warmup 2 $BARGS --layer-table $O/r05_conv_layer_table_384x1280.csv > $O/r05_bench_384.log 2>&1
   tail -1 $O/r05_bench_384.log > $O/r05_bench_384x1280.json; cut -c1-200 $O/r05_bench_384x1280.json
   # (side streams OFF under the profiler: per-kernel durations of kernels that run alone, like the PMC passes)
-  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r05_rocprof.log 2>&1)
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r05_rocprof.log 2>&1)
   f=$(find $O/prof_r05 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r05_bench_kernel_stats.csv && head -12 $f | cut -c1-140
   t=$(find $O/prof_r05 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r05_step_breakdown.txt 2>&1 && head -8 $O/r05_step_breakdown.txt
   rm -rf $O/prof_r05 ;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)
-    (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r05_$n -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-prof $BARGS > $O/r05_pmc_$n.log 2>&1)
+    (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r05_$n -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-prof $BARGS > $O/r05_pmc_$n.log 2>&1)
     echo "pass $n: $(tail -1 $O/r05_pmc_$n.log | cut -c1-100)"
   done
   python tools/pmc_traffic.py $(find $O/pmc_r05_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_r05_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/r05_traffic.json $O/r05_conv_layer_table.csv 192,640,4 | head -8

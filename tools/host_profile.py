@@ -45,6 +45,10 @@ def main():
     out['loss'].backward(); t2 = time.perf_counter(); opt.step(); t3 = time.perf_counter()
     print('forward %.2f ms, backward %.2f ms, optimizer %.2f ms' % (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)))
     torch.cuda.synchronize()
+    try:    # run backward on the calling thread so that cProfile sees the Python of the backward Functions
+        torch.autograd.set_multithreading_enabled(False)
+    except Exception as e:
+        print('set_multithreading_enabled failed:', e)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(n):
@@ -54,11 +58,11 @@ def main():
     torch.cuda.synchronize()
     s = io.StringIO()
     st = pstats.Stats(pr, stream=s)
-    st.sort_stats('tottime').print_stats(45)
-    print(s.getvalue()[:9000])
+    st.sort_stats('tottime').print_stats(70)
+    print(s.getvalue()[:14000])
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(35)
-    print(s.getvalue()[:7000])
+    pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(60)
+    print(s.getvalue()[:12000])
 
 
 if __name__ == '__main__':

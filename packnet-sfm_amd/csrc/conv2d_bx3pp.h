@@ -304,8 +304,11 @@ __global__ void __launch_bounds__(512) conv2d_bx3pp_kernel(ConvArgs a) {
       // the 6 MT NT MFMAs of tap j (scheduling barriers keep hipcc from sinking them into the MFMA batch, where every MFMA would
       // wait for a read issued one instruction earlier) and have landed when that batch has been issued.  A chunk's ragged last
       // stage (KK % G taps; 1 of 13 stages of a 7x7 at G = 4) runs the same code: the slabs of its missing taps were fetched with
-      // out-of-range offsets, i.e. ZERO-filled by the LDS-DMA (issue_weights_half), so their MFMAs add nothing.  (One code path
-      // keeps the accumulators in place: a second, generic loop cost 32 v_mov_b64 per stage at the merge.)
+      // out-of-range offsets, i.e. ZERO-filled by the LDS-DMA (issue_weights_half), so their MFMAs add nothing: 2 of the 51 tap slots
+      // of a 7x7 chunk at G = 3.  (ONE code path keeps the accumulators in place.  Measured alternatives, ISA checked: a second arm for
+      // the ragged stage -- a generic loop, or a static one-tap block -- costs 32 v_mov_b64 of accumulator shuffling per stage at the
+      // merge, plus spills in the (2,2) tile; uniform branches around the leading taps of one block make hipcc guard every fragment
+      // read with a wait for the previous one, a ~250-cycle hole per tap.)
       // The barrier that ends this half-step sits IN FRONT of the last tap's MFMAs: that tap's fragments are in registers by then
       // (read underneath the previous tap's batch), so behind the barrier this wave issues 6 MT NT MFMAs that touch no LDS while the
       // partner -- released one MFMA batch early -- waits for its DMA, reads its first fragments and queues its own MFMAs behind

@@ -58,6 +58,16 @@ int pnsfm_conv2d_pack_item_fill(void* item_host, const float* w, float* wp_fwd, 
 int pnsfm_conv2d_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream);
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias /*nullable*/, float* y,
                          int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* Forward convolution that also leaves the GroupNorm statistics of its OUTPUT behind (round 5; replaces nn.Conv2d + the first pass
+ * of nn.GroupNorm in Conv2D, layers01.py:28-37): the epilogue of the conv kernel writes, per (sample, group), *nslot partial {sum, sum
+ * of squares} pairs (doubles, [(b G + g)][slot][2]) into stats_ws[pnsfm_conv2d_gn_ws_doubles(B, G, H, W)], which
+ * pnsfm_groupnorm_act_apply consumes -- the layer needs no statistics pass over y.  Inputs as pnsfm_conv2d_forward_cat (x1 / x2 may be
+ * null with C1 = C2 = 0: a single tensor).  *nslot == 0 on return: this launch could not produce them (a K-split configuration, or
+ * Cout / G not in {4, 8, 16, 32}); call pnsfm_groupnorm_act_forward instead. */
+size_t pnsfm_conv2d_gn_ws_doubles(int B, int G, int H, int W);
+int pnsfm_conv2d_forward_gn(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* wp_fwd,
+                            const float* bias, float* y, double* stats_ws, int G, int* nslot, int B, int Cout, int H, int W, int ks,
+                            void* stream);
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
                                int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 /* dw in the reference layout [Cout][Cin][k][k]; dbias [Cout] (nullable). Both are overwritten.  When the autotuner
@@ -177,6 +187,10 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res /*nullable*/, c
                                 const float* beta, float* y, float* mean, float* rstd, double* stats_ws,
                                 int B, int C, int HW, int G, float eps, int act, void* stream);
 /* red_ws: double[pnsfm_groupnorm_ws_doubles(B, C, G)] scratch. dx is the gradient w.r.t. x (and, identically, w.r.t. res). */
+/* The normalisation + activation pass alone, on statistics a convolution left behind (pnsfm_conv2d_forward_gn): stats
+ * [(b G + g)][nslot][2] doubles; mean / rstd [B*G] are written for the backward pass as pnsfm_groupnorm_act_forward does. */
+int pnsfm_groupnorm_act_apply(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              const double* stats, int nslot, int B, int C, int HW, int G, float eps, int act, void* stream);
 int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* res /*nullable*/,
                                  const float* gamma, const float* beta, const float* mean, const float* rstd,
                                  float* dx, float* dgamma, float* dbeta, double* red_ws,

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  if (!PNSFM_AB(32) || acc[0][0][0] == 1.2345f) conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz, lds_bias);
+  if (!PNSFM_AB(32) || acc[0][0][0] == 1.2345f) conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz, lds_bias, t, wave);
 #undef PNSFM_AB
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {

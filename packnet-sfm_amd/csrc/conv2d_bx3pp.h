@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(512) conv2d_bx3pp_kernel(ConvArgs a) {
 #ifdef PNSFM_PIPE_TRACE
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz, lds_bias);
+  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)bz, lds_bias, tvalid ? t : -1, wave);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();

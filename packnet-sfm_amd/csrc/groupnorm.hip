@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const double* __restrict__ stats, float* __restrict__ mean_out,
                                                         float* __restrict__ rstd_out, float* __restrict__ y, int BC, int C, int HW,
-                                                        int G, int act, double n, float eps, GnGeom g) {
+                                                        int G, int act, double n, float eps, GnGeom g, int nslot) {
   __shared__ double red[4];
   const int tid = threadIdx.x;
   const int r = tid / g.T, l = tid - r * g.T;
@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   const int cpg = C / G;
   const int b = bc / C, c = bc - b * C;
   const int gi = c / cpg;
-  const int nslot = cpg * g.nchunk;
+  // (nslot: partial {sum, sumsq} pairs per (sample, group) -- cpg * nchunk from gn_stats_kernel, or whatever the producing conv
+  // kernel's epilogue wrote: pnsfm_conv2d_forward_gn)
   const double* sp = stats + (size_t)(b * G + gi) * nslot * 2;
   double t1 = 0.0, t2 = 0.0;
   for (int k = l; k < nslot; k += g.T) { t1 += sp[2 * k]; t2 += sp[2 * k + 1]; }
@@ -341,8 +342,25 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
   int e = check_launch("gn_stats");
   if (e) return e;
   const double n = (double)cpg * (double)HW;
-  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g);
-  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g);
+  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g, cpg * g.nchunk);
+  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g, cpg * g.nchunk);
+  return check_launch("gn_apply");
+}
+
+// Second half of the forward pass alone: the statistics were left behind by the producing convolution (pnsfm_conv2d_forward_gn:
+// stats[(b G + g)][nslot][2] doubles).  One launch per layer instead of two, and y is read once instead of twice.
+int pnsfm_groupnorm_act_apply(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              const double* stats, int nslot, int B, int C, int HW, int G, float eps, int act, void* stream) {
+  if (C % G != 0 || B <= 0 || HW <= 0 || nslot <= 0) { set_error("groupnorm_apply: bad shape C=%d G=%d nslot=%d", C, G, nslot); return -1; }
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (HW % 4 == 0);
+  const int BC = B * C;
+  const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
+  dim3 grid(ceil_div(BC, g.rows), g.nchunk);
+  const double n = (double)(C / G) * (double)HW;
+  const float* res = nullptr;
+  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, stats, mean, rstd, y, BC, C, HW, G, act, n, eps, g, nslot);
+  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, stats, mean, rstd, y, BC, C, HW, G, act, n, eps, g, nslot);
   return check_launch("gn_apply");
 }
 

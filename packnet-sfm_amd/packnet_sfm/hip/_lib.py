@@ -30,6 +30,8 @@ SIGNATURES = {
     "pnsfm_conv2d_pack_item_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
     "pnsfm_conv2d_pack_table": (_i, [_p, _i, _i, _p]),
     "pnsfm_conv2d_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_conv2d_gn_ws_doubles": (_sz, [_i, _i, _i, _i]),
+    "pnsfm_conv2d_forward_gn": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_forward_cat": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -39,6 +41,7 @@ SIGNATURES = {
     "pnsfm_conv2d_backward_weight_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_groupnorm_ws_doubles": (_sz, [_i, _i, _i]),
     "pnsfm_groupnorm_act_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "pnsfm_groupnorm_act_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_space_to_depth": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_space_to_depth_strided": (_i, [_p, _p, _i, _i, _i, _i, _sz, _p]),

@@ -570,6 +570,115 @@ def conv2d_cat(xs, weight, bias, cache):
     return Conv2dCatFn.apply(weight, bias, cache, torch.is_grad_enabled(), _cat_wgrad_ok(xs, weight), *xs)
 
 
+class ConvGnActFn(Function):
+    """act(GroupNorm_G(conv2d(zero_pad(cat(xs, 1)), weight) + bias)) as ONE autograd node (round 5): the reference's Conv2D block
+    (layers01.py:28-37).  xs: 1..3 tensors (the decoder's concatenations stay folded into the K loop).  One node instead of two halves
+    the autograd / Python overhead of the block (profiles/r05_host_profile.txt: ~35 us per Function.apply, the host needs 16-18 ms
+    to enqueue a 24 ms step).
+    PNSFM_CONV_GN_STATS=1 (off by default): the conv kernel's epilogue also leaves the GroupNorm statistics of its output behind
+    (ops.conv2d_forward_gn) and the block runs two launches instead of three.  Built, parity-tested and measured NEUTRAL to slightly
+    negative (profiles/r05_ab_conv_gn_stats.txt: 164.6 / 165.4 vs 164.5 / 165.4 img/s at 192x640, 48.9 vs 48.7 at 384x1280): the
+    statistics kernel it removes re-reads y at the HBM roof (0.25 ms per step over the ~32 layers that qualify), but per-(tile, wave)
+    partials are 1 920 - 7 680 slots per (sample, group) on the full-resolution maps, which every row of gn_apply adds up again
+    (gn_stats hands it <= 256), and the epilogue's shuffle tree costs the conv kernels 0.8 %."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, gamma, beta, cache, recording, cat_wgrad, G, eps, act, *xs):
+        xs = tuple(t.contiguous() for t in xs)
+        ctx.cat_wgrad = cat_wgrad
+        need_dx = any(ctx.needs_input_grad[10:])
+        wp_fwd, wp_bwd = cache.get(weight, need_dx)
+        Cout, Cin, ks, _ = weight.shape
+        if sum(t.shape[1] for t in xs) != Cin:
+            raise RuntimeError("conv_gn_act: inputs have %d channels, weight expects %d" % (sum(t.shape[1] for t in xs), Cin))
+        bias_d = bias.detach() if bias is not None else None
+        if _CONV_GN_STATS:
+            y, ws, nslot = ops.conv2d_forward_gn(xs, wp_fwd, bias_d, Cout, ks, G)
+        else:
+            y = ops.conv2d_forward(xs[0], wp_fwd, bias_d, Cout, ks) if len(xs) == 1 else ops.conv2d_forward_cat(xs, wp_fwd, bias_d, Cout, ks)
+            ws, nslot = None, 0
+        if nslot > 0:
+            out, mean, rstd = ops.groupnorm_act_apply(y, gamma.detach(), beta.detach(), ws, nslot, G, eps, act)
+        else:
+            out, mean, rstd = ops.groupnorm_act_forward(y, None, gamma.detach(), beta.detach(), G, eps, act)
+        ctx.save_for_backward(wp_bwd if wp_bwd is not None else y.new_empty(0), y, gamma, beta, mean, rstd, *xs)
+        ctx.meta = (Cin, Cout, ks, bias is not None, G, act)
+        ctx.params = (weight, bias)
+        _WgradStream.note_use(recording, weight, bias)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        wp_bwd, y, gamma, beta, mean, rstd, *xs = ctx.saved_tensors
+        Cin, Cout, ks, has_bias, G, act = ctx.meta
+        dy, dgamma, dbeta = ops.groupnorm_act_backward(dout.contiguous(), y, None, gamma.detach(), beta.detach(), mean, rstd, G, act)
+        dxs = [None] * len(xs)
+        dw = db = None
+        detached = _WgradStream.side_ok(*ctx.params)
+        sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[0])
+        want_w = ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1])
+
+        def wgrad():
+            if len(xs) == 1:
+                return ops.conv2d_backward_weight(xs[0], dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+            if ctx.cat_wgrad and get_conv_math() == 'bx3':
+                return ops.conv2d_backward_weight_cat(xs, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+            return ops.conv2d_backward_weight(torch.cat(xs, 1), dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
+
+        wait = None
+        if want_w and _WgradStream.use_for(dy):
+            r = _WgradStream.run(wgrad, dy, *xs, detached=detached)
+            (dw, db), wait = (r, None) if detached else r
+            want_w = False
+        if any(ctx.needs_input_grad[10:]):
+            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
+            if len(xs) == 1:
+                dxs[0] = dx
+            else:
+                c0 = 0
+                for i, t in enumerate(xs):
+                    if ctx.needs_input_grad[10 + i]:
+                        dxs[i] = dx[:, c0:c0 + t.shape[1]]
+                    c0 += t.shape[1]
+        if want_w:
+            dw, db = wgrad()
+        if wait is not None:
+            wait()
+        return (dw, db, dgamma, dbeta, None, None, None, None, None, None) + tuple(dxs)
+
+
+_CONV_GN_FUSE = os.environ.get('PNSFM_CONV_GN_FUSE', '1') != '0'
+_CONV_GN_STATS = os.environ.get('PNSFM_CONV_GN_STATS', '0') == '1'
+
+
+def set_conv_gn_stats(on):
+    global _CONV_GN_STATS
+    _CONV_GN_STATS = bool(on)
+
+
+
+def set_conv_gn_fuse(on):
+    global _CONV_GN_FUSE
+    _CONV_GN_FUSE = bool(on)
+
+
+def conv2d_gn_act(x, weight, bias, gamma, beta, cache, G=16, eps=1e-5, act=ops.ACT_ELU):
+    """The Conv2D block: x a tensor or a tuple of 2-3 tensors standing for their channel concatenation."""
+    xs = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+    if len(xs) > 1:
+        C0 = xs[0].shape[1]
+        fold = os.environ.get('PNSFM_CAT_FOLD', '1') != '0' and len(xs) in (2, 3) and C0 % 16 == 0 and \
+            (len(xs) == 2 or (C0 + xs[1].shape[1]) % 16 == 0) and get_conv_math() == 'bx3' and sum(t.shape[1] for t in xs) >= 16
+        if not fold:
+            xs = (torch.cat(xs, 1),)
+    if not _CONV_GN_FUSE:
+        y = conv2d(xs[0], weight, bias, cache) if len(xs) == 1 else conv2d_cat(xs, weight, bias, cache)
+        return groupnorm_act(y, gamma, beta, G, eps, act)
+    cat_wgrad = _cat_wgrad_ok(xs, weight) if len(xs) > 1 else False
+    return ConvGnActFn.apply(weight, bias, gamma, beta, cache, torch.is_grad_enabled(), cat_wgrad, G, eps, act, *xs)
+
+
 class Conv2dStride2Fn(Function):
     """Stride-2 conv with zero padding k//2 (PoseNet).  Forward and weight-gradient run the strided MFMA kernels; the
     data-gradient is the stride-1 backward-data kernel on dy zero-upsampled onto the input grid."""

@@ -164,6 +164,30 @@ def conv2d_forward_cat(xs, wp_fwd, bias, Cout, ks):
     return y
 
 
+_CONV_GN_WS = {}
+
+
+def conv2d_forward_gn(xs, wp_fwd, bias, Cout, ks, G):
+    """conv(cat(xs, 1)) (xs: 1..3 NCHW tensors) whose epilogue also leaves the GroupNorm(G) statistics of y behind.  Returns
+    (y, stats workspace, nslot); nslot == 0: the launch could not produce them (K split / unsupported channels per group) and the
+    caller runs groupnorm_act_forward."""
+    _chk(*xs, wp_fwd, bias); _f32(*xs, wp_fwd, bias)
+    B, _, H, W = xs[0].shape
+    C = [t.shape[1] for t in xs] + [0] * (3 - len(xs))
+    lib = _lib.get()
+    key = (B, G, H, W)
+    n = _CONV_GN_WS.get(key)
+    if n is None:
+        n = _CONV_GN_WS[key] = int(lib.pnsfm_conv2d_gn_ws_doubles(B, G, H, W))
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xs[0].device)
+    ws = torch.empty((n,), dtype=torch.float64, device=xs[0].device)
+    nslot = ctypes.c_int(0)
+    rc = lib.pnsfm_conv2d_forward_gn(_ptr(xs[0]), C[0], _ptr(xs[1] if len(xs) > 1 else None), C[1], _ptr(xs[2] if len(xs) > 2 else None), C[2],
+                                     _ptr(wp_fwd), _ptr(bias), _ptr(y), _ptr(ws), G, ctypes.byref(nslot), B, Cout, H, W, ks, _stream(xs[0]))
+    _lib.check(rc, "conv2d_forward_gn")
+    return y, ws, int(nslot.value)
+
+
 def conv2d_cat_wgrad_supported(channels, Cout, H, W, ks, B=1):
     """Will conv2d_backward_weight_cat take sources with these channel counts (list of 2 or 3)?  Pure query."""
     C = list(channels) + [0] * (3 - len(channels))
@@ -238,6 +262,20 @@ def groupnorm_act_forward(x, res, gamma, beta, G, eps, act):
     rc = _lib.get().pnsfm_groupnorm_act_forward(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
                                                 _ptr(ws), B, C, HW, G, float(eps), act, _stream(x))
     _lib.check(rc, "groupnorm_act_forward")
+    return y, mean, rstd
+
+
+def groupnorm_act_apply(x, gamma, beta, stats, nslot, G, eps, act):
+    """act(GroupNorm_G(x)) from statistics a convolution left behind (conv2d_forward_gn): one launch, x read once."""
+    _chk(x, gamma, beta, stats); _f32(x, gamma, beta)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    ms = torch.empty((2, B * G), dtype=torch.float32, device=x.device)
+    mean, rstd = ms[0], ms[1]
+    rc = _lib.get().pnsfm_groupnorm_act_apply(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(stats), nslot,
+                                              B, C, HW, G, float(eps), act, _stream(x))
+    _lib.check(rc, "groupnorm_act_apply")
     return y, mean, rstd
 
 

@@ -47,8 +47,9 @@ class Conv2D(nn.Module):
         self.normalize = nn.GroupNorm(16, out_channels)
 
     def forward(self, x):
-        y = self.conv_base(x)
-        return HF.groupnorm_act(y, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU)
+        base, norm = self.conv_base, self.normalize
+        # one autograd node and two launches: the conv kernel's epilogue leaves the GroupNorm statistics behind (HF.ConvGnActFn)
+        return HF.conv2d_gn_act(x, base.weight, base.bias, norm.weight, norm.bias, base._packed, 16, norm.eps, _ops.ACT_ELU)
 
 
 class ResidualConv(nn.Module):

@@ -654,6 +654,63 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     assert 3e-3 < moved <= 5e-3 * 1.2, moved     # ~lr * m/sqrt(v): the new lr (was 1e-2) took effect
 
 
+@pytest.mark.parametrize('variant', [3, 6, 7, 0])
+@pytest.mark.parametrize('shape', [(2, 32, 64, 9, 32, 3), (1, 16, 128, 6, 20, 3), (2, 48, 256, 5, 24, 3), (1, 32, 512, 4, 32, 1),
+                                   (2, 20, 64, 7, 40, 5)])
+def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
+    """Round 5: the Conv2D block as one autograd node whose conv epilogue leaves the GroupNorm statistics behind
+    (hip.functional.ConvGnActFn, csrc/conv2d.hip: conv_epilogue, pnsfm_groupnorm_act_apply) against the two-node form (conv, then
+    statistics + apply) and against torch: output and every gradient.  Channels per group 4 / 8 / 16 / 32 (the four lane layouts of the
+    epilogue reduction), ragged tiles, the ping-pong kernel (7), three workgroups per CU (6), the f32 kernels (0)."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, functional as HF, ops
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    bx3 = variant >= 3 and Cin >= 16
+    lib.pnsfm_set_conv_math(1 if variant >= 3 else 0)
+    lib.pnsfm_set_conv_variant(variant if variant < 7 else 3)
+    if variant == 7 and bx3:
+        for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+            key = (ctypes.c_int * 7)(kind + 10 + 100, B, K, M, H, W, ks)
+            assert lib.pnsfm_tune_set(key, 1 | (7 << 4), 1) == 0
+    g = torch.Generator().manual_seed(sum(shape) + variant)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    dout = torch.randn(B, Cout, H, W, generator=g)
+    res = {}
+    HF.set_conv_gn_stats(True)          # (off by default: measured neutral; the kernels stay covered here)
+    for fused in (True, False):
+        HF.set_conv_gn_fuse(fused)
+        leaves = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+        out = HF.conv2d_gn_act(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], HF.PackedConvWeight(), 16, 1e-5, ops.ACT_ELU)
+        out.backward(dout)
+        res[fused] = [out.detach()] + [t.grad for t in leaves]
+    HF.set_conv_gn_fuse(True)
+    ref = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    o = F.elu(F.group_norm(F.conv2d(ref[0], ref[1], ref[2], padding=ks // 2), 16, ref[3], ref[4], 1e-5))
+    o.backward(dout)
+    names = ('out', 'dx', 'dw', 'db', 'dgamma', 'dbeta')
+    for n, a, c, r in zip(names, res[True], res[False], [o.detach()] + [t.grad for t in ref]):
+        # (the conv bias in front of a GroupNorm has a mathematically zero gradient: round-off in every implementation)
+        if n == 'db':
+            continue
+        P.check(a, c, 2e-5, n + ' fused vs two nodes')
+        P.check(a, r, 1e-4, n + ' vs torch')
+    # the epilogue statistics themselves: produced (these shapes do not split K), and equal to the sums over y per (sample, group)
+    wf, _ = ops.conv2d_pack(w, want_bwd=False)
+    y, ws, nslot = ops.conv2d_forward_gn((x,), wf, b, Cout, ks, 16)
+    assert nslot > 0 and nslot % 4 == 0
+    st = ws[:B * 16 * nslot * 2].view(B, 16, nslot, 2).sum(2)
+    yg = y.double().view(B, 16, -1)
+    P.check(st[..., 0], yg.sum(2), 1e-5, 'epilogue sum', floor=1e-3 * float(yg.abs().sum(2).max()))
+    P.check(st[..., 1], (yg * yg).sum(2), 1e-5, 'epilogue sum of squares')
+    HF.set_conv_gn_stats(False)
+    lib.pnsfm_set_conv_variant(0)
+
+
 def test_flat_adam_update_underneath_backward(emulated_kernels):
     """Round 5: FlatAdam updates a group bucket by bucket from post-accumulate hooks while backward is still running
     (rccl/flat_adam.py: _update_chunk) and re-packs the bucket's conv weights right behind it.  Several small buckets, a parameter

@@ -412,6 +412,10 @@ int pnsfm_adam_flat_update(float* param, const float* grad, float* exp_avg, floa
  * When enabled, every launch of kind k is bracketed by hipEvents on its own stream.
  * kinds: 0 = conv2d forward/backward-data MFMA kernel, 1 = conv2d backward-weight MFMA kernel.
  * collect() synchronises the recorded events and returns totals since the last reset. */
+/* Stream fork / join: nothing enqueued on `waiter` after this call runs before everything enqueued on `signaler` so far has finished
+ * (hipEventRecord + hipStreamWaitEvent on a library-owned, timing-less event).  Host plumbing for the weight-gradient side stream of
+ * packnet_sfm/hip/functional.py (replaces the all-reduce-overlap role of horovod's background thread, trainers/horovod_trainer.py). */
+int pnsfm_stream_wait_stream(void* waiter, void* signaler);
 int pnsfm_prof_enable(int on);
 int pnsfm_prof_reset(void);
 int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long long* launches);

@@ -191,6 +191,40 @@ const char* pnsfm_build_target(void) {
 #endif
 }
 
+// Stream fork / join without Python stream objects (round 5): `waiter` will not run anything enqueued after this call before everything
+// enqueued on `signaler` so far has finished.  One event record + one stream wait from a per-device ring of timing-less events (an
+// event may be re-recorded while an earlier wait on it is still pending: a wait captures the record that precedes it).  The weight
+// gradients' side stream forks and joins ~75 times per training step; torch's Stream.wait_stream + the stream context manager cost
+// the host ~50 us per fork (profiles/r05_host_profile.txt), this call ~3.
+int pnsfm_stream_wait_stream(void* waiter, void* signaler) {
+#ifdef PNSFM_EMU
+  (void)waiter; (void)signaler;
+  return 0;
+#else
+  if (waiter == signaler) return 0;
+  static std::mutex mu;
+  static std::vector<std::vector<hipEvent_t>> ring(64);
+  static int next[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { pnsfm::set_error("stream_wait_stream: hipGetDevice failed"); return -1; }
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto& r = ring[dev];
+    if (r.size() < 256) {
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipEventCreate failed"); return -1; }
+      r.push_back(ev);
+    } else {
+      ev = r[next[dev]];
+      next[dev] = (next[dev] + 1) % 256;
+    }
+  }
+  if (hipEventRecord(ev, (hipStream_t)signaler) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipEventRecord failed"); return -1; }
+  if (hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipStreamWaitEvent failed"); return -1; }
+  return 0;
+#endif
+}
+
 int pnsfm_prof_enable(int on) {
 #ifndef PNSFM_EMU
   std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);

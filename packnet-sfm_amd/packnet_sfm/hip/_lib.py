@@ -86,6 +86,7 @@ SIGNATURES = {
     "pnsfm_adam_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _f, _i, _p]),
     "pnsfm_adam_flat_step": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "pnsfm_adam_flat_update": (_i, [_p, _p, _p, _p, _sz, _p, _i, _p]),
+    "pnsfm_stream_wait_stream": (_i, [_p, _p]),
     "pnsfm_resample8": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_jitter_totensor": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_nrs_project_forward": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),

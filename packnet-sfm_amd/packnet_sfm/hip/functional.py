@@ -289,12 +289,28 @@ class _WgradStream:
         return st
 
     @classmethod
-    def run(cls, fn, *tensors, detached=True):
+    def run(cls, fn, *tensors, detached=True, pure=True):
         """fn() -> outputs, executed on the side stream of tensors[0].device.  detached: nothing on the compute stream
         will touch the outputs before the end-of-backward join; otherwise returns (outputs, wait) and the caller must
-        call wait() on the compute stream after it has enqueued its own independent work."""
+        call wait() on the compute stream after it has enqueued its own independent work.
+        pure (round 5): fn calls nothing but ops.* launches -- the fork is one C call (ops.stream_wait_stream) and the launches are
+        redirected with ops.stream_override instead of torch's Stream.wait_stream + stream context (~50 -> ~10 us of host time per
+        weight gradient, ~75 of them per step).  Outputs are then allocated in the COMPUTE stream's pool: they are gradients that live
+        until the optimizer has run, long after the end-of-backward join, so the allocator cannot hand their memory out early."""
         dev = tensors[0].device
-        side, main = cls.get(dev), torch.cuda.current_stream(dev)
+        side = cls.get(dev)
+        if pure and _FAST_FORK:
+            main_raw, side_raw = ops.current_raw_stream(dev), side.cuda_stream
+            ops.stream_wait_stream(side_raw, main_raw)
+            with ops.stream_override(side_raw):
+                out = fn()
+            for t in tensors:
+                t.record_stream(side)       # inputs live in the compute stream's pool but are read here
+            if not detached:
+                return out, (lambda: ops.stream_wait_stream(main_raw, side_raw))
+            cls._pending.add(dev)
+            return out
+        main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             out = fn()
@@ -322,6 +338,9 @@ class _WgradStream:
         for dev in list(cls._pending):
             torch.cuda.current_stream(dev).wait_stream(cls.get(dev))
         cls._pending.clear()
+
+
+_FAST_FORK = os.environ.get('PNSFM_FAST_FORK', '1') != '0'
 
 
 def set_wgrad_stream(on):
@@ -532,7 +551,8 @@ class Conv2dCatFn(Function):
 
         wait = None
         if want_w and _WgradStream.use_for(dy):
-            r = _WgradStream.run(wgrad, dy, *xs, detached=detached)
+            # (pure: the closure launches kernels only -- the concatenating fallback calls torch.cat and takes the stream-context path)
+            r = _WgradStream.run(wgrad, dy, *xs, detached=detached, pure=(len(xs) == 1 or (ctx.cat_wgrad and get_conv_math() == 'bx3')))
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if any(ctx.needs_input_grad[5:]):
@@ -628,7 +648,8 @@ class ConvGnActFn(Function):
 
         wait = None
         if want_w and _WgradStream.use_for(dy):
-            r = _WgradStream.run(wgrad, dy, *xs, detached=detached)
+            # (pure: the closure launches kernels only -- the concatenating fallback calls torch.cat and takes the stream-context path)
+            r = _WgradStream.run(wgrad, dy, *xs, detached=detached, pure=(len(xs) == 1 or (ctx.cat_wgrad and get_conv_math() == 'bx3')))
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if any(ctx.needs_input_grad[10:]):

@@ -16,11 +16,45 @@ except AttributeError:                                      # pragma: no cover
     _raw_stream = None
 
 
+_STREAM_OVERRIDE = [None]      # a raw hipStream_t (int): every launch goes there instead of torch's current stream (stream_override)
+
+
+class stream_override:
+    """`with stream_override(raw_handle):` -- the ops inside enqueue on that HIP stream WITHOUT switching torch's current stream
+    (torch.cuda.stream costs ~20 us per enter / exit).  Only for code that calls nothing but these ops: a torch operation inside would
+    still go to torch's current stream.  Allocations stay in the current stream's pool: the caller orders their reuse (functional.py)."""
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        self.prev = _STREAM_OVERRIDE[0]
+        _STREAM_OVERRIDE[0] = self.raw
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM_OVERRIDE[0] = self.prev
+        return False
+
+
+def current_raw_stream(device):
+    """torch's current stream of `device` as an int handle."""
+    if _raw_stream is not None:
+        return int(_raw_stream(device.index))
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def stream_wait_stream(waiter_raw, signaler_raw):
+    _lib.check(_lib.get().pnsfm_stream_wait_stream(ctypes.c_void_p(waiter_raw), ctypes.c_void_p(signaler_raw)), "stream_wait_stream")
+
+
 def _stream(t):
     """torch's CURRENT stream of t's device as a hipStream_t.  ~800 launches per training step go through here: the raw-handle
     query costs ~0.3 us against ~5 us for torch.cuda.current_stream(...).cuda_stream (round 5 host profile)."""
     if not t.is_cuda:
         return ctypes.c_void_p(0)
+    if _STREAM_OVERRIDE[0] is not None:
+        return ctypes.c_void_p(_STREAM_OVERRIDE[0])
     if _raw_stream is not None:
         return ctypes.c_void_p(_raw_stream(t.device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

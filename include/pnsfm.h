@@ -407,6 +407,20 @@ int pnsfm_adam_flat_step(float* param, const float* grad, float* exp_avg, float*
  * hp[0] (the group's step counter) first -- exactly one slice per group and step does that. */
 int pnsfm_adam_flat_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float* hp, int tick,
                            void* stream);
+/* Round 5: the optimizer tail in two launches for the whole model.  (1) pnsfm_adam_pack_table: the Adam update of every conv weight
+ * that takes the split-bf16 layout in both directions AND the re-pack of its forward / backward-data images in one pass (a workgroup
+ * per 32 x 32 (co, ci) super-tile: p, g, m, v read once, p, m, v and both images written: 40 B per parameter instead of the 28 + 20
+ * of pnsfm_adam_flat_step + pnsfm_conv2d_pack_table).  Items are filled on the host (pnsfm_adam_pack_item_fill returns the item's
+ * workgroup count, 0: not eligible) into a table of pnsfm_adam_pack_item_bytes()-sized records copied to the device.
+ * (2) pnsfm_adam_segments: the same update over a list of arena segments -- everything the table does not cover.  hp[0] must have
+ * been advanced for the step (pnsfm_adam_flat_update(..., n = 0, tick = 1)) before either launch. */
+size_t pnsfm_adam_pack_item_bytes(void);
+int pnsfm_adam_pack_item_fill(void* item_host, float* w, const float* g, float* m, float* v, const float* hp, float* wp_fwd,
+                              float* wp_bwd, int Cin, int Cout, int ks, int first_block);
+int pnsfm_adam_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream);
+size_t pnsfm_adam_seg_bytes(void);
+int pnsfm_adam_seg_fill(void* seg_host, float* p, const float* g, float* m, float* v, const float* hp, size_t n, int first_block);
+int pnsfm_adam_segments(const void* segs_dev, int nseg, int total_blocks, void* stream);
 
 /* ---- live timing of the dominant kernels (used by bench.py's roofline block) ---------------
  * When enabled, every launch of kind k is bracketed by hipEvents on its own stream.

@@ -1604,6 +1604,40 @@ int pnsfm_conv2d_pack_item_fill(void* item_host, const float* w, float* wp_fwd, 
   return it.nblk;
 }
 
+size_t pnsfm_adam_pack_item_bytes(void) { return sizeof(AdamPackItem); }
+
+// One item of the fused Adam + re-pack table (adam_pack_table_kernel): w / g / m / v = the parameter's slices of the optimizer's four
+// arenas, hp = the group's device-resident hyper-parameters.  Returns the item's workgroup count, 0 when the weight does not take
+// the split-bf16 layout in both directions (it stays with the plain update + the per-layer packer).
+int pnsfm_adam_pack_item_fill(void* item_host, float* w, const float* g, float* m, float* v, const float* hp, float* wp_fwd,
+                              float* wp_bwd, int Cin, int Cout, int ks, int first_block) {
+  if (ks != 1 && ks != 3 && ks != 5 && ks != 7) { set_error("adam_pack_item_fill: unsupported kernel size %d", ks); return -1; }
+  if (!item_host || !w || !g || !m || !v || !hp || !wp_fwd || !wp_bwd) { set_error("adam_pack_item_fill: null pointer"); return -1; }
+  if (!conv_use_bx3(Cin, ks) || !conv_use_bx3(Cout, ks)) return 0;
+  AdamPackItem it;
+  it.w = w; it.g = g; it.m = m; it.v = v; it.hp = hp;
+  it.pf = reinterpret_cast<unsigned char*>(wp_fwd);
+  it.pb = reinterpret_cast<unsigned char*>(wp_bwd);
+  it.Cin = Cin; it.Cout = Cout; it.ks = ks;
+  it.nchF = conv_pack_KP(Cin) / 16; it.nchB = conv_pack_KP(Cout) / 16;
+  // the packed images have conv_pack_MP(.) / 32 m-blocks; a super-tile row / column is one of them
+  const int cotiles = conv_pack_MP(Cout) / 32;
+  it.citiles = conv_pack_MP(Cin) / 32;
+  if (2 * it.citiles < it.nchF || 2 * cotiles < it.nchB) { set_error("adam_pack_item_fill: tile / chunk mismatch"); return -1; }
+  it.blk0 = first_block;
+  it.nblk = cotiles * it.citiles;
+  memcpy(item_host, &it, sizeof(it));
+  return it.nblk;
+}
+
+int pnsfm_adam_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream) {
+  if (n_items <= 0 || total_blocks <= 0) return 0;
+  if (!table_dev) { set_error("adam_pack_table: null table"); return -1; }
+  PNSFM_LAUNCH(adam_pack_table_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const AdamPackItem*>(table_dev), n_items);
+  return check_launch("adam_pack_table");
+}
+
 int pnsfm_conv2d_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream) {
   if (n_items <= 0 || total_blocks <= 0) return 0;
   if (!table_dev) { set_error("pack_table: null table"); return -1; }

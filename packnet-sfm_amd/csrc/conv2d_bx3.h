@@ -28,6 +28,7 @@
 // LDS per block = PB*3*PS*32 B (patch) + 2*G*MT*3072 B (weights) + 256 B (the tile's bias values); the host picks G (and PB) so that two blocks share a CU
 // where possible (the second block's math covers this block's staging).
 #pragma once
+#include "adam_math.h"
 
 #define PNSFM_BX3_SLAB 3072      // bytes per (32-row m-block, 16-channel chunk, tap)
 #define PNSFM_BX3_MAXIT 4        // patch items (pixel, 8-channel half) a thread prefetches in registers (PS <= 512 pixels); larger patches are staged in rounds
@@ -478,4 +479,97 @@ __global__ void __launch_bounds__(256) pack_bx3_table_kernel(const PackItem* __r
   else if (it.ks == 1) pack_bx3_block<1>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
   else if (it.ks == 5) pack_bx3_block<5>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
   else pack_bx3_block<7>(tile, it.w, it.pf, it.pb, it.Cin, it.Cout, it.nchF, it.nchB, it.nf, blk);
+}
+
+// ---- Adam update + re-pack of the split-bf16 conv weights in ONE pass (round 5).  adam_flat_kernel moved 28 B
+// per parameter and pack_bx3_table_kernel then read every weight TWICE (forward image, backward-data image) and wrote 2 x 6 B: 48 B
+// per parameter and two launches between backward and the next forward, where nothing overlaps them.  Here a workgroup owns a
+// 32 (co) x 32 (ci) super-tile of one weight: it reads p, g, m, v once (16 B), applies the update of adam_math.h (the same inline
+// function adam_flat_kernel uses: bit-identical parameters and moments), writes p, m, v back (12 B) and, from the updated values it
+// holds in LDS, both packed images (12 B): 40 B per parameter, one launch.  Taps go through the tile like in pack_bx3_block (all 9
+// of a 3x3 at once, one kernel row at a time for 5x5 / 7x7); a super-tile covers two 16-channel chunks of the forward image's
+// m-block (co tile) and two of the backward image's (ci tile).
+struct AdamPackItem {
+  float* w;            // the parameter's slice of the parameter arena, [Cout][Cin][k][k]
+  const float* g;      // ... of the gradient arena
+  float* m;            // ... of the exp_avg arena
+  float* v;            // ... of the exp_avg_sq arena
+  const float* hp;     // the group's device-resident hyper-parameters (adam_math.h)
+  unsigned char* pf;
+  unsigned char* pb;
+  int Cin, Cout, ks, nchF, nchB, citiles, blk0, nblk;
+};
+
+template <int KS>
+__device__ __forceinline__ void adam_pack_block(float (*tile)[32][33], const AdamPackItem& it, int blk) {
+  constexpr int KK = KS * KS, TSEG = (KS == 3) ? 9 : KS;
+  const int cot = blk / it.citiles, cit = blk - cot * it.citiles;
+  const int co0 = cot * 32, ci0 = cit * 32;
+  const int Cin = it.Cin, Cout = it.Cout;
+  const AdamCoef c = adam_coef(it.hp);
+  for (int t0 = 0; t0 < KK; t0 += TSEG) {
+    // update: for a row co the (ci, tap) elements of the segment are runs of TSEG floats, KK apart (one run of 32 * 9 for a 3x3)
+    for (int e = threadIdx.x; e < 32 * 32 * TSEG; e += 256) {
+      const int co = e / (32 * TSEG), r = e - co * (32 * TSEG), ci = r / TSEG, tt = r - ci * TSEG;
+      float pv = 0.f;
+      if (co0 + co < Cout && ci0 + ci < Cin) {
+        const size_t idx = ((size_t)(co0 + co) * Cin + ci0 + ci) * KK + t0 + tt;
+        pv = it.w[idx];
+        float mv = it.m[idx], vv = it.v[idx];
+        adam_update(c, it.g[idx], pv, mv, vv);
+        it.w[idx] = pv; it.m[idx] = mv; it.v[idx] = vv;
+      }
+      tile[tt][co][ci] = pv;
+    }
+    __syncthreads();
+    // forward image: m-block = co tile, chunks 2 cit and 2 cit + 1:  A[m = co][k = ci][tap]
+    for (int e = threadIdx.x; e < TSEG * 128; e += 256) {
+      const int tt = e >> 7, ch = (e >> 6) & 1, kh = (e >> 5) & 1, mrow = e & 31;
+      const int chunk = 2 * cit + ch;
+      if (chunk < it.nchF) {
+        float vals[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vals[i] = tile[tt][mrow][ch * 16 + kh * 8 + i];
+        pnsfm_u32x4 Hh, Mm, Ll;
+        bx3_split8(vals, Hh, Mm, Ll);
+        unsigned char* o = it.pf + ((size_t)(cot * it.nchF + chunk) * KK + t0 + tt) * PNSFM_BX3_SLAB + kh * 512 + mrow * 16;
+        *reinterpret_cast<pnsfm_u32x4*>(o) = Hh;
+        *reinterpret_cast<pnsfm_u32x4*>(o + 1024) = Mm;
+        *reinterpret_cast<pnsfm_u32x4*>(o + 2048) = Ll;
+      }
+    }
+    // backward-data image: m-block = ci tile, chunks 2 cot and 2 cot + 1:  A[m = ci][k = co][KK - 1 - tap]
+    for (int e = threadIdx.x; e < TSEG * 128; e += 256) {
+      const int tt = e >> 7, ch = (e >> 6) & 1, kh = (e >> 5) & 1, mrow = e & 31;
+      const int chunk = 2 * cot + ch;
+      if (chunk < it.nchB) {
+        float vals[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vals[i] = tile[tt][ch * 16 + kh * 8 + i][mrow];
+        pnsfm_u32x4 Hh, Mm, Ll;
+        bx3_split8(vals, Hh, Mm, Ll);
+        unsigned char* o = it.pb + ((size_t)(cit * it.nchB + chunk) * KK + (KK - 1 - (t0 + tt))) * PNSFM_BX3_SLAB + kh * 512 + mrow * 16;
+        *reinterpret_cast<pnsfm_u32x4*>(o) = Hh;
+        *reinterpret_cast<pnsfm_u32x4*>(o + 1024) = Mm;
+        *reinterpret_cast<pnsfm_u32x4*>(o + 2048) = Ll;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) adam_pack_table_kernel(const AdamPackItem* __restrict__ tab, int n) {
+  __shared__ float tile[9][32][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamPackItem it = tab[lo];
+  const int blk = (int)blockIdx.x - it.blk0;
+  if (blk >= it.nblk) return;
+  if (it.ks == 3) adam_pack_block<3>(tile, it, blk);
+  else if (it.ks == 1) adam_pack_block<1>(tile, it, blk);
+  else if (it.ks == 5) adam_pack_block<5>(tile, it, blk);
+  else adam_pack_block<7>(tile, it, blk);
 }

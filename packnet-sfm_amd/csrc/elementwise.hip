@@ -9,7 +9,9 @@
 //                 /root/reference/packnet_sfm/models/model_wrapper.py:128-149 and stepped at
 //                 /root/reference/packnet_sfm/trainers/horovod_trainer.py:93 (28 B/parameter of HBM traffic).
 #include "pnsfm_common.h"
+#include <cstring>
 #include "../../include/pnsfm.h"
+#include "adam_math.h"
 
 namespace pnsfm {
 
@@ -108,41 +110,66 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 //   the host's double arithmetic like torch.optim.Adam does: 1.f - 0.999f is 4.7e-5 off)
 __global__ void adam_tick_kernel(float* __restrict__ hp) { hp[0] += 1.f; }
 
-// float4 streaming Adam: 28 B/parameter of HBM traffic, bias corrections computed per thread from the device-side step
+// float4 streaming Adam: 28 B/parameter of HBM traffic, bias corrections computed per thread from the device-side step (adam_math.h)
 __global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, size_t n, const float* __restrict__ hp) {
-  const float step = hp[0], lr = hp[1], beta1 = hp[2], beta2 = hp[3], eps = hp[4], wd = hp[5], gscale = hp[6];
-  const float omb1 = hp[7], omb2 = hp[8];
-  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));          // once per thread, in double like the host formula
-  const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
-  const float step_size = lr / bc1;
+  const AdamCoef c = adam_coef(hp);
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
     float ga[4] = {gg.x, gg.y, gg.z, gg.w}, pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float gi = ga[k] * gscale;
-      if (wd != 0.f) gi = fmaf(wd, pa[k], gi);
-      ma[k] = beta1 * ma[k] + omb1 * gi;
-      va[k] = beta2 * va[k] + omb2 * gi * gi;
-      pa[k] -= step_size * (ma[k] / (sqrtf(va[k]) * rsqrt_bc2 + eps));
-    }
+    for (int k = 0; k < 4; ++k) adam_update(c, ga[k], pa[k], ma[k], va[k]);
     reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
     reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
     reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
   }
   // tail (n % 4 elements)
   for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    float gi = g[i] * gscale;
-    const float pi = p[i];
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    const float mi = beta1 * m[i] + omb1 * gi;
-    const float vi = beta2 * v[i] + omb2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = pi - step_size * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_update(c, g[i], pi, mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// The same update over a LIST of segments of the arenas in one launch (round 5: everything that is not a split-bf16 conv weight --
+// those are updated by adam_pack_table_kernel, conv2d_bx3.h, which writes their packed copies from the registers the update left them
+// in).  One workgroup per <= 1024 elements of a segment (binary search over the segments' first blocks, like the pack table).
+struct AdamSeg {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const float* hp;
+  unsigned n;
+  int blk0;
+};
+__global__ void __launch_bounds__(256) adam_segments_kernel(const AdamSeg* __restrict__ segs, int nseg) {
+  int lo = 0, hi = nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamSeg sg = segs[lo];
+  const unsigned e0 = ((unsigned)blockIdx.x - (unsigned)sg.blk0) * 1024u + threadIdx.x * 4u;
+  if (e0 >= sg.n) return;
+  const AdamCoef c = adam_coef(sg.hp);
+  if (e0 + 4u <= sg.n) {           // (segments start on 16-byte boundaries of the arenas: FlatAdam aligns every parameter)
+    const float4 gg = *reinterpret_cast<const float4*>(sg.g + e0);
+    float4 pp = *reinterpret_cast<float4*>(sg.p + e0), mm = *reinterpret_cast<float4*>(sg.m + e0), vv = *reinterpret_cast<float4*>(sg.v + e0);
+    float ga[4] = {gg.x, gg.y, gg.z, gg.w}, pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) adam_update(c, ga[k], pa[k], ma[k], va[k]);
+    *reinterpret_cast<float4*>(sg.p + e0) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(sg.m + e0) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *reinterpret_cast<float4*>(sg.v + e0) = make_float4(va[0], va[1], va[2], va[3]);
+  } else {
+    for (unsigned i = e0; i < sg.n; ++i) {
+      float pi = sg.p[i], mi = sg.m[i], vi = sg.v[i];
+      adam_update(c, sg.g[i], pi, mi, vi);
+      sg.p[i] = pi; sg.m[i] = mi; sg.v[i] = vi;
+    }
   }
 }
 
@@ -380,6 +407,21 @@ int pnsfm_adam_flat_update(float* param, const float* grad, float* exp_avg, floa
   if (tick) PNSFM_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, hp);
   if (n) PNSFM_LAUNCH(adam_flat_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, (const float*)hp);
   return check_launch("adam_flat_update");
+}
+
+size_t pnsfm_adam_seg_bytes(void) { return sizeof(AdamSeg); }
+int pnsfm_adam_seg_fill(void* seg_host, float* p, const float* g, float* m, float* v, const float* hp, size_t n, int first_block) {
+  if (!seg_host || !p || !g || !m || !v || !hp || n == 0 || n > 0xffffffffu) { set_error("adam_seg_fill: bad segment"); return -1; }
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) { set_error("adam_seg_fill: segments must start on 16-byte boundaries"); return -1; }
+  AdamSeg sg = {p, g, m, v, hp, (unsigned)n, first_block};
+  memcpy(seg_host, &sg, sizeof(sg));
+  return (int)((n + 1023) / 1024);
+}
+int pnsfm_adam_segments(const void* segs_dev, int nseg, int total_blocks, void* stream) {
+  if (nseg <= 0 || total_blocks <= 0) return 0;
+  if (!segs_dev) { set_error("adam_segments: null table"); return -1; }
+  PNSFM_LAUNCH(adam_segments_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const AdamSeg*>(segs_dev), nseg);
+  return check_launch("adam_segments");
 }
 
 int pnsfm_region_ops(const void* ops_host, int n_ops, void* stream) {

@@ -87,6 +87,12 @@ SIGNATURES = {
     "pnsfm_adam_flat_step": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "pnsfm_adam_flat_update": (_i, [_p, _p, _p, _p, _sz, _p, _i, _p]),
     "pnsfm_stream_wait_stream": (_i, [_p, _p]),
+    "pnsfm_adam_pack_item_bytes": (_sz, []),
+    "pnsfm_adam_pack_item_fill": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i]),
+    "pnsfm_adam_pack_table": (_i, [_p, _i, _i, _p]),
+    "pnsfm_adam_seg_bytes": (_sz, []),
+    "pnsfm_adam_seg_fill": (_i, [_p, _p, _p, _p, _p, _p, _sz, _i]),
+    "pnsfm_adam_segments": (_i, [_p, _i, _i, _p]),
     "pnsfm_resample8": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_jitter_totensor": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "pnsfm_nrs_project_forward": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),

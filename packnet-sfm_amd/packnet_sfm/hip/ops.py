@@ -875,6 +875,55 @@ def adam_flat_step(param, grad, exp_avg, exp_avg_sq, hp):
                                                _stream(param)), "adam_flat_step")
 
 
+def adam_fused_plan(conv_items, segments, device):
+    """Device tables of the two-launch optimizer tail (include/pnsfm.h: pnsfm_adam_pack_table / pnsfm_adam_segments).
+    conv_items: [(w, g, m, v, hp, wp_fwd, wp_bwd)] with w a [Cout, Cin, k, k] VIEW into the parameter arena and g, m, v the same slices
+    of the other arenas; segments: [(p, g, m, v, hp)] flat slices.  Returns (item table, n items, blocks, indices of the conv items the
+    table took, segment table, n segments, blocks); conv items it did not take must be added to `segments` by the caller."""
+    lib = _lib.get()
+    isz = int(lib.pnsfm_adam_pack_item_bytes())
+    host = (ctypes.c_ubyte * (isz * max(1, len(conv_items))))()
+    n, blocks, covered = 0, 0, []
+    for i, (w, g, m, v, hp, pf, pb) in enumerate(conv_items):
+        _chk(w, g, m, v, hp, pf, pb); _f32(w, g, m, v, hp, pf, pb)
+        Cout, Cin, ks, _ = w.shape
+        rc = lib.pnsfm_adam_pack_item_fill(ctypes.addressof(host) + n * isz, _ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(hp), _ptr(pf), _ptr(pb),
+                                           Cin, Cout, ks, blocks)
+        if rc < 0:
+            _lib.check(rc, "adam_pack_item_fill")
+        if rc > 0:
+            n += 1
+            blocks += rc
+            covered.append(i)
+    table = torch.frombuffer(bytearray(bytes(host)[:max(1, n) * isz]), dtype=torch.uint8).to(device)
+    return table, n, blocks, covered
+
+
+def adam_segment_table(segments, device):
+    lib = _lib.get()
+    ssz = int(lib.pnsfm_adam_seg_bytes())
+    host = (ctypes.c_ubyte * (ssz * max(1, len(segments))))()
+    blocks = 0
+    for i, (p, g, m, v, hp) in enumerate(segments):
+        _chk(p, g, m, v, hp); _f32(p, g, m, v, hp)
+        rc = lib.pnsfm_adam_seg_fill(ctypes.addressof(host) + i * ssz, _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hp), p.numel(), blocks)
+        if rc < 0:
+            _lib.check(rc, "adam_seg_fill")
+        blocks += rc
+    table = torch.frombuffer(bytearray(bytes(host)[:max(1, len(segments)) * ssz]), dtype=torch.uint8).to(device)
+    return table, len(segments), blocks
+
+
+def adam_pack_table_run(table, n, blocks):
+    if n:
+        _lib.check(_lib.get().pnsfm_adam_pack_table(_ptr(table), n, blocks, _stream(table)), "adam_pack_table")
+
+
+def adam_segments_run(table, n, blocks):
+    if n:
+        _lib.check(_lib.get().pnsfm_adam_segments(_ptr(table), n, blocks, _stream(table)), "adam_segments")
+
+
 def adam_flat_update(param, grad, exp_avg, exp_avg_sq, hp, tick):
     """adam_flat_step on a slice of the arenas; tick: advance the group's step counter first (one slice per group and step)."""
     _chk(param, grad, exp_avg, exp_avg_sq, hp); _f32(param, grad, exp_avg, exp_avg_sq, hp)

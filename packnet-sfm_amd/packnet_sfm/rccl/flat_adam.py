@@ -16,8 +16,13 @@ compatible (`param_groups[i]['lr']` is read before every step; `default_config.p
 `load_state_dict()` speak torch.optim.Adam's layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups'}), which
 is what the reference's checkpoints store (`model.optimizer.state_dict()`), so optimizer state moves between the two.
 
-Round 5 -- the update runs UNDERNEATH the backward pass (`overlap`, on by default; PNSFM_ADAM_OVERLAP=0 or FlatAdam(...,
-overlap=False) switch it off).  The arenas are laid out in the order backward produces gradients, so they are cut into the same
+Round 5 -- (a) the FUSED TAIL (on by default; PNSFM_ADAM_FUSED=0 / FlatAdam(..., fused=False) switch it off): once the conv layers own
+packed weight copies, step() is two launches for the whole model -- `adam_pack_table_kernel` (csrc/conv2d_bx3.h) updates every
+split-bf16 conv weight AND writes its forward / backward-data images from the values it holds (40 B per parameter instead of the 28 of
+the flat update + the 20 of the re-pack), `adam_segments_kernel` updates the rest of the arenas; both use the inline update of
+csrc/adam_math.h, like the flat kernel: bit-identical parameters and moments (tests/test_kernels_emulated.py).
+(b) the update UNDERNEATH the backward pass (`overlap`, OFF by default -- measured +0.2 % for +1.5 ms of host work per step;
+PNSFM_ADAM_OVERLAP=1 or FlatAdam(..., overlap=True) switch it on).  The arenas are laid out in the order backward produces gradients, so they are cut into the same
 <= 32 MiB buckets the gradient all-reduce uses, and the moment the last gradient of a bucket has been accumulated (post-accumulate
 hooks) its Adam update AND the re-pack of its conv weights are enqueued on a side HIP stream: 1.3 ms of
 HBM-bound work per step (28 B/parameter + the packer's 21 B) that used to sit exposed between backward and the next forward now runs
@@ -44,7 +49,7 @@ def _round_up(n, a):
 
 class FlatAdam:
     def __init__(self, param_groups, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_slots=True, overlap=None,
-                 bucket_bytes=32 << 20):
+                 bucket_bytes=32 << 20, fused=None):
         if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
             param_groups = [{'params': list(param_groups)}]
         self.param_groups = []
@@ -108,6 +113,9 @@ class FlatAdam:
             import weakref as _wr
             hooks = self._hooks
             _wr.finalize(self, lambda: [h.remove() for h in hooks])
+        # ---- the fused optimizer tail (round 5): conv weights updated AND re-packed by one launch, everything else by a second one
+        self._fused = (os.environ.get('PNSFM_ADAM_FUSED', '1') != '0') if fused is None else bool(fused)
+        self._plan = None               # [signature, item table, n, blocks, (cache, parameter) pairs it covers, segment table, n, blocks]
         self._slots = HF.register_grad_slots(slots) if grad_slots else None
         if self._slots is not None:
             # the slots are views of THIS optimizer's gradient arena: they go when the optimizer goes (and, independently,
@@ -221,6 +229,56 @@ class FlatAdam:
             self._stamp += HF.repack_subset(ch['slot'], ch['ids'])
         ch['done'] = True
 
+    # ---- fused tail: Adam + re-pack of the conv weights in one launch, the rest of the arenas in a second ---------------------------
+    def _fused_plan(self):
+        """Device tables of the two-launch tail, rebuilt when the set of (parameter, packed buffers) or the arithmetic mode changes.
+        None while no conv weight has packed copies yet (first steps) or when fusing is off."""
+        if not self._fused or not HF._pack_batch_on():
+            return None
+        mine = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                mine[id(p)] = (g, p)
+        pairs = []
+        for dev, prs in HF._pack_pairs(only=set(mine)).items():
+            pairs += [(c, w) for c, w in prs if w.dim() == 4 and w.device == self.param_groups[0]['_flat'].device]
+        if not pairs:
+            return None
+        sig = (HF.get_conv_math(),) + tuple((w.data_ptr(), c.wp_fwd.data_ptr(), c.wp_bwd.data_ptr()) for c, w in pairs)
+        if self._plan is not None and self._plan[0] == sig:
+            return self._plan
+        dev = self.param_groups[0]['_flat'].device
+
+        def slices(g, p):
+            o, k = g['_offs'][id(p)], p.numel()
+            return [g[a][o:o + k] for a in ('_flat', '_grad', '_m', '_v')]
+
+        items = []
+        for c, w in pairs:
+            g, p = mine[id(w)]
+            fl, gr, m, v = slices(g, p)
+            items.append((fl.view_as(p), gr.view_as(p), m.view_as(p), v.view_as(p), g['_hp'], c.wp_fwd, c.wp_bwd))
+        table, n, blocks, covered = ops.adam_fused_plan(items, [], dev)
+        taken = {id(pairs[i][1]) for i in covered}
+        # segments: maximal runs of the arenas between the covered conv weights (arena order; parameters are 16-byte aligned)
+        segs = []
+        for g in self.param_groups:
+            run = None
+            for p in g['_order']:
+                o = g['_offs'][id(p)]
+                e = o + _round_up(p.numel(), _ALIGN)
+                if id(p) in taken:
+                    if run is not None:
+                        segs.append((g, run[0], run[1]))
+                        run = None
+                else:
+                    run = [o, e] if run is None else [run[0], e]
+            if run is not None:
+                segs.append((g, run[0], run[1]))
+        seg_t, nseg, sblocks = ops.adam_segment_table([(g['_flat'][a:b], g['_grad'][a:b], g['_m'][a:b], g['_v'][a:b], g['_hp']) for g, a, b in segs], dev)
+        self._plan = [sig, table, n, blocks, [pairs[i] for i in covered], seg_t, nseg, sblocks]
+        return self._plan
+
     # ---- torch.optim.Optimizer surface --------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
         """Gradients are dropped, not zero-filled: the next backward writes every element of the arena slices it uses (the
@@ -266,6 +324,27 @@ class FlatAdam:
         self._armed = False
         for dev, side in self._side.items():
             torch.cuda.current_stream(dev).wait_stream(side)       # join the updates enqueued during backward (they ticked the step counters)
+        plan = None
+        if not any(ch['done'] for g in self.param_groups for ch in g['_chunks']):
+            plan = self._fused_plan()
+        if plan is not None:
+            # the two-launch tail: every gradient present (a parameter without one is skipped like torch does: plain path this step)
+            missing = [self._gather_grads(g) for g in self.param_groups]
+            if not any(missing):
+                for g in self.param_groups:
+                    self._sync_group(g)
+                    ops.adam_flat_update(g['_flat'][:0], g['_grad'][:0], g['_m'][:0], g['_v'][:0], g['_hp'], tick=True)    # step counter only
+                ops.adam_pack_table_run(plan[1], plan[2], plan[3])
+                ops.adam_segments_run(plan[5], plan[6], plan[7])
+                HF.bump_weight_epoch()
+                HF.stamp_packed(plan[4])
+                HF.repack_all(exclude={id(w) for _, w in plan[4]})
+                for g in self.param_groups:
+                    for ch in g['_chunks']:
+                        ch['pending'], ch['done'] = len(ch['params']), False
+                    g['_next'], g['_ticked'] = 0, False
+                self._stamp = []
+                return loss
         for g in self.param_groups:
             if not any(ch['done'] for ch in g['_chunks']):
                 # nothing of this group was updated underneath backward (overlap off, no zero_grad() since the last step, a reducer

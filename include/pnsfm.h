@@ -70,6 +70,13 @@ int pnsfm_conv2d_forward_gn(const float* x0, int C0, const float* x1, int C1, co
                             void* stream);
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
                                int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* Round 5: dx = backward-data + addend.  A tensor with two consumers (the encoder feature that is also a decoder skip input,
+ * PackNet01.py:119-174; the ResidualConv input read by conv1 and the 1x1 shortcut, layers01.py:66-72) receives two gradients that
+ * autograd sums with an elementwise pass; here the second consumer's backward-data launch adds the first gradient in its epilogue
+ * (or in the second stage of a K-split launch).  addend: [B][Cin][H][W] with addend_bstride floats between samples -- a channel slice
+ * of the wider gradient of a multi-source convolution is passed as it is; must not overlap dx.  addend == NULL: plain backward-data. */
+int pnsfm_conv2d_backward_data_add(const float* dy, const float* wp_bwd, float* dx, const float* addend, long long addend_bstride,
+                                   int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 /* dw in the reference layout [Cout][Cin][k][k]; dbias [Cout] (nullable). Both are overwritten.  When the autotuner
  * splits the pixel reduction the outputs are zero-filled first; placing dbias directly behind dw (dbias == dw +
  * Cout*Cin*k*k) lets one fill cover both. */
@@ -297,6 +304,19 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
 /* Variants that keep scalars on the device (round 4: no ATen launch between these kernels and autograd): forward_mean writes
  * loss_mean float[1] = loss_sum / (B*H*W); backward_dev multiplies grad_scale by upstream[0] (device scalar, nullable) and takes
  * clip = 0 | 1 (the byte layout of pnsfm_photometric_forward / _forward_clip). */
+/* Round 5: view synthesis fused into the photometric loss (reference: losses/multiview_photometric_loss.py:127-253 -- warp_ref_image,
+ * SSIM, calc_photometric_loss, automask + reduce -- with geometry/camera.py:112-191 and camera_utils.py:27-59 inside): the kernels
+ * warp the J context images `ref` [J][B][3][H][W] to the target view themselves (inv_depth [B][H][W], K / refK [B][3][3], T [J][B][4][4],
+ * padding_mode 0 zeros | 1 border | 2 reflection), no `warped` tensor and no gradient of it ever exists.  loss_mean: float[1], the
+ * pixel mean of the reduced map; argmin as pnsfm_photometric_forward.  Backward: d_inv_depth [B][H][W], dT [J][B][4][4].  No clipping,
+ * ssim_weight > 0 (other configurations: pnsfm_view_synthesis_* + pnsfm_photometric_*). */
+int pnsfm_photometric_warp_forward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
+                                   const float* T, float* loss_mean, uint8_t* argmin, int J, int B, int H, int W, float ssim_weight,
+                                   float C1, float C2, int automask, int reduce_op, int padding_mode, void* stream);
+int pnsfm_photometric_warp_backward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
+                                    const float* T, const uint8_t* argmin, float* d_inv_depth, float* dT, float grad_scale,
+                                    const float* upstream, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
+                                    int automask, int reduce_op, int padding_mode, void* stream);
 int pnsfm_photometric_forward_mean(const float* warped, const float* ref, const float* target, float* loss_mean, uint8_t* argmin,
                                    int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
                                    void* stream);

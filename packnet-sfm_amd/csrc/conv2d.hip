@@ -382,6 +382,11 @@ struct ConvArgs {
   // slot = tile-in-image * 4 + wave, gn_nslot = tiles_per_img * 4.  null: off.
   double* gn_stats;
   int gn_G, gn_nslot;
+  // round 5: y = conv + bias + addend -- the other gradient of a tensor with two consumers (skip connection, 1x1 shortcut), added where
+  // the backward-data result is in registers instead of by a separate elementwise pass (3 passes over the tensor and a launch each).
+  // [B][Cout][H][W] with `addend_bs` floats between samples (a channel slice of a wider tensor is fine).  null: off.
+  const float* addend;
+  size_t addend_bs;
 #ifdef PNSFM_BX3_ABLATE
   int ablate;         // debug build only (tools/bx3_ablate.py): what-if switches of conv2d_bx3_kernel -- results are wrong
 #endif
@@ -401,7 +406,7 @@ __device__ __attribute__((aligned(16))) float pnsfm_zero_page[64];
 // The 16*MT bias values a lane needs are fetched up front in ONE batch (the store loop used to fetch each one right
 // before its store and wait for it: 32 dependent L2 round trips per workgroup).
 // paths are separate loops so the compiler can stream the stores.
-template <int MT, int NT>
+template <int MT, int NT, bool ADD = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], int b, int co0, int half,
                                               const int (&oy)[NT], const int (&ox)[NT], const bool (&pvalid)[NT], int bz,
                                               const float* lds_bias = nullptr, int gn_tile = -1, int gn_wave = 0) {
@@ -433,6 +438,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
   int poff[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) poff[nt] = oy[nt] * a.W + ox[nt];
+  if (ADD && a.addend != nullptr && !split) {       // (ADD = false: the f32 kernels, which no addend launch runs -- enqueue_conv)
+    // one M tile's 16 x NT values per batch: the loads of a batch are in flight together (a uniform branch: launches without an
+    // addend skip it); padded rows / pixels read element 0 of the sample's slice and are never stored
+    const float* ab = a.addend + (size_t)b * a.addend_bs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float av[16][NT];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) av[r][nt] = ab[(co < a.Cout && pvalid[nt]) ? (size_t)co * HW + poff[nt] : (size_t)0];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] += av[r][nt];
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -496,11 +520,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
   }
 }
 
-// second stage of a K-split launch: y = bias + sum over the splits' slabs, in split order (bit-reproducible)
+// second stage of a K-split launch: y = bias + sum over the splits' slabs, in split order (bit-reproducible) [+ addend, last]
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                                 float* __restrict__ y, int Z, int Cout, int HW, size_t total) {
+                                                                 float* __restrict__ y, int Z, int Cout, int HW, size_t total,
+                                                                 const float* __restrict__ addend, size_t addend_bs) {
   const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= total) return;
+  const size_t chw = (size_t)Cout * HW;
   if ((HW & 3) == 0) {                 // (then total % 4 == 0 and the four elements share a channel)
     float4 s = *reinterpret_cast<const float4*>(ws + i4);
     for (int z = 1; z < Z; ++z) {
@@ -508,12 +534,18 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (bias) { const float bv = bias[(i4 / HW) % Cout]; s.x += bv; s.y += bv; s.z += bv; s.w += bv; }
+    if (addend) {
+      const size_t bb = i4 / chw;
+      const float* ap = addend + bb * addend_bs + (i4 - bb * chw);       // (a slice's start need not be 16-byte aligned)
+      s.x += ap[0]; s.y += ap[1]; s.z += ap[2]; s.w += ap[3];
+    }
     *reinterpret_cast<float4*>(y + i4) = s;
   } else {
     for (size_t i = i4; i < i4 + 4 && i < total; ++i) {
       float s = ws[i];
       for (int z = 1; z < Z; ++z) s += ws[(size_t)z * total + i];
       if (bias) s += bias[(i / HW) % Cout];
+      if (addend) { const size_t bb = i / chw; s += addend[bb * addend_bs + (i - bb * chw)]; }
       y[i] = s;
     }
   }
@@ -701,7 +733,7 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
     if constexpr (DMA) dma_cur ^= 1;
   }
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z, nullptr, t, wave);
+  conv_epilogue<MT, NT, false>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z, nullptr, t, wave);
 }
 
 
@@ -935,7 +967,7 @@ __global__ void __launch_bounds__(256) conv2d_pipe_kernel(ConvArgs a) {
   const long long tr_epi = __builtin_readcyclecounter();
 #endif
 
-  conv_epilogue<MT, NT>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z, nullptr, t, wave);
+  conv_epilogue<MT, NT, false>(a, acc, b, co0, half, oy, ox, pvalid, (int)blockIdx.z, nullptr, t, wave);
 #ifdef PNSFM_PIPE_TRACE
   if (a.trace && lane == 0) {
     const long long tr_end = __builtin_readcyclecounter();
@@ -963,6 +995,8 @@ struct ConvGnOut {
   double* stats;
   int G;
   int nslot;
+  const float* addend;      // round 5: the launch's epilogue extras also carry the addend of ConvArgs (null: none)
+  size_t addend_bs;
 };
 static bool conv_gn_ok(const ConvGeom& g, int Cout, int G) {
   if (G <= 0 || Cout % G != 0 || g.splitK != 1) return false;
@@ -975,6 +1009,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
                         const ConvSrc* ms = nullptr, ConvGnOut* gn = nullptr) {
   ConvArgs a;
   a.gn_stats = nullptr; a.gn_G = 0; a.gn_nslot = 0;
+  a.addend = gn ? gn->addend : nullptr; a.addend_bs = gn ? gn->addend_bs : 0;
   if (gn) {
     gn->nslot = 0;
     if (gn->stats && conv_gn_ok(g, Cout, gn->G)) {
@@ -985,6 +1020,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.x1 = ms ? ms->x1 : nullptr; a.x2 = ms ? ms->x2 : nullptr;
   a.C0 = ms ? ms->C0 : Cin; a.C01 = ms ? ms->C0 + ms->C1 : Cin;
   if (ms && g.DMA < 3) { set_error("%s: several input tensors need the split-bf16 kernels", what); return -1; }
+  if (a.addend && g.DMA < 3) { set_error("%s: an addend needs the split-bf16 kernels (>= 16 channels of dy, 'bx3' arithmetic)", what); return -1; }
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.S = S; a.Hi = Hi; a.Wi = Wi;
   a.CI = g.CI; a.mode = g.mode; a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img;
@@ -1109,7 +1145,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   int rc = check_launch(what);
   if (!rc && g.splitK > 1) {
     PNSFM_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)ceil_div_sz(out_elems, 1024)), dim3(256), 0, stream, (const float*)a.ws, bias, y,
-                 g.splitK, Cout, H * W, out_elems);
+                 g.splitK, Cout, H * W, out_elems, a.addend, a.addend_bs);
     rc = check_launch(what);
   }
   return rc;
@@ -1657,6 +1693,17 @@ int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx, 
   return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data", 1);
 }
 
+// dx = conv(dY, flipped/transposed W) + addend: the tensor's OTHER gradient (a skip connection's, a 1x1 shortcut's) added in the
+// epilogue instead of by autograd's elementwise sum afterwards.  addend: [B][Cin][H][W], `addend_bstride` floats between samples
+// (>= Cin*H*W: a channel slice of the wider gradient a multi-source convolution produced); must not overlap dx.
+int pnsfm_conv2d_backward_data_add(const float* dy, const float* wp_bwd, float* dx, const float* addend, long long addend_bstride,
+                                   int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
+  if (!addend) return pnsfm_conv2d_backward_data(dy, wp_bwd, dx, B, Cin, Cout, H, W, ks, stream);
+  if (addend_bstride < (long long)Cin * H * W) { set_error("conv2d_backward_data_add: addend_bstride smaller than a sample"); return -1; }
+  ConvGnOut ex = {nullptr, 0, 0, addend, (size_t)addend_bstride};
+  return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data_add", 1, 1, 0, 0, nullptr, &ex);
+}
+
 static bool conv_ms_ok(int C0, int C1, int C2, int granule, const char* what) {
   if (C0 <= 0 || C1 <= 0 || C2 < 0 || C0 % granule != 0 || (C2 > 0 && (C0 + C1) % granule != 0)) {
     set_error("%s: input tensors of %d / %d / %d channels: every tensor but the last must end on a %d-channel boundary", what, C0, C1,
@@ -1679,7 +1726,7 @@ int pnsfm_conv2d_forward_gn(const float* x0, int C0, const float* x1, int C1, co
                             const float* bias, float* y, double* stats_ws, int G, int* nslot, int B, int Cout, int H, int W, int ks,
                             void* stream) {
   if (!nslot) { set_error("conv2d_forward_gn: null nslot"); return -1; }
-  ConvGnOut gn = {stats_ws, G, 0};
+  ConvGnOut gn = {stats_ws, G, 0, nullptr, 0};
   int rc;
   if (C1 == 0 && C2 == 0) {
     rc = launch_conv(x0, wp_fwd, bias, y, B, C0, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward", 0, 1, 0, 0, nullptr, &gn);

@@ -61,6 +61,81 @@ __global__ void __launch_bounds__(256) invdepth_conv_fwd_kernel(const float* __r
   }
 }
 
+// Round 5 (250 MB per launch against 45 MB algorithmic): the kernel above gives every 64-pixel block its own three
+// image rows, and consecutive block indices go round robin over the 8 XCDs -- so every row of x is fetched by three different L2s
+// (the blocks of rows y-1, y, y+1) plus the partial lines of the one-pixel halo.  The strip form: a block owns R rows x 64 columns;
+// per channel a lane loads the R + 2 centre values of its column ONCE and takes the left / right neighbours from the adjacent lanes
+// (wave shifts; lanes 0 and 63 fetch the strip's halo column with a second, two-lane load), so x is read (R + 2) / R times instead of
+// 3 x 3 times through the texture path and 3+ times from HBM; the logical block order (x strips, then y strips, then images) is cut
+// into one contiguous range per XCD, so the strips that share halo rows / halo lines share an L2.  The per-pixel accumulation order
+// (channels of a quarter in sequence, taps 0..8, then the four quarters + bias) is the kernel above's: results are bit-identical.
+// Used for the maps with enough strips to fill the chip (192x640: R = 8, 96x320: R = 4); the low-resolution heads stay above.
+template <int R>
+__global__ void __launch_bounds__(256) invdepth_conv_fwd_strip_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                                       int C, int H, int W, int sx_n, int sy_n, float inv_min_depth) {
+  __shared__ float part[4][R][64];
+  const int tid = threadIdx.x, lane = tid & 63, quarter = tid >> 6;
+  const int HW = H * W;
+  const unsigned L = pnsfm_xcd_logical_block(blockIdx.x, gridDim.x);
+  const int sx = (int)(L % (unsigned)sx_n), sy = (int)((L / (unsigned)sx_n) % (unsigned)sy_n), b = (int)(L / (unsigned)(sx_n * sy_n));
+  const int px = sx * 64 + lane, y0 = sy * R;
+  const unsigned kOut = 0x7fffffffu;
+  // byte offsets inside a channel plane: the lane's own column, and (lanes 0 / 63 only) the column left / right of the strip
+  const int hx = lane == 0 ? px - 1 : (lane == 63 ? px + 1 : -1);
+  unsigned offc[R + 2], offh[R + 2];
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r) {
+    const int yy = y0 + r - 1;
+    const bool rok = yy >= 0 && yy < H;
+    offc[r] = (rok && px < W) ? (unsigned)(yy * W + px) * 4u : kOut;
+    offh[r] = (rok && hx >= 0 && hx < W) ? (unsigned)(yy * W + hx) * 4u : kOut;
+  }
+  const int cq = (C + 3) / 4;
+  const int c0 = quarter * cq;
+  const int c1 = (c0 + cq < C) ? c0 + cq : C;
+  float acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc[i] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    const int cu = PNSFM_UNIFORM(c);
+    const pnsfm_buf pb = pnsfm_make_buf(x + ((size_t)b * C + cu) * HW, (unsigned)HW * 4u);
+    const float* wc = w + cu * 9;
+    float vc[R + 2], vh[R + 2], vl[R + 2], vr[R + 2];
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+      vc[r] = pnsfm_buf_load(pb, offc[r], 0u);
+      vh[r] = pnsfm_buf_load(pb, offh[r], 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < R + 2; ++r) {
+      const float up = __shfl_up(vc[r], 1), dn = __shfl_down(vc[r], 1);
+      vl[r] = lane == 0 ? vh[r] : up;
+      vr[r] = lane == 63 ? vh[r] : dn;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc[i] = fmaf(wc[ky * 3 + 0], vl[i + ky], acc[i]);
+        acc[i] = fmaf(wc[ky * 3 + 1], vc[i + ky], acc[i]);
+        acc[i] = fmaf(wc[ky * 3 + 2], vr[i + ky], acc[i]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) part[quarter][i][lane] = acc[i];
+  __syncthreads();
+  // 256 threads finish R x 64 pixels: thread -> (row = tid / 64 + 4 * k, column = lane)
+#pragma unroll
+  for (int i = quarter; i < R; i += 4) {
+    const int yy = y0 + i;
+    if (yy < H && px < W) {
+      const float z = part[0][i][lane] + part[1][i][lane] + part[2][i][lane] + part[3][i][lane] + bias[0];
+      y[(size_t)b * HW + (size_t)yy * W + px] = inv_min_depth / (1.f + expf(-z));
+    }
+  }
+}
+
 constexpr int kIdCh = 8;                    // channels per thread in the backward kernel
 constexpr int kIdVals = kIdCh * 9 + 1;      // + the bias sum
 constexpr int kIdRow = 256 + 16;            // padded LDS row (conflict-free 16-lane strided reads)
@@ -168,8 +243,28 @@ int pnsfm_invdepth_conv_forward(const float* x, const float* w, const float* bia
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("invdepth_conv_forward: bad shape"); return -1; }
   if (min_depth <= 0.f) { set_error("invdepth_conv_forward: min_depth must be > 0"); return -1; }
   if ((size_t)H * W * 4 >= 0x7fffffffull) { set_error("invdepth_conv_forward: plane exceeds the 2 GiB buffer window"); return -1; }
-  PNSFM_LAUNCH(invdepth_conv_fwd_kernel, dim3(ceil_div(H * W, 64), 1, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
-               C, H, W, 1.0f / min_depth);
+  // strips of R rows x 64 columns where they fill the chip (see invdepth_conv_fwd_strip_kernel); PNSFM_INVDEPTH_STRIP = 0: never,
+  // 4 / 8: always, with that R (tests)
+  const char* e = getenv("PNSFM_INVDEPTH_STRIP");
+  const int mode = e ? atoi(e) : 1;
+  const int sx_n = ceil_div(W, 64);
+  const bool wide = mode == 1 && W >= 64 && sx_n * 64 - W <= 16;        // at most a quarter of the last strip idle
+  int R = 0;
+  if (mode == 4 || mode == 8) R = mode;
+  else if (wide && (long)sx_n * ceil_div(H, 8) * B >= 768) R = 8;
+  else if (wide && (long)sx_n * ceil_div(H, 4) * B >= 400) R = 4;
+  if (R) {
+    const int sy_n = ceil_div(H, R);
+    if (R == 8)
+      PNSFM_LAUNCH(invdepth_conv_fwd_strip_kernel<8>, dim3(sx_n * sy_n * B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, H, W,
+                   sx_n, sy_n, 1.0f / min_depth);
+    else
+      PNSFM_LAUNCH(invdepth_conv_fwd_strip_kernel<4>, dim3(sx_n * sy_n * B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, C, H, W,
+                   sx_n, sy_n, 1.0f / min_depth);
+  } else {
+    PNSFM_LAUNCH(invdepth_conv_fwd_kernel, dim3(ceil_div(H * W, 64), 1, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                 C, H, W, 1.0f / min_depth);
+  }
   return check_launch("invdepth_conv_forward");
 }
 

@@ -464,7 +464,7 @@ class Conv2dFn(Function):
     """y = conv2d(zero_pad_{k//2}(x), weight) + bias, stride 1 (fp32 implicit GEMM on the matrix pipe; arithmetic: set_conv_math)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache, recording=True):
+    def forward(ctx, x, weight, bias, cache, recording=True, tap=False):
         x = x.contiguous()
         need_dx = ctx.needs_input_grad[0]
         wp_fwd, wp_bwd = cache.get(weight, need_dx)
@@ -476,11 +476,18 @@ class Conv2dFn(Function):
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
         _WgradStream.note_use(recording, weight, bias)
+        # tap (see conv2d_tap): the input comes back as a second output; what its other consumers send back arrives here as g_tap
+        # (None when nobody read the tap: no zero tensor is materialised) and is added inside the backward-data launch
+        if tap:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_tap=None):
+        if dy is None:         # only the tap was used: its gradient passes straight through
+            return g_tap, None, None, None, None, None
         x, wp_bwd = ctx.saved_tensors
         Cin, Cout, ks, has_bias = ctx.meta
         dy = dy.contiguous()
@@ -495,16 +502,49 @@ class Conv2dFn(Function):
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
+            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=g_tap)
         if want_w:
             dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
         if wait is not None:
             wait()
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv2d(x, weight, bias, cache):
     return Conv2dFn.apply(x, weight, bias, cache, torch.is_grad_enabled())
+
+
+# Round 5: gradient taps.  A tensor read by a convolution AND by something else (the encoder feature that is also a decoder skip input;
+# the ResidualConv input read by conv1 and by the 1x1 shortcut; the decoder feature read by the next unpack block and by the InvDepth
+# head) receives two gradients, which autograd adds with an elementwise kernel: 3 passes over the tensor and a launch, 18 times per
+# PackNet01 step (1.2 GB).  conv2d_tap / conv2d_gn_act_tap return (y, x_tap): x_tap is x again, but as an OUTPUT of the convolution's
+# node -- the other consumers read x_tap, their gradient comes back to the node as g_tap, and the convolution's backward-data launch
+# adds it in its epilogue (ops.conv2d_backward_data(addend=...)): one read of the addend, no extra launch.  For a tensor with two
+# consumers the bits are the untapped graph's (fl(acc + addend) either way); with three (ResidualConv input that is also a skip) the
+# association differs from autograd's arrival order -- fixed, deterministic, inside every golden's tolerance.
+# PNSFM_GRAD_TAPS=0 / set_grad_taps(False): plain graph.
+_GRAD_TAPS = os.environ.get('PNSFM_GRAD_TAPS', '1') != '0'
+
+
+def set_grad_taps(on):
+    global _GRAD_TAPS
+    _GRAD_TAPS = bool(on)
+
+
+def grad_taps():
+    return _GRAD_TAPS
+
+
+def _tap_ok(weight):
+    # the addend lives in the split-bf16 kernels' epilogue: backward-data's K is the layer's Cout
+    return get_conv_math() == 'bx3' and weight.shape[0] >= 16
+
+
+def conv2d_tap(x, weight, bias, cache):
+    """(conv2d(x), x_tap)."""
+    if not (_GRAD_TAPS and torch.is_grad_enabled() and x.requires_grad and _tap_ok(weight)):
+        return conv2d(x, weight, bias, cache), x
+    return Conv2dFn.apply(x, weight, bias, cache, True, True)
 
 
 class Conv2dCatFn(Function):
@@ -603,10 +643,10 @@ class ConvGnActFn(Function):
     (gn_stats hands it <= 256), and the epilogue's shuffle tree costs the conv kernels 0.8 %."""
 
     @staticmethod
-    def forward(ctx, weight, bias, gamma, beta, cache, recording, cat_wgrad, G, eps, act, *xs):
+    def forward(ctx, weight, bias, gamma, beta, cache, recording, cat_wgrad, G, eps, act, tap, *xs):
         xs = tuple(t.contiguous() for t in xs)
         ctx.cat_wgrad = cat_wgrad
-        need_dx = any(ctx.needs_input_grad[10:])
+        need_dx = any(ctx.needs_input_grad[11:])
         wp_fwd, wp_bwd = cache.get(weight, need_dx)
         Cout, Cin, ks, _ = weight.shape
         if sum(t.shape[1] for t in xs) != Cin:
@@ -625,11 +665,17 @@ class ConvGnActFn(Function):
         ctx.meta = (Cin, Cout, ks, bias is not None, G, act)
         ctx.params = (weight, bias)
         _WgradStream.note_use(recording, weight, bias)
+        # tap (single input only, see conv2d_tap): x comes back as a second output, its other consumers' gradient is added in backward-data
+        if tap:
+            ctx.set_materialize_grads(False)
+            return out, xs[0].view_as(xs[0])
         return out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, g_tap=None):
+        if dout is None:       # only the tap was used: its gradient passes straight through
+            return (None,) * 11 + (g_tap,)
         wp_bwd, y, gamma, beta, mean, rstd, *xs = ctx.saved_tensors
         Cin, Cout, ks, has_bias, G, act = ctx.meta
         dy, dgamma, dbeta = ops.groupnorm_act_backward(dout.contiguous(), y, None, gamma.detach(), beta.detach(), mean, rstd, G, act)
@@ -652,21 +698,21 @@ class ConvGnActFn(Function):
             r = _WgradStream.run(wgrad, dy, *xs, detached=detached, pure=(len(xs) == 1 or (ctx.cat_wgrad and get_conv_math() == 'bx3')))
             (dw, db), wait = (r, None) if detached else r
             want_w = False
-        if any(ctx.needs_input_grad[10:]):
-            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks)
+        if any(ctx.needs_input_grad[11:]):
+            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=g_tap if len(xs) == 1 else None)
             if len(xs) == 1:
                 dxs[0] = dx
             else:
                 c0 = 0
                 for i, t in enumerate(xs):
-                    if ctx.needs_input_grad[10 + i]:
+                    if ctx.needs_input_grad[11 + i]:
                         dxs[i] = dx[:, c0:c0 + t.shape[1]]
                     c0 += t.shape[1]
         if want_w:
             dw, db = wgrad()
         if wait is not None:
             wait()
-        return (dw, db, dgamma, dbeta, None, None, None, None, None, None) + tuple(dxs)
+        return (dw, db, dgamma, dbeta, None, None, None, None, None, None, None) + tuple(dxs)
 
 
 _CONV_GN_FUSE = os.environ.get('PNSFM_CONV_GN_FUSE', '1') != '0'
@@ -697,7 +743,14 @@ def conv2d_gn_act(x, weight, bias, gamma, beta, cache, G=16, eps=1e-5, act=ops.A
         y = conv2d(xs[0], weight, bias, cache) if len(xs) == 1 else conv2d_cat(xs, weight, bias, cache)
         return groupnorm_act(y, gamma, beta, G, eps, act)
     cat_wgrad = _cat_wgrad_ok(xs, weight) if len(xs) > 1 else False
-    return ConvGnActFn.apply(weight, bias, gamma, beta, cache, torch.is_grad_enabled(), cat_wgrad, G, eps, act, *xs)
+    return ConvGnActFn.apply(weight, bias, gamma, beta, cache, torch.is_grad_enabled(), cat_wgrad, G, eps, act, False, *xs)
+
+
+def conv2d_gn_act_tap(x, weight, bias, gamma, beta, cache, G=16, eps=1e-5, act=ops.ACT_ELU):
+    """The Conv2D block with a gradient tap on its (single-tensor) input: (out, x_tap) -- see conv2d_tap."""
+    if not (_GRAD_TAPS and _CONV_GN_FUSE and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad and _tap_ok(weight)):
+        return conv2d_gn_act(x, weight, bias, gamma, beta, cache, G, eps, act), x
+    return ConvGnActFn.apply(weight, bias, gamma, beta, cache, True, False, G, eps, act, True, x)
 
 
 class Conv2dStride2Fn(Function):
@@ -1406,6 +1459,56 @@ class PhotometricL1Fn(Function):
         automask, reduce_op, n = ctx.meta
         up = g.reshape(1).to(torch.float32).contiguous()
         return ops.photometric_l1_backward(warped, target, rec, 1.0 / n, up, automask, reduce_op), None, None, None, None, None
+
+
+class WarpPhotometricFn(Function):
+    """Round 5: view synthesis FUSED into the photometric loss (csrc/loss.hip: pnsfm_photometric_warp_*): the photometric kernels
+    warp the J context images to the target view inside their tile loaders, backward pushes a pixel's gradient straight through the
+    bilinear sample and the projection -- neither `warped` nor its gradient ([J, B, 3, H, W] each) exists, and a scale is 2 + 2
+    launches instead of 3 + 3.  Differentiable w.r.t. inv_depth and the [J, B, 4, 4] pose matrices."""
+
+    @staticmethod
+    def forward(ctx, inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, padding_mode):
+        inv_depth, ref, target, K, refK, T = (t.contiguous() for t in (inv_depth, ref, target, K, refK, T))
+        J, B, _, H, W = ref.shape
+        loss, argmin = ops.photometric_warp_forward(inv_depth, ref, target, K, refK, T.detach(), ssim_w, C1, C2, automask, reduce_op,
+                                                    padding_mode)
+        ctx.save_for_backward(inv_depth, ref, target, K, refK, T, argmin)
+        ctx.meta = (ssim_w, C1, C2, automask, reduce_op, padding_mode, B * H * W)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        inv_depth, ref, target, K, refK, T, argmin = ctx.saved_tensors
+        ssim_w, C1, C2, automask, reduce_op, padding_mode, n = ctx.meta
+        up = g.reshape(1).to(torch.float32).contiguous()
+        d_inv, dT = ops.photometric_warp_backward(inv_depth, ref, target, K, refK, T.detach(), argmin, 1.0 / n, up, ssim_w, C1, C2, automask,
+                                                  reduce_op, padding_mode)
+        return d_inv, None, None, None, None, dT, None, None, None, None, None, None
+
+
+# Measured (profiles/r05_ab_loss_fuse.txt, same box, alternating): 162.7 img/s fused vs 163.2 two-step at 192x640 batch 4 -- the
+# 51 MB per step it stops moving are ~10 us of HBM time, while every tile re-projects its halo (1.27x the pixels forward, 1.56x
+# backward) and backward re-samples what the two-step path kept in `warped`.  Parked OFF (PNSFM_LOSS_FUSE=1 / set_loss_fuse(True));
+# both paths are pinned by the same goldens.
+_LOSS_FUSE = os.environ.get('PNSFM_LOSS_FUSE', '0') != '0'
+
+
+def set_loss_fuse(on):
+    global _LOSS_FUSE
+    _LOSS_FUSE = bool(on)
+
+
+def warp_photometric(inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0, padding_mode='zeros'):
+    """view_synthesis + photometric of one scale: two-step by default, the fused kernels (SSIM + L1 loss without clipping) behind
+    PNSFM_LOSS_FUSE=1."""
+    if padding_mode not in ops.PADDING_MODES:
+        raise ValueError('Unknown padding_mode {}'.format(padding_mode))
+    if _LOSS_FUSE and clip_loss == 0.0 and ssim_w > 0.0:
+        return WarpPhotometricFn.apply(inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, ops.PADDING_MODES[padding_mode])
+    warped = view_synthesis(inv_depth, ref, K, refK, T, padding_mode)
+    return photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
 
 
 def photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0):

@@ -149,12 +149,28 @@ def conv2d_forward(x, wp_fwd, bias, Cout, ks):
     return y
 
 
-def conv2d_backward_data(dy, wp_bwd, Cin, ks):
+def conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=None):
+    """dx [B,Cin,H,W]; addend (optional): the tensor's other gradient, added in the launch's epilogue -- [B,Cin,H,W], dense or a
+    channel slice of a wider dense tensor (any sample stride)."""
     _chk(dy, wp_bwd); _f32(dy, wp_bwd)
     B, Cout, H, W = dy.shape
     dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    rc = _lib.get().pnsfm_conv2d_backward_data(_ptr(dy), _ptr(wp_bwd), _ptr(dx), B, Cin, Cout, H, W, ks, _stream(dy))
-    _lib.check(rc, "conv2d_backward_data")
+    if addend is None:
+        rc = _lib.get().pnsfm_conv2d_backward_data(_ptr(dy), _ptr(wp_bwd), _ptr(dx), B, Cin, Cout, H, W, ks, _stream(dy))
+        _lib.check(rc, "conv2d_backward_data")
+        return dx
+    _f32(addend)
+    if addend.device != dy.device:
+        raise RuntimeError("conv2d_backward_data: addend lives on %s, dy on %s" % (addend.device, dy.device))
+    if tuple(addend.shape) != (B, Cin, H, W):
+        raise RuntimeError("conv2d_backward_data: addend %s does not match dx %s" % (tuple(addend.shape), (B, Cin, H, W)))
+    st = addend.stride()
+    if not (st[3] == 1 and st[2] == W and st[1] == H * W and (B == 1 or st[0] >= Cin * H * W)):
+        addend = addend.contiguous()
+        st = addend.stride()
+    rc = _lib.get().pnsfm_conv2d_backward_data_add(_ptr(dy), _ptr(wp_bwd), _ptr(dx), _ptr(addend), int(st[0]) if B > 1 else Cin * H * W, B,
+                                                   Cin, Cout, H, W, ks, _stream(dy))
+    _lib.check(rc, "conv2d_backward_data_add")
     return dx
 
 
@@ -609,6 +625,31 @@ def photometric_backward_dev(warped, target, argmin, grad_scale, upstream, ssim_
                                                          int(automask), int(reduce_op), int(bool(clip)), _stream(warped)),
                "photometric_backward_dev")
     return d_warped
+
+
+def photometric_warp_forward(inv_depth, ref, target, K, refK, T, ssim_weight, C1, C2, automask, reduce_op, padding_mode=0):
+    """View synthesis fused into the photometric loss -> (loss float32[1], argmin uint8[B,H,W])."""
+    _chk(inv_depth, ref, target, K, refK, T); _f32(inv_depth, ref, target, K, refK, T)
+    J, B, _, H, W = ref.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=ref.device)
+    argmin = torch.empty((B, H, W), dtype=torch.uint8, device=ref.device)
+    _lib.check(_lib.get().pnsfm_photometric_warp_forward(_ptr(inv_depth), _ptr(ref), _ptr(target), _ptr(K), _ptr(refK), _ptr(T), _ptr(loss),
+                                                         _ptr(argmin), J, B, H, W, float(ssim_weight), float(C1), float(C2), int(automask),
+                                                         int(reduce_op), int(padding_mode), _stream(ref)), "photometric_warp_forward")
+    return loss, argmin
+
+
+def photometric_warp_backward(inv_depth, ref, target, K, refK, T, argmin, grad_scale, upstream, ssim_weight, C1, C2, automask, reduce_op,
+                              padding_mode=0):
+    _chk(inv_depth, ref, target, K, refK, T, argmin, upstream); _f32(inv_depth, ref, target, K, refK, T, upstream)
+    J, B, _, H, W = ref.shape
+    d_inv = torch.empty_like(inv_depth)
+    dT = torch.empty_like(T)
+    _lib.check(_lib.get().pnsfm_photometric_warp_backward(_ptr(inv_depth), _ptr(ref), _ptr(target), _ptr(K), _ptr(refK), _ptr(T), _ptr(argmin),
+                                                          _ptr(d_inv), _ptr(dT), float(grad_scale), _ptr(upstream), J, B, H, W,
+                                                          float(ssim_weight), float(C1), float(C2), int(automask), int(reduce_op),
+                                                          int(padding_mode), _stream(ref)), "photometric_warp_backward")
+    return d_inv, dT
 
 
 def photometric_l1_forward(warped, ref, target, automask, reduce_op, clip_loss):

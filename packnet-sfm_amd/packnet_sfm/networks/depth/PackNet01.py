@@ -80,21 +80,32 @@ class PackNet01(nn.Module):
 
     def forward(self, rgb):
         """Inverse depth maps: list of 4 scales (training) or the full-resolution map (eval)."""
+        # (round 5) every tensor with a second consumer -- the five skip connections and the three decoder features that also feed an
+        # InvDepth head -- is read by that consumer through the gradient tap of the convolution that reads it first
+        # (layers01._HipConv2d.forward_tap): its two gradients meet inside a backward-data launch, not in an elementwise sum
         x = self.pre_calc(rgb)
-        x1p = self.pack1(self.conv1(x))
-        x2p = self.pack2(self.conv2(x1p))
-        x3p = self.pack3(self.conv3(x2p))
-        x4p = self.pack4(self.conv4(x3p))
-        x5p = self.pack5(self.conv5(x4p))
+        c1, x_s = self.conv1.forward_tap(x)
+        x1p = self.pack1(c1)
+        c2, x1p_s = self.conv2.forward_tap(x1p)
+        x2p = self.pack2(c2)
+        c3, x2p_s = self.conv3.forward_tap(x2p)
+        x3p = self.pack3(c3)
+        c4, x3p_s = self.conv4.forward_tap(x3p)
+        x4p = self.pack4(c4)
+        c5, x4p_s = self.conv5.forward_tap(x4p)
+        x5p = self.pack5(c5)
 
-        iconv5 = self.iconv5(self._merge(self.unpack5(x5p), x4p))
-        iconv4 = self.iconv4(self._merge(self.unpack4(iconv5), x3p))
-        disp4 = self.disp4_layer(iconv4)
-        iconv3 = self.iconv3(self._merge(self.unpack3(iconv4), x2p, disp4))
-        disp3 = self.disp3_layer(iconv3)
-        iconv2 = self.iconv2(self._merge(self.unpack2(iconv3), x1p, disp3))
-        disp2 = self.disp2_layer(iconv2)
-        iconv1 = self.iconv1(self._merge(self.unpack1(iconv2), x, disp2))
+        iconv5 = self.iconv5(self._merge(self.unpack5(x5p), x4p_s))
+        iconv4 = self.iconv4(self._merge(self.unpack4(iconv5), x3p_s))
+        up3, iconv4_t = self.unpack3.forward_tap(iconv4)
+        disp4 = self.disp4_layer(iconv4_t)
+        iconv3 = self.iconv3(self._merge(up3, x2p_s, disp4))
+        up2, iconv3_t = self.unpack2.forward_tap(iconv3)
+        disp3 = self.disp3_layer(iconv3_t)
+        iconv2 = self.iconv2(self._merge(up2, x1p_s, disp3))
+        up1, iconv2_t = self.unpack1.forward_tap(iconv2)
+        disp2 = self.disp2_layer(iconv2_t)
+        iconv1 = self.iconv1(self._merge(up1, x_s, disp2))
         disp1 = self.disp1_layer(iconv1)
 
         if self.training:

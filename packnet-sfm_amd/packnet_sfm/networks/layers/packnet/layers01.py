@@ -35,6 +35,11 @@ class _HipConv2d(nn.Conv2d):
             return HF.conv2d_cat(tuple(x), self.weight, self.bias, self._packed)
         return HF.conv2d(x, self.weight, self.bias, self._packed)
 
+    def forward_tap(self, x):
+        """(conv(x), x_tap): consumers of x other than this convolution read x_tap, and their gradient is added inside this
+        convolution's backward-data launch instead of by an elementwise pass (hip.functional.conv2d_tap)."""
+        return HF.conv2d_tap(x, self.weight, self.bias, self._packed)
+
 
 class Conv2D(nn.Module):
     """2D convolution (zero 'same' padding) + GroupNorm(16) + ELU.  `x` may be a tuple of tensors standing for their channel
@@ -50,6 +55,11 @@ class Conv2D(nn.Module):
         base, norm = self.conv_base, self.normalize
         # one autograd node and two launches: the conv kernel's epilogue leaves the GroupNorm statistics behind (HF.ConvGnActFn)
         return HF.conv2d_gn_act(x, base.weight, base.bias, norm.weight, norm.bias, base._packed, 16, norm.eps, _ops.ACT_ELU)
+
+    def forward_tap(self, x):
+        """(block(x), x_tap) for a single-tensor x -- see _HipConv2d.forward_tap."""
+        base, norm = self.conv_base, self.normalize
+        return HF.conv2d_gn_act_tap(x, base.weight, base.bias, norm.weight, norm.bias, base._packed, 16, norm.eps, _ops.ACT_ELU)
 
 
 class ResidualConv(nn.Module):
@@ -78,14 +88,22 @@ class ResidualConv(nn.Module):
                 state_dict[plain] = state_dict.pop(seq)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
+        """tap=True: (out, x_tap) -- x_tap is what a further consumer of x (a decoder skip) reads, see _HipConv2d.forward_tap."""
         # The 1x1 shortcut depends on the block input only and is launch-latency-sized (240-512 workgroups of a few microseconds:
         # tools/bx3_ablate.py puts its floor at 9-14 us whatever it computes), so it goes to the second compute stream
         # (hip/functional.py: shortcut_stream) underneath conv1 -> GroupNorm -> conv2; autograd replays its backward-data and
         # weight-gradient kernels on the same stream, underneath the main path's.  Same kernels and the same order of operations
         # within each result: bit-identical to the single-stream form (PNSFM_SHORTCUT_STREAM=0).
         side = HF.shortcut_stream(x)
-        if side is None:
+        x_tap = x
+        if side is None and HF.grad_taps() and isinstance(self.conv3, _HipConv2d):
+            # x feeds conv1 and the shortcut (and, through x_tap, maybe a skip connection): chained taps -- conv1's backward-data adds
+            # the skip's gradient, the shortcut's backward-data adds conv1's: no elementwise gradient sums (round 5)
+            shortcut, xa = self.conv3.forward_tap(x)
+            y1, x_tap = self.conv1.forward_tap(xa)
+            main = self.conv2(y1)
+        elif side is None:
             main = self.conv2(self.conv1(x))
             shortcut = self.conv3(x)
         else:
@@ -97,15 +115,27 @@ class ResidualConv(nn.Module):
             main = self.conv2(self.conv1(x))
             cur.wait_stream(side)
             shortcut.record_stream(cur)
-        return HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
-                                res=shortcut)
+        out = HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
+                               res=shortcut)
+        return (out, x_tap) if tap else out
+
+
+class _ResidualSequence(nn.Sequential):
+    """nn.Sequential of ResidualConv layers (same state-dict keys) that can hand out the gradient tap of its input."""
+
+    def forward_tap(self, x):
+        it = iter(self)
+        y, x_tap = next(it)(x, tap=True)
+        for m in it:
+            y = m(y)
+        return y, x_tap
 
 
 def ResidualBlock(in_channels, out_channels, num_blocks, stride, dropout=None):
     """`num_blocks` ResidualConv layers in sequence."""
     blocks = [ResidualConv(in_channels if i == 0 else out_channels, out_channels, stride if i == 0 else 1, dropout=dropout)
               for i in range(num_blocks)]
-    return nn.Sequential(*blocks)
+    return _ResidualSequence(*blocks)
 
 
 class InvDepth(nn.Module):
@@ -232,6 +262,11 @@ class UnpackLayerConv3d(nn.Module):
     def forward(self, x):
         feats = HF.conv3d_1to8(self.conv(x), self.conv3d.weight, self.conv3d.bias)
         return HF.depth_to_space(feats)
+
+    def forward_tap(self, x):
+        """(unpack(x), x_tap) -- see _HipConv2d.forward_tap (the decoder feature also feeds an InvDepth head)."""
+        y, x_tap = self.conv.forward_tap(x)
+        return HF.depth_to_space(HF.conv3d_1to8(y, self.conv3d.weight, self.conv3d.bias)), x_tap
 
 
 # names of the reference's module of the same path that the hot path does not re-implement (packnet_sfm/_merge.py)

@@ -175,3 +175,80 @@ def test_collapsed_pack_on_maps_smaller_than_two_strips(hw):
         gmax = max(float(v.abs().max()) for v in g0.values())
         for n in g0:    # (floor: the conv bias in front of the GroupNorm has a mathematically zero gradient -- round-off in both forms)
             assert float((g0[n] - g1[n]).abs().max()) <= 5e-4 * max(float(g0[n].abs().max()), 1e-2 * gmax), (k, hw, n)
+
+
+@pytest.mark.parametrize('shape,pad,automask,reduce_op', [((2, 4, 192, 640), 'zeros', True, 0), ((1, 1, 33, 65), 'border', False, 1),
+                                                         ((3, 2, 97, 131), 'reflection', True, 0), ((2, 3, 5, 7), 'zeros', False, 0)])
+def test_warp_photometric_fused(shape, pad, automask, reduce_op):
+    """Round 5: fused view synthesis + photometric kernels vs the two-step path (full bench size and ragged maps)."""
+    P.case_warp_photometric_fused('cuda', shape, pad, automask, reduce_op)
+
+
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_border', 'loss_reflection'])
+def test_loss_goldens_through_the_fused_kernels(name):
+    from packnet_sfm.hip import functional as HF
+    HF.set_loss_fuse(True)
+    try:
+        P.case_loss(name, 'cuda')
+    finally:
+        HF.set_loss_fuse(False)
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 192, 640), (4, 64, 96, 320), (2, 64, 384, 1280), (1, 19, 13, 70)])
+def test_invdepth_conv_strip_kernel_is_bit_identical(monkeypatch, shape):
+    """Round 5: strip form of the InvDepth forward kernel (what 192x640 / 96x320 run) vs the 64-pixel kernel: equal bits."""
+    from packnet_sfm.hip import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, generator=g).cuda()
+    w = (0.2 * torch.randn(1, C, 3, 3, generator=g)).cuda()
+    b = torch.randn(1, generator=g).cuda()
+    monkeypatch.setenv('PNSFM_INVDEPTH_STRIP', '0')
+    y0 = ops.invdepth_conv_forward(x, w, b, 0.5)
+    for mode in ('1', '4', '8'):
+        monkeypatch.setenv('PNSFM_INVDEPTH_STRIP', mode)
+        assert torch.equal(y0, ops.invdepth_conv_forward(x, w, b, 0.5)), mode
+    ref = torch.sigmoid(F.conv2d(x.double(), w.double(), b.double(), padding=1)) / 0.5
+    P.check(y0, ref.float(), 1e-5, 'invdepth fwd vs fp64')
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 64, 192, 640, 7), (4, 64, 64, 96, 320, 1), (4, 512, 512, 12, 40, 3), (2, 48, 33, 19, 40, 3)])
+def test_conv2d_backward_data_addend(shape):
+    """Round 5: dx = backward-data + addend inside the launch (epilogue or K-split second stage, whatever the tuned configuration of
+    the shape is): the bits of the separate elementwise sum, for a dense addend and for a channel slice of a wider tensor."""
+    from packnet_sfm.hip import ops
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1).cuda()
+    _, wb = ops.conv2d_pack(w)
+    dy = torch.randn(B, Cout, H, W, generator=g).cuda()
+    wide = torch.randn(B, Cin + 65, H, W, generator=g).cuda()
+    plain = ops.conv2d_backward_data(dy, wb, Cin, ks)
+    for addend in (wide[:, :Cin].contiguous(), wide[:, 64:64 + Cin]):
+        assert torch.equal(ops.conv2d_backward_data(dy, wb, Cin, ks, addend=addend), plain + addend)
+
+
+def test_gradient_taps_match_the_plain_graph_packnet01():
+    """PackNet01 forward + backward with the gradient taps (default) against the plain autograd graph (PNSFM_GRAD_TAPS=0 path)."""
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.networks.depth.PackNet01 import PackNet01
+    torch.manual_seed(5)
+    net = PackNet01(dropout=None, version='1A').cuda().train()
+    rgb = torch.rand(1, 3, 64, 128, device='cuda')
+    res = []
+    for taps in (True, False):
+        HF.set_grad_taps(taps)
+        try:
+            net.zero_grad()
+            out = net(rgb)['inv_depths']
+            loss = sum((d * d).mean() * (i + 1) for i, d in enumerate(out))
+            loss.backward()
+            res.append(([d.detach().clone() for d in out], {n: p.grad.clone() for n, p in net.named_parameters()}))
+        finally:
+            HF.set_grad_taps(True)
+    (o1, g1), (o0, g0) = res
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        P.check(g1[n], g0[n], 2e-4, n, floor=1e-3 * gmax)

@@ -458,6 +458,25 @@ def test_invdepth_conv_raw(emulated_kernels, shape):
     P.check(bd.grad, br.grad, 1e-5, 'invdepth db')
 
 
+@pytest.mark.parametrize('shape,R', [((2, 5, 7, 9), 4), ((1, 19, 13, 70), 8), ((1, 8, 9, 130), 4), ((2, 6, 16, 64), 8)])
+def test_invdepth_conv_strip_kernel_is_bit_identical(emulated_kernels, monkeypatch, shape, R):
+    """Round 5: the strip form of the InvDepth forward kernel (R rows x 64 columns per block, neighbours by wave shifts, XCD-ranged
+    block order) keeps the per-pixel accumulation order of the 64-pixel kernel: equal bits on ragged strips / rows / channel quarters."""
+    from packnet_sfm.hip import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + R)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = 0.2 * torch.randn(1, C, 3, 3, generator=g)
+    b = torch.randn(1, generator=g)
+    monkeypatch.setenv('PNSFM_INVDEPTH_STRIP', '0')
+    y0 = ops.invdepth_conv_forward(x, w, b, 0.5)
+    monkeypatch.setenv('PNSFM_INVDEPTH_STRIP', str(R))
+    y1 = ops.invdepth_conv_forward(x, w, b, 0.5)
+    assert torch.equal(y0, y1)
+    ref = torch.sigmoid(torch.nn.functional.conv2d(x, w, b, padding=1)) / 0.5
+    P.check(y1, ref, 1e-5, 'invdepth strip fwd')
+
+
 def test_supervised_loss(emulated_kernels):
     P.case_supervised_loss('cpu')
 
@@ -1133,3 +1152,84 @@ def test_conv2d_cat_multi_source(emulated_kernels, case):
     if case[1] in ((64, 1), (32, 33)):
         from packnet_sfm.hip import ops
         assert ops.conv2d_cat_wgrad_supported(list(case[1]), case[2], case[3], case[4], case[5], B=case[0])
+
+
+@pytest.mark.parametrize('shape,pad,automask,reduce_op', [((2, 2, 21, 37), 'zeros', True, 0), ((1, 1, 16, 16), 'border', False, 1),
+                                                         ((3, 1, 19, 50), 'reflection', True, 0), ((2, 3, 5, 7), 'zeros', False, 0)])
+def test_warp_photometric_fused(emulated_kernels, shape, pad, automask, reduce_op):
+    P.case_warp_photometric_fused('cpu', shape, pad, automask, reduce_op)
+
+
+@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_border', 'loss_reflection'])
+def test_loss_goldens_through_the_fused_kernels(emulated_kernels, name):
+    """The reference's loss goldens with view synthesis fused into the photometric kernels (PNSFM_LOSS_FUSE=1)."""
+    from packnet_sfm.hip import functional as HF
+    HF.set_loss_fuse(True)
+    try:
+        P.case_loss(name, 'cpu')
+    finally:
+        HF.set_loss_fuse(False)
+
+
+@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (1, 4, 1, 3), (2, 7, 0, 1), (1, 7, 1, 2), (2, 6, 0, 1)])
+@pytest.mark.parametrize('shape', [(2, 48, 64, 9, 32, 3), (2, 40, 33, 5, 24, 1), (1, 32, 40, 8, 32, 7)])
+def test_conv2d_backward_data_addend(emulated_kernels, shape, cfg):
+    """Round 5: dx = backward-data + addend in the launch's epilogue (un-split) / in the second stage of a K-split launch, for a dense
+    addend and for a channel slice of a wider tensor: the bits of the separate elementwise sum."""
+    import ctypes
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    NT, variant, narrow, split = cfg
+    lib.pnsfm_set_conv_math(1)
+    B, Cin, Cout, H, W, ks = shape
+    key = (ctypes.c_int * 7)(1 + 10 + 100, B, Cout, Cin, H, W, ks)
+    assert lib.pnsfm_tune_set(key, NT | (variant << 4) | (narrow << 8), split) == 0
+    g = torch.Generator().manual_seed(sum(shape) + sum(cfg))
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    _, wb = ops.conv2d_pack(w)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    wide = torch.randn(B, Cin + 7, H, W, generator=g)
+    try:
+        plain = ops.conv2d_backward_data(dy, wb, Cin, ks)
+        for addend in (wide[:, :Cin].contiguous(), wide[:, 5:5 + Cin], wide[:, 5:5 + Cin].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)):
+            got = ops.conv2d_backward_data(dy, wb, Cin, ks, addend=addend)
+            assert torch.equal(got, plain + addend)
+    finally:
+        lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
+
+
+def test_gradient_taps_match_the_plain_graph(emulated_kernels):
+    """Round 5: ResidualConv / Conv2D / UnpackLayerConv3d with gradient taps (the input's other consumers' gradient added inside the
+    convolution's backward-data launch) against the same modules on the plain autograd graph: outputs equal, every gradient close
+    (the three-consumer case associates the sum differently), and no zero tensor is materialised for an unused tap."""
+    from packnet_sfm.hip import functional as HF
+    from packnet_sfm.networks.layers.packnet.layers01 import ResidualBlock, Conv2D, UnpackLayerConv3d
+    torch.manual_seed(3)
+    blk, c2d, unp = ResidualBlock(32, 32, 2, 1), Conv2D(32, 32, 3, 1), UnpackLayerConv3d(32, 32, 3)
+    x0 = torch.randn(1, 32, 6, 8)
+    res = []
+    for taps in (True, False):
+        HF.set_grad_taps(taps)
+        try:
+            for m in (blk, c2d, unp):
+                m.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            h = x * 1.0                                     # a non-leaf producer, as in the network
+            y, h_s = blk.forward_tap(h)                     # encoder stage + its skip
+            z, y_t = c2d.forward_tap(y)                     # tensor with two consumers
+            u, z_t = unp.forward_tap(z)
+            loss = (u * u).sum() + (h_s * 0.3).sum() + (y_t * y_t).sum() * 0.1 + z_t.sum() * 0.2
+            loss.backward()
+            res.append((loss.detach(), x.grad.clone(), [p.grad.clone() for m in (blk, c2d, unp) for p in m.parameters()]))
+        finally:
+            HF.set_grad_taps(True)
+    (l1, g1, p1), (l0, g0, p0) = res
+    assert torch.equal(l1, l0)
+    P.check(g1, g0, 1e-5, 'd input')
+    for a, b in zip(p1, p0):
+        P.check(a, b, 1e-5, 'parameter gradient', floor=1e-6)
+    # an unused tap costs nothing: the block alone (tap output dropped) still trains
+    x = x0.clone().requires_grad_(True)
+    y, _ = blk.forward_tap(x * 1.0)
+    y.sum().backward()
+    assert x.grad is not None

@@ -482,8 +482,6 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
             ops.prof_enable(False)
             return ops.prof_collect(0), ops.prof_collect(1)
         res['timed'] = profiled(res['nprof'])
-        if rank == 0 and layer_table:
-            ops.prof_dump(layer_table)
         ws_on, br_on, sc_on = bool(HF._WgradStream.enabled), bool(HF._BRANCH_ON), bool(HF._SHORTCUT_ON)
         if ws_on or br_on or sc_on:     # side streams (the default): measure the kernels alone as well
             HF.set_wgrad_stream(False)
@@ -495,6 +493,10 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
             HF.set_shortcut_stream(sc_on)
         else:                           # every kernel already runs alone on the compute stream
             res['iso'] = res['timed']
+        # the per-launch table is the ISOLATED pass's (the library's buffer holds the last profiled pass): with the side streams on, a
+        # backward-data launch shares the GPU with a weight-gradient launch and the event pair around either reads ~1.4x long
+        if rank == 0 and layer_table:
+            ops.prof_dump(layer_table)
     return res
 
 
@@ -521,7 +523,7 @@ def main():
                          'single-GPU run appends to its JSON line as `extra`')
     ap.add_argument('--optimizer', default='flat', choices=['flat', 'torch'],
                     help="'flat': FlatAdam (one gfx950 adam_kernel launch per group); 'torch': torch.optim.Adam(fused=True)")
-    ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps here')
+    ap.add_argument('--layer-table', default='', help='write the per-launch conv table (CSV) of the profiled steps (the isolated pass: side streams off) here')
     args = ap.parse_args()
 
     if args.gpu_baseline_worker:          # child of gpu_eager_baseline_bounded: one JSON line, nothing else

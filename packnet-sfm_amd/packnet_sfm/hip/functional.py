@@ -502,7 +502,7 @@ class Conv2dFn(Function):
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=g_tap)
+            dx = _dgrad_tap(dy, wp_bwd, Cin, ks, g_tap)
         if want_w:
             dw, db = ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb)
         if wait is not None:
@@ -533,6 +533,14 @@ def set_grad_taps(on):
 
 def grad_taps():
     return _GRAD_TAPS
+
+
+def _dgrad_tap(dy, wp_bwd, Cin, ks, g_tap):
+    """backward-data (+ the tap's gradient).  The tap was granted at forward time under the arithmetic mode in force then; should the
+    mode have left 'bx3' since, the sum is formed the ordinary way instead of raising."""
+    if g_tap is not None and get_conv_math() != 'bx3':
+        return ops.conv2d_backward_data(dy, wp_bwd, Cin, ks) + g_tap
+    return ops.conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=g_tap)
 
 
 def _tap_ok(weight):
@@ -699,7 +707,7 @@ class ConvGnActFn(Function):
             (dw, db), wait = (r, None) if detached else r
             want_w = False
         if any(ctx.needs_input_grad[11:]):
-            dx = ops.conv2d_backward_data(dy, wp_bwd, Cin, ks, addend=g_tap if len(xs) == 1 else None)
+            dx = _dgrad_tap(dy, wp_bwd, Cin, ks, g_tap if len(xs) == 1 else None)
             if len(xs) == 1:
                 dxs[0] = dx
             else:

@@ -322,11 +322,19 @@ def measured_traffic(H, W, B):
                 continue
             if d.get('csrc_sha') != sha:
                 continue
-            k = d.get('pnsfm::conv2d_bx3_kernel') or d['pnsfm::conv2d_mfma_kernel']
-            alg = k.get('algorithmic_bytes_per_launch', 0)
-            return {'hbm_bytes_per_launch': round(k['hbm_bytes_per_launch']), 'algorithmic_bytes_per_launch': round(alg),
-                    'ratio_vs_algorithmic': round(k['hbm_bytes_per_launch'] / alg, 3) if alg else None,
-                    'fetch_bytes_corrected': round(k.get('fetch_bytes_per_launch', 0)), 'write_bytes': round(k.get('write_bytes_per_launch', 0)),
+            # the forward / backward-data implicit GEMM is two kernel names since round 5 (conv2d_bx3_kernel and the ping-pong
+            # workgroup conv2d_bx3pp_kernel): launch-weighted mean over both; the algorithmic bytes are the layer table's average
+            # over ALL forward / backward-data launches (tools/pmc_traffic.py files them under conv2d_bx3_kernel)
+            names = [n for n in ('pnsfm::conv2d_bx3_kernel', 'pnsfm::conv2d_bx3pp_kernel') if n in d] or ['pnsfm::conv2d_mfma_kernel']
+            ks = [d[n] for n in names]
+            nl = sum(k.get('launches_in_pass', 1) for k in ks)
+            mean = lambda key: sum(k.get(key, 0) * k.get('launches_in_pass', 1) for k in ks) / nl
+            alg = ks[0].get('algorithmic_bytes_per_launch', 0)
+            hbm = mean('hbm_bytes_per_launch')
+            return {'hbm_bytes_per_launch': round(hbm), 'algorithmic_bytes_per_launch': round(alg),
+                    'ratio_vs_algorithmic': round(hbm / alg, 3) if alg else None,
+                    'fetch_bytes_corrected': round(mean('fetch_bytes_per_launch')), 'write_bytes': round(mean('write_bytes_per_launch')),
+                    'kernels': {n: {'launches': k.get('launches_in_pass'), 'hbm_bytes_per_launch': round(k['hbm_bytes_per_launch'])} for n, k in zip(names, ks)},
                     'fetch_correction_factor': d.get('fetch_factor'), 'csrc_sha': sha, 'source': os.path.relpath(f, ROOT)}
         except Exception:
             continue

@@ -64,7 +64,11 @@ prof)
   (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r05_rocprof.log 2>&1)
   f=$(find $O/prof_r05 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r05_bench_kernel_stats.csv && head -12 $f | cut -c1-140
   t=$(find $O/prof_r05 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r05_step_breakdown.txt 2>&1 && head -8 $O/r05_step_breakdown.txt
-  rm -rf $O/prof_r05 ;;
+  rm -rf $O/prof_r05
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r05b -o bench -- python $R/bench.py --height 384 --width 1280 --batch 2 --steps 6 --warmup 2 $BARGS > $O/r05_rocprof_384.log 2>&1)
+  f=$(find $O/prof_r05b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r05_bench_kernel_stats_384x1280.csv
+  t=$(find $O/prof_r05b -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r05_step_breakdown_384x1280.txt 2>&1 && head -4 $O/r05_step_breakdown_384x1280.txt
+  rm -rf $O/prof_r05b ;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)

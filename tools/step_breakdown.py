@@ -12,7 +12,8 @@ for r in rows:
     r['s'] = int(r['Start_Timestamp'])
     r['e'] = int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name'] or 'adam_flat_kernel' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if 'FusedAdam' in r['Kernel_Name'] or 'adam_flat_kernel' in r['Kernel_Name']
+        or 'adam_pack_table_kernel' in r['Kernel_Name'] or 'adam_segments_kernel' in r['Kernel_Name']]      # (round 5: the fused optimizer tail)
 bursts, prev = [], None
 for i in adam:
     if prev is None or i - prev > 50:

@@ -402,6 +402,14 @@ def _slots_for(weight, bias, usable):
     return sw, sb
 
 
+def side_streams(device):
+    """The side streams gradients may still be in flight on (weight-gradient stream, independent-branch stream) -- for a consumer
+    that wants ITS stream to wait for them instead of joining them into the compute stream (rccl/reducer.py)."""
+    if device.type != 'cuda':
+        return []
+    return [st for st in (_WgradStream._streams.get(device), _BRANCH_STREAMS.get(device)) if st is not None]
+
+
 def join_wgrad_stream(device):
     """Make the current stream of `device` wait for every weight gradient launched so far (no-op when unused) and for the
     independent-branch stream (branch_stream) -- the gradient all-reduce calls this before it gathers a bucket in the middle

@@ -174,22 +174,35 @@ class GradBucketReducer:
             self._launch(b)
             self._next += 1
 
-    @staticmethod
-    def _gather(bucket):
+    def _gather(self, bucket):
         """Copy the bucket's gradients into its flat buffer with one multi-tensor launch and alias p.grad to the views."""
-        # weight gradients may still be in flight on the side stream of hip/functional.py:_WgradStream
+        # Weight gradients may still be in flight on the side streams of hip/functional.py (weight-gradient stream, pose branch).
+        # Round 5: with a communication stream, IT waits for them (and for the compute stream) and runs the gather copy itself --
+        # the compute stream is never joined in the middle of backward.  (Joining it here, once per bucket, serialised backward-data
+        # behind every outstanding weight gradient ten times per step: the 1-rank rehearsal ran 7.7 % under the plain step.)
         from packnet_sfm.hip import functional as HF
-        HF.join_wgrad_stream(bucket.flat.device)
-        src, dst = [], []
-        for p, v in zip(bucket.params, bucket.views):
-            g = p.grad
-            if g is None:
-                v.zero_()                               # unused parameter this step
-            elif g.data_ptr() != v.data_ptr():
-                src.append(g.detach())
-                dst.append(v)
-        if src:
-            torch._foreach_copy_(dst, src)
+        comm = self.side_stream
+        if comm is not None:
+            comm.wait_stream(torch.cuda.current_stream(self.device))
+            for st in HF.side_streams(self.device):
+                if st != comm:
+                    comm.wait_stream(st)
+        else:
+            HF.join_wgrad_stream(bucket.flat.device)
+        with (torch.cuda.stream(comm) if comm is not None else HF._nullctx()):
+            src, dst = [], []
+            for p, v in zip(bucket.params, bucket.views):
+                g = p.grad
+                if g is None:
+                    v.zero_()                               # unused parameter this step
+                elif g.data_ptr() != v.data_ptr():
+                    src.append(g.detach())
+                    dst.append(v)
+            if src:
+                torch._foreach_copy_(dst, src)
+                if comm is not None:
+                    for g in src:                           # read on the communication stream after p.grad lets go of them
+                        g.record_stream(comm)
         for p, v in zip(bucket.params, bucket.views):
             p.grad = v
 
@@ -249,9 +262,9 @@ class GradBucketReducer:
                 for w in b.work:
                     w.wait()                   # compute stream waits for the collective (stream-ordered, the host does not block)
                 b.work = None
-        if self.side_stream is not None and (self.world > 1 or self.force):
+        if self.side_stream is not None:           # (always: the gather copies run there even when no collective does)
             cur.wait_stream(self.side_stream)
-            if self._exposed is not None:
+            if self._exposed is not None and (self.world > 1 or self.force):
                 after = torch.cuda.Event(enable_timing=True)
                 after.record(cur)
                 self._exposed.append((before, after))

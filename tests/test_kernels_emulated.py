@@ -179,9 +179,13 @@ def test_conv2d_raw(emulated_kernels, shape, direct_a):
     P.check(db, br.grad, 1e-5, 'dbias')
 
 
-@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1), (1, 6, 0, 1), (2, 6, 1, 2),
-                                 (2, 7, 0, 1), (1, 7, 0, 2), (2, 7, 1, 3), (1, 7, 1, 1)])       # 7: ping-pong workgroup (conv2d_bx3pp.h)
-@pytest.mark.parametrize('shape', [(1, 48, 64, 9, 32, 3), (1, 40, 64, 20, 24, 5), (1, 32, 40, 8, 32, 7)])
+_PIN_CFGS = [(2, 3, 0, 1), (2, 3, 0, 2), (2, 4, 0, 2), (2, 5, 1, 1), (1, 4, 1, 3), (2, 0, 0, 2), (2, 2, 1, 1), (1, 6, 0, 1), (2, 6, 1, 2),
+             (2, 7, 0, 1), (1, 7, 0, 2), (2, 7, 1, 3), (1, 7, 1, 1)]       # 7: ping-pong workgroup (conv2d_bx3pp.h)
+
+
+# every configuration on the 3x3 shape; on the 5x5 / 7x7 shapes the ping-pong ones and every other one of the rest (CPU-suite time)
+@pytest.mark.parametrize('shape,cfg', [(sh, c) for i, sh in enumerate([(1, 48, 64, 9, 32, 3), (1, 40, 64, 20, 24, 5), (1, 32, 40, 8, 32, 7)])
+                                       for j, c in enumerate(_PIN_CFGS) if i == 0 or c[1] == 7 or (i + j) % 2 == 0])
 def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     """Configurations the un-tuned heuristics never pick for small test shapes (two pixel tiles per wave, narrow M tiles,
     K splits) pinned through pnsfm_tune_set -- what the autotuner does on the GPU: cfg = (NT, variant, narrow-M, K-split)."""
@@ -210,10 +214,15 @@ def test_conv2d_pinned_tilings(emulated_kernels, shape, cfg):
     lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
-@pytest.mark.parametrize('cfg', [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2),
-                                 (1, 7, 0, 1, 1), (2, 7, 1, 2, 1), (2, 7, 0, 1, 2)])
-@pytest.mark.parametrize('shape', [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7),
-                                   (1, 16, 32, 18, 64, 7), (1, 32, 16, 10, 32, 5)])
+_RB_CFGS = [(1, 3, 0, 1, 1), (2, 3, 0, 1, 1), (2, 4, 1, 2, 1), (1, 3, 0, 1, 2), (2, 5, 0, 1, 2), (2, 3, 1, 2, 2),
+            (1, 7, 0, 1, 1), (2, 7, 1, 2, 1), (2, 7, 0, 1, 2)]
+_RB_SHAPES = [(1, 32, 64, 12, 48, 3), (2, 48, 40, 7, 40, 3), (2, 16, 32, 6, 20, 5), (1, 32, 32, 9, 80, 7),
+              (1, 16, 32, 18, 64, 7), (1, 32, 16, 10, 32, 5)]
+
+
+# every configuration on the first 3x3 and the first 7x7 shape; a rotating third of them on the other four (CPU-suite time)
+@pytest.mark.parametrize('shape,cfg', [(sh, c) for i, sh in enumerate(_RB_SHAPES) for j, c in enumerate(_RB_CFGS)
+                                       if i in (0, 3) or (i + j) % 3 == 0])
 def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):
     """Tile modes of the split-bf16 kernels for maps whose width is not a multiple of 32 (24x80, 12x40, 6x20 in PackNet01), pinned
     like the autotuner does: cfg = (NT, variant, narrow-M, K-split, tile mode) with tile mode 1 = 16-wide rectangles (16 x 8*NT),
@@ -330,9 +339,11 @@ def test_conv2d_wgrad_split_bf16_pinned(emulated_kernels, shape, cfg):
     lib.pnsfm_set_wgrad_variant(-1)      # clears the pinned entry
 
 
-@pytest.mark.parametrize('cfg', [(1, 1, 0, 0), (2, 2, 4, 0), (3, 1, 5, 0), (2, 1, 0, 6), (5, 2, 0, 4)])
-@pytest.mark.parametrize('shape', [(1, 64, 64, 8, 32, 3), (2, 48, 70, 5, 40, 3), (2, 40, 24, 6, 20, 3), (1, 33, 129, 7, 80, 3),
-                                   (1, 16, 32, 9, 4, 3), (1, 130, 20, 9, 8, 3)])
+# every configuration on the first two shapes, a rotating 3 of 5 on the others (CPU-suite time)
+@pytest.mark.parametrize('shape,cfg', [(sh, c) for i, sh in enumerate([(1, 64, 64, 8, 32, 3), (2, 48, 70, 5, 40, 3), (2, 40, 24, 6, 20, 3), (1, 33, 129, 7, 80, 3),
+                                                                      (1, 16, 32, 9, 4, 3), (1, 130, 20, 9, 8, 3)])
+                                       for j, c in enumerate([(1, 1, 0, 0), (2, 2, 4, 0), (3, 1, 5, 0), (2, 1, 0, 6), (5, 2, 0, 4)])
+                                       if i < 2 or (i + j) % 5 in (0, 2, 3)])
 def test_conv2d_wgrad_nine_taps(emulated_kernels, shape, cfg):
     """The nine-taps-per-workgroup 3x3 weight gradient on the 16x16x32 MFMA (csrc/conv2d_wgrad4.hip) vs torch, pinned through
     pnsfm_tune_set (variant 3): cfg = (pixel split, ci tiles per workgroup, tile width in 8-pixel groups, tile rows; 0 = the
@@ -673,9 +684,9 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
     assert 3e-3 < moved <= 5e-3 * 1.2, moved     # ~lr * m/sqrt(v): the new lr (was 1e-2) took effect
 
 
-@pytest.mark.parametrize('variant', [3, 6, 7, 0])
-@pytest.mark.parametrize('shape', [(2, 32, 64, 9, 32, 3), (1, 16, 128, 6, 20, 3), (2, 48, 256, 5, 24, 3), (1, 32, 512, 4, 32, 1),
-                                   (2, 20, 64, 7, 40, 5)])
+# (every variant on the small shapes; the 256- / 512-channel ones -- channels per group 16 / 32 -- on the two kernels that ship)
+@pytest.mark.parametrize('shape,variant', [(sh, v) for sh in [(2, 32, 64, 5, 32, 3), (1, 16, 128, 6, 20, 3), (1, 20, 64, 7, 40, 5)] for v in (3, 6, 7, 0)] +
+                         [(sh, v) for sh in [(1, 48, 256, 5, 24, 3), (1, 32, 512, 4, 32, 1)] for v in (3, 7)])
 def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
     """Round 5: the Conv2D block as one autograd node whose conv epilogue leaves the GroupNorm statistics behind
     (hip.functional.ConvGnActFn, csrc/conv2d.hip: conv_epilogue, pnsfm_groupnorm_act_apply) against the two-node form (conv, then
@@ -759,9 +770,9 @@ def test_flat_adam_fused_tail(emulated_kernels):
         return [{'params': list(n.a.parameters()) + list(n.r.parameters()), 'lr': 1e-2, 'weight_decay': 1e-3},
                 {'params': list(n.c.parameters()) + list(n.side.parameters()), 'lr': 3e-3}]
     opts = [FlatAdam(groups(nets[0]), fused=False, overlap=False), FlatAdam(groups(nets[1]), fused=True, overlap=False)]
-    x = torch.randn(2, 16, 6, 32)
+    x = torch.randn(1, 16, 4, 32)
     used_fused = 0
-    for step in range(5):
+    for step in range(4):
         for net, opt in zip(nets, opts):
             opt.zero_grad()
             net(x, step != 2).backward()                 # step 2: `side` gets no gradient
@@ -1171,8 +1182,9 @@ def test_loss_goldens_through_the_fused_kernels(emulated_kernels, name):
         HF.set_loss_fuse(False)
 
 
-@pytest.mark.parametrize('cfg', [(2, 3, 0, 1), (1, 4, 1, 3), (2, 7, 0, 1), (1, 7, 1, 2), (2, 6, 0, 1)])
-@pytest.mark.parametrize('shape', [(2, 48, 64, 9, 32, 3), (2, 40, 33, 5, 24, 1), (1, 32, 40, 8, 32, 7)])
+@pytest.mark.parametrize('shape,cfg', [((2, 48, 64, 9, 32, 3), c) for c in [(2, 3, 0, 1), (1, 4, 1, 3), (2, 7, 0, 1), (1, 7, 1, 2), (2, 6, 0, 1)]] +
+                         [((2, 40, 33, 5, 24, 1), (2, 7, 0, 1)), ((2, 40, 33, 5, 24, 1), (1, 4, 1, 3)),
+                          ((1, 32, 40, 8, 32, 7), (1, 7, 1, 2)), ((1, 32, 40, 8, 32, 7), (2, 3, 0, 1))])
 def test_conv2d_backward_data_addend(emulated_kernels, shape, cfg):
     """Round 5: dx = backward-data + addend in the launch's epilogue (un-split) / in the second stage of a K-split launch, for a dense
     addend and for a channel slice of a wider tensor: the bits of the separate elementwise sum."""

@@ -252,3 +252,9 @@ def test_gradient_taps_match_the_plain_graph_packnet01():
     gmax = max(float(v.abs().max()) for v in g0.values())
     for n in g0:
         P.check(g1[n], g0[n], 2e-4, n, floor=1e-3 * gmax)
+
+
+def test_flat_adam_fused_tail_gpu():
+    """Round 5: the two-launch optimizer tail (Adam + re-pack from registers) against the flat update + batched re-pack on the GPU:
+    parameters, moments, step counters and both packed images bit for bit (same case as the emulated test)."""
+    P.case_flat_adam_fused_tail('cuda')

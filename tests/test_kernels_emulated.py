@@ -742,56 +742,7 @@ def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
 
 
 def test_flat_adam_fused_tail(emulated_kernels):
-    """Round 5: the two-launch optimizer tail (adam_pack_table_kernel + adam_segments_kernel; rccl/flat_adam.py: _fused_plan) against
-    the flat update + batched re-pack: parameters, moments, step counters and the PACKED weight copies bit for bit, over 3x3 / 1x1 / 5x5
-    convs with channel counts that are not multiples of 32, two parameter groups, weight decay, and a step on which one parameter
-    has no gradient (that step takes the plain path)."""
-    from packnet_sfm.hip import functional as HF
-    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D, ResidualConv
-    from packnet_sfm.rccl.flat_adam import FlatAdam
-
-    class Net(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.a = Conv2D(16, 48, 3, 1)
-            self.r = ResidualConv(48, 80, 1)            # 3x3, 3x3 and a 1x1 shortcut; 80 and 48 channels: ragged 32-wide tiles
-            self.c = Conv2D(80, 32, 5, 1)
-            self.side = torch.nn.Linear(4, 4)
-
-        def forward(self, x, use_side):
-            y = self.c(self.r(self.a(x))).pow(2).mean()
-            return y + self.side(x[:, 0, :4, :4]).sum() * 1e-3 if use_side else y
-
-    torch.manual_seed(11)
-    nets = [Net(), Net()]
-    nets[1].load_state_dict(nets[0].state_dict())
-
-    def groups(n):
-        return [{'params': list(n.a.parameters()) + list(n.r.parameters()), 'lr': 1e-2, 'weight_decay': 1e-3},
-                {'params': list(n.c.parameters()) + list(n.side.parameters()), 'lr': 3e-3}]
-    opts = [FlatAdam(groups(nets[0]), fused=False, overlap=False), FlatAdam(groups(nets[1]), fused=True, overlap=False)]
-    x = torch.randn(1, 16, 4, 32)
-    used_fused = 0
-    for step in range(4):
-        for net, opt in zip(nets, opts):
-            opt.zero_grad()
-            net(x, step != 2).backward()                 # step 2: `side` gets no gradient
-            opt.step()
-        used_fused += opts[1]._plan is not None and step != 2
-        for (n, pa), pb in zip(nets[0].named_parameters(), nets[1].parameters()):
-            assert torch.equal(pa.detach(), pb.detach()), 'step %d: %s differs between the fused and the plain tail' % (step, n)
-        for ga, gb in zip(opts[0].param_groups, opts[1].param_groups):
-            for k in ('_m', '_v', '_hp'):
-                assert torch.equal(ga[k], gb[k]), (step, k)
-        # the packed copies: same bytes, and stamped fresh (the next forward packs nothing)
-        for ma, mb in zip(nets[0].modules(), nets[1].modules()):
-            ca, cb = getattr(ma, '_packed', None), getattr(mb, '_packed', None)
-            if ca is not None and ca.wp_fwd is not None and ca.wp_bwd is not None:
-                assert torch.equal(ca.wp_fwd, cb.wp_fwd) and torch.equal(ca.wp_bwd, cb.wp_bwd), 'packed copies differ at step %d' % step
-                assert cb.key_fwd == HF.PackedConvWeight.key_of(mb.weight)
-    assert used_fused >= 3 and opts[1]._plan[2] >= 4, (used_fused, opts[1]._plan and opts[1]._plan[2])
-    for opt in opts:
-        opt._slots.remove()
+    P.case_flat_adam_fused_tail('cpu')
 
 
 def test_flat_adam_update_underneath_backward(emulated_kernels):

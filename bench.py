@@ -555,6 +555,8 @@ def main():
     ndev = torch.cuda.device_count()
     device = torch.device('cuda', hvd.local_rank() % ndev)
     torch.cuda.set_device(device)
+    if os.environ.get('PNSFM_MAIN_PRIORITY'):      # experiment: the step on a high-priority compute stream (profiles/r05_ab_side_priority.txt)
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ['PNSFM_MAIN_PRIORITY'])))
 
     H, W, B = args.height, args.width, args.batch
     model = build_model(device, args.depth_net)

@@ -194,6 +194,12 @@ class _nullctx:
         return False
 
 
+# HIP priority of the weight-gradient side stream (torch numbering: 0 = lowest, negative = higher).  The data gradient on the compute
+# stream is the critical path of backward; PNSFM_SIDE_PRIORITY exists to measure whether the dispatcher honours that
+# (profiles/r05_ab_side_priority.txt).
+_SIDE_PRIORITY = int(os.environ.get('PNSFM_SIDE_PRIORITY', '0'))
+
+
 class _WgradStream:
     """Weight gradients on a side HIP stream.  ON by default since round 5 (PNSFM_WGRAD_STREAM=0 switches it off): most launches of
     the backward pass are resident in ONE round of workgroups (tools/bx3_ablate.py: prologue -> matrix work -> store burst, all
@@ -285,7 +291,7 @@ class _WgradStream:
     def get(cls, device):
         st = cls._streams.get(device)
         if st is None:
-            st = cls._streams[device] = torch.cuda.Stream(device=device)
+            st = cls._streams[device] = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
         return st
 
     @classmethod

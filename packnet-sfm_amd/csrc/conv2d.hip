@@ -1177,6 +1177,9 @@ static float time_on_stream(hipStream_t stream, int reps, F fn) {
 }
 #endif
 
+// configuration of the calling thread's most recent forward / backward-data launch (pnsfm_conv2d_last_config)
+static thread_local std::array<int, 8> g_last_conv = {-1, 0, 0, 0, 0, 0, 0, 0};
+
 static int launch_conv(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout,
                        int H, int W, int ks, hipStream_t stream, const char* what, int kind_tag, int S = 1, int Hi = 0,
                        int Wi = 0, const ConvSrc* ms = nullptr, ConvGnOut* gn = nullptr) {
@@ -1244,6 +1247,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
+  g_last_conv = {g.DMA, g.NT, g.MT, g.G, g.splitK, g.mode == 2 ? (g.TW == 16 ? 1 : 2) : 0, meta[7], (int)g.smem_bytes};
   prof_begin(0, flops, stream, meta);
   const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi, ms, gn);
   prof_end(0, stream);
@@ -2090,6 +2094,12 @@ int pnsfm_set_conv_math(int mode) {
   return prev;
 }
 int pnsfm_get_conv_math(void) { return conv_math(); }
+
+int pnsfm_conv2d_last_config(int* out8) {
+  if (!out8) { set_error("conv2d_last_config: null pointer"); return -1; }
+  for (int i = 0; i < 8; ++i) out8[i] = g_last_conv[i];
+  return g_last_conv[0] < 0 ? 1 : 0;
+}
 
 int pnsfm_tune_shipped_entries(void) {
   (void)autotune_enabled();      // first call reads the environment / the shipped database

@@ -1,0 +1,228 @@
+"""GPU (MI355X): round-6 parity pins.
+
+The ping-pong workgroup (csrc/conv2d_bx3pp.h, tuner variant 7) pinned ON THE DEVICE against the oracle's convolution.  The host
+emulator (tests/test_kernels_emulated.py) runs workgroups serially and cannot see what is new in this kernel: the barrier in front
+of the last tap's MFMAs, the in-place overwrite of a group's single patch buffer, lgkmcnt-only barriers with LDS-DMA in flight,
+zero-filled ragged stages, the idle second group of an odd tile count.  Every case pins the configuration through pnsfm_tune_set and
+asserts with pnsfm_conv2d_last_config that variant 7 is what ran (a pin that does not fit a shape falls back silently).
+Reference op: nn.Conv2d of packnet_sfm/networks/layers/packnet/layers01.py:28-36 (+ its autograd backward-data)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), 'these tests need an MI355X'
+    from packnet_sfm.hip import _lib
+    assert _lib.get().pnsfm_build_target() == b'gfx950'
+    assert _lib.REQUIRE_CUDA
+
+
+def _cfg(NT, variant, narrow=0, tm=0):
+    return NT | (variant << 4) | (narrow << 8) | (tm << 9)
+
+
+def _pin(lib, kind, B, K, M, H, W, ks, v0, split):
+    key = (ctypes.c_int * 7)(kind + 10 + 100, B, K, M, H, W, ks)
+    assert lib.pnsfm_tune_set(key, v0, split) == 0
+
+
+def _last(lib):
+    out = (ctypes.c_int * 8)()
+    assert lib.pnsfm_conv2d_last_config(out) == 0
+    return dict(zip(('variant', 'NT', 'MT', 'G', 'split', 'tm', 'blocks', 'lds'), list(out)))
+
+
+def _data(shape, seed_extra=0):
+    B, Cin, Cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(sum(shape) + seed_extra)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    return x, w, b, dy
+
+
+# (shape, (NT, narrow, tile mode), K-split forward, K-split backward-data).  The first five are the shipped database's own variant-7
+# decisions at BASELINE.json configs[1] (csrc/tuned_gfx950.db); then an odd number of pixel tiles (group 1 of the last workgroup
+# idles), a 7x7 whose 49 taps leave a ragged last stage at G = 3 on a map with ragged tiles, the 32-row M tile and a 1-round launch.
+PP_CASES = [
+    ((4, 64, 64, 192, 640, 7), (2, 0, 1), 1, 1),        # conv1 -- 626 1 in the database
+    ((4, 256, 64, 96, 320, 7), (2, 0, 1), 1, 1),        # pack1 collapsed 7x7
+    ((4, 8192, 256, 12, 40, 3), (2, 0, 2), 16, 1),      # pack4.conv, K split 16 -- 1138 16
+    ((4, 512, 128, 24, 80, 5), (2, 0, 2), 8, 2),        # pack3 collapsed 5x5, split 8 -- 1138 8
+    ((4, 129, 64, 192, 640, 3), (2, 0, 0), 1, 1),       # iconv1 (129 K-channels: a nearly empty ninth chunk)
+    ((4, 256, 256, 24, 80, 3), (1, 1, 1), 1, 1),        # conv4 body -- 881 1 (NT 1, 32-row tiles, rectangles)
+    ((3, 64, 64, 36, 96, 3), (2, 0, 0), 1, 1),          # 3 x ceil(36/8) x 3 = 45 pixel tiles: odd -> the last workgroup's group 1 idles
+    ((1, 64, 64, 40, 80, 3), (2, 0, 1), 1, 1),          # 5 x 3 = 15 rectangle tiles: odd
+    ((1, 48, 64, 28, 72, 7), (2, 0, 1), 1, 1),          # 7x7, G = 3: 16 full stages + 1 ragged; ragged tiles in both directions
+    ((2, 112, 64, 13, 40, 5), (2, 0, 2), 3, 2),         # 5x5 row bands, ragged last band, K split 3 of 7 chunks (3 + 3 + 1)
+    ((2, 512, 512, 12, 40, 3), (2, 0, 2), 8, 8),        # conv5 body
+]
+
+
+@pytest.mark.parametrize('case', PP_CASES, ids=lambda c: 'x'.join(map(str, c[0])))
+def test_pingpong_kernel_vs_cpu_oracle(case):
+    """Forward AND backward-data of the ping-pong kernel against the oracle's convolution at 2e-5 (the tolerance of the other
+    variants in test_gpu_parity.py::test_conv2d_vs_cpu_oracle), on the configurations the shipped database takes."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    shape, (NT, narrow, tm), split_f, split_b = case
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b, dy = _data(shape)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    yr.backward(dy)
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    wf, wb = ops.conv2d_pack(wd)
+    try:
+        _pin(lib, 0, B, Cin, Cout, H, W, ks, _cfg(NT, 7, narrow, tm), split_f)
+        _pin(lib, 1, B, Cout, Cin, H, W, ks, _cfg(NT, 7, narrow, tm), split_b)
+        y = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+        c = _last(lib)
+        assert c['variant'] == 7 and c['NT'] == NT and c['split'] == split_f, c
+        dx = ops.conv2d_backward_data(dyd, wb, Cin, ks)
+        c = _last(lib)
+        assert c['variant'] == 7 and c['split'] == split_b, c
+        P.check(y, yr, 2e-5, 'fwd (ping-pong)')
+        P.check(dx, xr.grad, 2e-5, 'dgrad (ping-pong)')
+    finally:
+        lib.pnsfm_set_conv_variant(3)      # clears the pinned entries
+
+
+@pytest.mark.parametrize('channels', [(64, 128, 1), (64, 64, 1), (32, 32, 0)])
+def test_pingpong_kernel_multi_source(channels):
+    """The decoder's concatenations folded into the K loop (pnsfm_conv2d_forward_cat: iconv3 = cat(unpack3, skip3, up(disp4)),
+    PackNet01.py:150-168) through the ping-pong kernel against conv(cat(...)) on the CPU."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    C = [c for c in channels if c]
+    Cin, Cout, B, H, W, ks = sum(C), 128, 2, 48, 160, 3
+    g = torch.Generator().manual_seed(Cin)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in C]
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    yr = F.conv2d(torch.cat(xs, 1), w, b, padding=1)
+    wf, _ = ops.conv2d_pack(w.to(DEV), want_bwd=False)
+    try:
+        _pin(lib, 0, B, Cin, Cout, H, W, ks, _cfg(2, 7), 2)
+        y = ops.conv2d_forward_cat([t.to(DEV) for t in xs], wf, b.to(DEV), Cout, ks)
+        c = _last(lib)
+        assert c['variant'] == 7 and c['split'] == 2, c
+        P.check(y, yr, 2e-5, 'fwd cat (ping-pong)')
+    finally:
+        lib.pnsfm_set_conv_variant(3)
+
+
+@pytest.mark.parametrize('shape,pp', [((1, 64, 64, 48, 160, 7), (2, 0, 1, 1)), ((1, 64, 64, 48, 160, 7), (2, 0, 1, 4)),
+                                      ((1, 2048, 64, 24, 80, 5), (2, 0, 2, 4)), ((4, 512, 512, 6, 20, 3), (1, 1, 2, 4))])
+def test_pingpong_error_vs_fp64(shape, pp):
+    """The fp64 error study of test_conv2d_bx3_error_vs_fp64 for variant 7, with both arithmetics pinned to the SAME K split: the
+    error of either kernel follows the length of its fp32 accumulation chain (profiles/r06_pp_err_probe.txt: 5.8e-7 / 2.6e-7 /
+    2.1e-7 of sum |x||w| for the f32-MFMA kernel of the 7x7 shape at K split 1 / 2 / 4, 4.9e-7 / 2.4e-7 / 2.0e-7 for every split-bf16
+    variant), so a comparison across different splits says nothing about the arithmetic.  At equal split the six-product arithmetic
+    must stay within 1.25x of the f32 instruction's error (measured 0.55-0.94x) and below 1e-6 outright; plain bf16 sits at ~4e-4."""
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    NT, narrow, tm, split = pp
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, Cin, 1, 1, generator=g))      # mixed magnitudes
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * (2.0 / (Cin * ks * ks)) ** 0.5
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    y64 = F.conv2d(x.double(), w.double(), padding=ks // 2)
+    ymag = F.conv2d(x.double().abs(), w.double().abs(), padding=ks // 2)
+    dx64 = F.conv_transpose2d(dy.double(), w.double(), padding=ks // 2)
+    dxmag = F.conv_transpose2d(dy.double().abs(), w.double().abs(), padding=ks // 2)
+    err = {}
+    try:
+        for mode in ('f32', 'pp'):
+            HF.set_conv_math('f32' if mode == 'f32' else 'bx3')
+            for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+                key = (ctypes.c_int * 7)(kind + 10 + (100 if mode == 'pp' else 0), B, K, M, H, W, ks)
+                v0 = _cfg(NT, 7, narrow, tm) if mode == 'pp' else _cfg(1, 0)
+                assert lib.pnsfm_tune_set(key, v0, split) == 0
+            wf, wb = ops.conv2d_pack(w.to(DEV))
+            y = ops.conv2d_forward(x.to(DEV), wf, None, Cout, ks).cpu().double()
+            c = _last(lib)
+            assert c['variant'] == (7 if mode == 'pp' else 0) and c['split'] == split, c
+            dx = ops.conv2d_backward_data(dy.to(DEV), wb, Cin, ks).cpu().double()
+            c = _last(lib)
+            assert c['variant'] == (7 if mode == 'pp' else 0) and c['split'] == split, c
+            err[mode] = (float(((y - y64).abs() / ymag).max()), float(((dx - dx64).abs() / dxmag).max()))
+    finally:
+        HF.set_conv_math('bx3')
+        lib.pnsfm_set_conv_variant(0)
+        lib.pnsfm_set_conv_variant(3)
+    print('K split %d: max |err| / sum|a||b|  (fwd, dgrad):  f32 MFMA %.2e %.2e   ping-pong %.2e %.2e   [2^-24 = 5.96e-08]'
+          % ((split,) + err['f32'] + err['pp']))
+    for i in range(2):
+        assert err['pp'][i] <= max(1.25 * err['f32'][i], 1.5e-7), err
+        assert err['pp'][i] <= 1e-6, err
+
+
+@pytest.mark.parametrize('shape,NT,tm,split', [((4, 64, 64, 96, 320, 3), 2, 0, 1), ((2, 64, 64, 48, 160, 7), 2, 1, 1),
+                                                ((4, 512, 128, 24, 80, 5), 2, 2, 8), ((2, 256, 256, 24, 80, 3), 1, 1, 1)])
+def test_pingpong_bit_identical_to_single_tile_kernel(shape, NT, tm, split):
+    """conv2d_bx3pp.h's header: "bit-identical results for the same chunk order" -- a pixel tile accumulates the same piece products
+    in the same order (chunks ascending, taps ascending, l-m-h pieces) as conv2d_bx3_kernel does with the same (NT, tile mode,
+    K-split): torch.equal between variant 7 and variant 3 on the device."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b, dy = _data(shape, 3)
+    xd, bd, dyd = x.to(DEV), b.to(DEV), dy.to(DEV)
+    wf, wb = ops.conv2d_pack(w.to(DEV))
+    narrow = 1 if NT == 1 else 0
+    out = {}
+    try:
+        for variant in (3, 7):
+            _pin(lib, 0, B, Cin, Cout, H, W, ks, _cfg(NT, variant, narrow, tm), split)
+            _pin(lib, 1, B, Cout, Cin, H, W, ks, _cfg(NT, variant, narrow, tm), split)
+            y = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+            assert _last(lib)['variant'] == variant, _last(lib)
+            dx = ops.conv2d_backward_data(dyd, wb, Cin, ks)
+            assert _last(lib)['variant'] == variant, _last(lib)
+            out[variant] = (y, dx)
+    finally:
+        lib.pnsfm_set_conv_variant(3)
+    assert torch.equal(out[3][0], out[7][0]), 'forward: max |d| %.3e' % float((out[3][0] - out[7][0]).abs().max())
+    assert torch.equal(out[3][1], out[7][1]), 'backward-data: max |d| %.3e' % float((out[3][1] - out[7][1]).abs().max())
+
+
+@pytest.mark.parametrize('shape,NT,tm,split', [((4, 64, 64, 192, 640, 7), 2, 1, 1), ((4, 8192, 256, 12, 40, 3), 2, 2, 16),
+                                                ((3, 64, 64, 36, 96, 3), 2, 0, 1)])
+def test_pingpong_repeated_launches_are_bit_identical(shape, NT, tm, split):
+    """Races are intermittent: 50 launches of one shape (other kernels of the library in between, so that the workgroups meet
+    different neighbours and LDS contents) must all return the bits of the first."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b, dy = _data(shape, 5)
+    xd, bd = x.to(DEV), b.to(DEV)
+    wf, _ = ops.conv2d_pack(w.to(DEV), want_bwd=False)
+    noise = torch.randn(2, 64, 48, 160, device=DEV)
+    nwf, _ = ops.conv2d_pack(torch.randn(64, 64, 3, 3, device=DEV), want_bwd=False)
+    try:
+        _pin(lib, 0, B, Cin, Cout, H, W, ks, _cfg(NT, 7, 0, tm), split)
+        y0 = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+        assert _last(lib)['variant'] == 7
+        bad = 0
+        for it in range(50):
+            if it % 3 == 0:
+                ops.conv2d_forward(noise, nwf, None, 64, 3)          # leaves other data in LDS / other weights in L2
+            y = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+            bad += int(not torch.equal(y, y0))
+        assert bad == 0, '%d of 50 launches differ from the first' % bad
+    finally:
+        lib.pnsfm_set_conv_variant(3)
+    # and the first launch is right
+    P.check(y0, F.conv2d(x, w, b, padding=ks // 2), 2e-5, 'fwd')

@@ -197,7 +197,7 @@ def cpu_baseline(H, W, seconds_budget=75.0):
                          H, W, nb, best_th, len(times))}
 
 
-def gpu_eager_baseline(H, W, B, device, seconds_budget=90.0):
+def gpu_eager_baseline(H, W, B, device, seconds_budget=90.0, wait_for_go=False):
     """Like-for-like GPU baseline: the reference path's math through STOCK PyTorch-ROCm eager
     ops (MIOpen / ATen, fp32) on this same MI355X -- the full training step incl. torch.optim.Adam.  The GPU box has no
     /root/reference, so the ops are driven by oracle/packnet_oracle.py, the torch restatement of the reference's modules that
@@ -223,6 +223,13 @@ def gpu_eager_baseline(H, W, B, device, seconds_budget=90.0):
     step()
     torch.cuda.synchronize()
     warm = time.perf_counter() - t_start
+    if wait_for_go:
+        # the parent times its CPU baseline on the host cores meanwhile: the timed steps below are host-launch-bound eager steps
+        # and must not share the cores with it -- block until the parent says go (or closes the pipe)
+        sys.stdin.readline()
+        t_start = time.perf_counter()
+        step()                       # one more untimed step: clocks and caches back to the loaded state after the wait
+        torch.cuda.synchronize()
     times = []
     while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < seconds_budget):
         t0 = time.perf_counter()
@@ -245,8 +252,20 @@ def gpu_eager_baseline_start(H, W, B):
     first-use kernel compilation (~260 s on a fresh box) behind work the default run does anyway."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--gpu-baseline-worker', '%d,%d,%d' % (H, W, B)]
+    # MIOpen's first-use compilation is host work: the child is confined to the LAST cores of the box (at most 8, at most a quarter
+    # of them) so that the CPU baseline leg, which runs meanwhile on up to 64 threads, keeps cores of its own (ADVICE r05)
+    ncpu = os.cpu_count() or 8
+    keep = max(1, min(8, ncpu // 4))
+    cpus = set(range(ncpu - keep, ncpu))
+
+    def confine():
+        try:
+            os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            pass
     try:
-        return (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True, text=True), time.time())
+        return (subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True,
+                                 text=True, preexec_fn=confine), time.time())
     except OSError as e:
         return (None, 'could not start the baseline process: %s' % e)
 
@@ -266,7 +285,7 @@ def gpu_eager_baseline_finish(handle, H, W, B, value, budget_s):
     else:
         try:
             left = None if budget_s is None else max(1.0, budget_s - (time.time() - t_start))
-            out, _ = p.communicate(timeout=left)
+            out, _ = p.communicate(input='go\n', timeout=left)      # the CPU leg is over: the child may time its steps now
             line = [ln for ln in out.splitlines() if ln.startswith('{')]
             res = json.loads(line[-1]) if line else None
             if res is None:
@@ -288,7 +307,8 @@ def gpu_eager_baseline_finish(handle, H, W, B, value, budget_s):
                 continue
     if res.get('value'):
         res['speedup_of_value'] = round(value / res['value'], 2)
-        res['measured'] = 'in this run, on this GPU (child process, concurrent with the cpu_baseline leg on the host cores)'
+        res['measured'] = ('in this run, on this GPU: a child process whose MIOpen warm-up step ran beside the cpu_baseline leg (confined '
+                           'to the last <= 8 host cores) and whose timed steps ran after that leg had finished')
     elif (res.get('recorded') or {}).get('value'):
         res['speedup_vs_recorded'] = round(value / res['recorded']['value'], 2)
     return res
@@ -339,6 +359,116 @@ def measured_traffic(H, W, B):
         except Exception:
             continue
     return None
+
+
+def _gpu_sysfs_dir(device):
+    """hwmon directory of `device` in sysfs (freq1_input = sclk in Hz, power1_input = socket power in uW), found through the PCI
+    address torch reports; None when the box does not expose it."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        addr = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        hw = glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % addr)
+        return hw[0] if hw and os.path.exists(os.path.join(hw[0], 'freq1_input')) else None
+    except Exception:
+        return None
+
+
+class ClockSampler:
+    """Shader clock and socket power of the GPU, read from sysfs by a background thread every 20 ms while a region runs (one pread
+    of two tiny files per sample: ~30 us of host time, 0.15 % of a core)."""
+
+    def __init__(self, device):
+        self.dir = _gpu_sysfs_dir(device)
+        self.rows = []
+        self._stop = None
+
+    def _read(self):
+        try:
+            f = int(open(os.path.join(self.dir, 'freq1_input')).read()) / 1e6
+            pw = int(open(os.path.join(self.dir, 'power1_input')).read()) / 1e6
+            return f, pw
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+        if self.dir is None:
+            return self
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                r = self._read()
+                if r:
+                    self.rows.append(r)
+                self._stop.wait(0.02)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._stop is not None:
+            self._stop.set()
+            self._th.join()
+        return False
+
+    def summary(self):
+        if not self.rows:
+            return None
+        fr, pw = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        return {'sclk_mhz_avg': round(sum(fr) / len(fr), 1), 'sclk_mhz_min': round(min(fr), 1), 'sclk_mhz_max': round(max(fr), 1),
+                'power_w_avg': round(sum(pw) / len(pw), 1), 'power_w_max': round(max(pw), 1), 'samples': len(fr),
+                'source': 'sysfs hwmon freq1_input / power1_input of this GPU, one sample per 20 ms'}
+
+
+def box_calibration(device):
+    """What THIS box sustains, measured right before the timed region (the driver's lease and the builder's leases
+    of the same SKU differ by 5 %, more than a round of kernel work moves): (a) the bare six-product bf16 MFMA stream of the split
+    arithmetic, operands in registers (csrc/calib.hip; ~0.5 s of it, the sustained second half quoted) in fp32-equivalent TFLOP/s -- the ceiling the conv kernels
+    would reach with nothing but their MFMAs; (b) a 1 GiB -> 1 GiB float4 streaming copy in GB/s; (c) shader clock and socket power
+    while (a) ran.  `roofline.frac_vs_box` divides by (a) instead of the guide's 2500 / 6."""
+    from packnet_sfm.hip import ops
+    sink = torch.empty(1024 * 256, dtype=torch.float32, device=device)
+    ops.calib_mfma(sink, 1024, 200)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ~0.5 s of the loop in 8 segments of 8 launches (~7 ms each): a burst of a few tens of ms runs at clocks the power limit has not
+    # caught up with yet (372 fp32-equivalent TFLOP/s measured that way against 306 sustained), so the figure quoted is the rate over
+    # the LAST half of the run and the first segment is kept next to it as `mfma_tflops_burst`
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+    per_seg = 0.0
+    with ClockSampler(device) as cs:
+        evs[0].record()
+        for seg in range(8):
+            per_seg = 0.0
+            for _ in range(8):
+                per_seg += ops.calib_mfma(sink, 1024, 4000)
+            evs[seg + 1].record()
+        torch.cuda.synchronize(device)
+    ms = evs[4].elapsed_time(evs[8])
+    bf16_tf = 4 * per_seg / (ms * 1e-3) / 1e12
+    burst_tf = per_seg / (evs[0].elapsed_time(evs[1]) * 1e-3) / 1e12
+    ms_total = evs[0].elapsed_time(evs[8])
+    n = (1 << 30) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+    dst = torch.empty_like(src)
+    best = 0.0
+    for i in range(4):
+        e0.record()
+        nbytes = ops.calib_copy(src, dst)
+        e1.record()
+        torch.cuda.synchronize(device)
+        if i:
+            best = max(best, nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst, sink
+    torch.cuda.empty_cache()
+    return {'mfma_tflops': round(bf16_tf / 6.0, 1), 'mfma_bf16_tflops': round(bf16_tf, 1), 'mfma_tflops_burst': round(burst_tf / 6.0, 1),
+            'mfma_loop_ms': round(ms_total, 1),
+            'hbm_gbps': round(best, 1),
+            'clocks_during_mfma_loop': cs.summary(),
+            'what': 'six-product v_mfma_f32_32x32x16_bf16 stream with register operands (fp32-equivalent = bf16 rate / 6) and a 1 GiB '
+                    'float4 streaming copy (read + write bytes), both on this GPU right before the timed region (csrc/calib.hip)'}
 
 
 def _self_launch(args):
@@ -447,11 +577,16 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
     reducer = getattr(optimizer, '_reducer', None)
     if reducer is not None:
         reducer.exposed_reset(True)        # events around the end-of-backward join: all-reduce time NOT hidden behind backward
+    sampler = ClockSampler(device) if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     exposed = reducer.exposed_ms() if reducer is not None else None
     if reducer is not None:
         reducer.exposed_reset(False)
@@ -460,6 +595,7 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = {'elapsed': elapsed, 'loss': float(loss.detach().float().item()), 'timed': None, 'iso': None, 'nprof': 3,
+           'clocks': sampler.summary() if sampler is not None else None,
            'exposed_allreduce_ms_per_step': (round(exposed / steps, 4) if exposed is not None else None)}
     # Host-issue headroom: wall time of the Python + ctypes + hipLaunchKernel work that ENQUEUES one step, measured
     # with an empty GPU queue in front of it (fence, then one step, clock stopped when the last launch call returns -- nothing in the
@@ -526,6 +662,7 @@ def main():
                          'figure recorded in profiles/; `on` waits without a limit')
     ap.add_argument('--gpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch event timing of the conv kernels (roofline = null)')
+    ap.add_argument('--no-calibration', action='store_true', help='skip the box calibration (bare MFMA stream + streaming copy, ~0.2 s)')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the short 384x1280 batch-2 measurement (BASELINE.json configs[2] shape) that the default 192x640 '
                          'single-GPU run appends to its JSON line as `extra`')
@@ -536,7 +673,7 @@ def main():
 
     if args.gpu_baseline_worker:          # child of gpu_eager_baseline_bounded: one JSON line, nothing else
         h, w, b = (int(v) for v in args.gpu_baseline_worker.split(','))
-        rec = gpu_eager_baseline(h, w, b, torch.device('cuda', 0), seconds_budget=1e9)
+        rec = gpu_eager_baseline(h, w, b, torch.device('cuda', 0), seconds_budget=1e9, wait_for_go=True)
         rec['workload_shape'] = [h, w, b]
         print(json.dumps(rec), flush=True)
         return
@@ -573,6 +710,7 @@ def main():
         optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                              compression=hvd.Compression.none, force_collectives=force_ddp)
     ctx = {'rank': rank, 'world': world, 'device': device, 'ddp': ddp}
+    calibration = box_calibration(device) if (rank == 0 and not args.no_calibration) else None
 
     m = run_workload(model, optimizer, H, W, B, args.steps, args.warmup, ctx, want_prof=not args.no_prof,
                      layer_table=args.layer_table)
@@ -621,6 +759,15 @@ def main():
                        'rccl_ranks': dist.get_world_size() if (dist.is_initialized() and backend == 'nccl') else None},
             'roofline': roofline,
         }
+        if calibration is not None:
+            calibration['clocks_during_timed_region'] = m.get('clocks')
+            result['calibration'] = calibration
+            if roofline is not None and calibration.get('mfma_tflops'):
+                # the same achieved figure against what THIS box's matrix pipe sustains with nothing but the MFMAs (not a peak from a
+                # data sheet): comparable across leases; `frac` (against the guide's 2500 / 6) stays the headline
+                roofline['frac_vs_box'] = round(roofline['achieved'] / calibration['mfma_tflops'], 4)
+                if roofline['wgrad_kernel'].get('achieved'):
+                    roofline['wgrad_kernel']['frac_vs_box'] = round(roofline['wgrad_kernel']['achieved'] / calibration['mfma_tflops'], 4)
         if ddp:
             red = optimizer._reducer
             sizes = [b.flat.numel() * b.flat.element_size() for b in red.buckets]

@@ -455,6 +455,11 @@ int pnsfm_adam_segments(const void* segs_dev, int nseg, int total_blocks, void* 
  * (hipEventRecord + hipStreamWaitEvent on a library-owned, timing-less event).  Host plumbing for the weight-gradient side stream of
  * packnet_sfm/hip/functional.py (replaces the all-reduce-overlap role of horovod's background thread, trainers/horovod_trainer.py). */
 int pnsfm_stream_wait_stream(void* waiter, void* signaler);
+/* Box calibration for bench.py's `calibration` block (csrc/calib.hip; nothing on the training step calls these): the bare six-product
+ * bf16 MFMA stream of the split arithmetic -- blocks x 4 waves x iters x 24 v_mfma_f32_32x32x16_bf16, operands in registers, `sink`
+ * receives blocks * 256 floats -- and a float4 streaming copy of n_floats (multiple of 4) floats. */
+int pnsfm_calib_mfma(float* sink, int blocks, int iters, void* stream);
+int pnsfm_calib_copy(const float* src, float* dst, size_t n_floats, void* stream);
 int pnsfm_prof_enable(int on);
 int pnsfm_prof_reset(void);
 int pnsfm_prof_collect(int kind, double* total_ms, double* total_flops, long long* launches);

@@ -205,8 +205,22 @@ int pnsfm_stream_wait_stream(void* waiter, void* signaler) {
   static std::mutex mu;
   static std::vector<std::vector<hipEvent_t>> ring(64);
   static int next[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { pnsfm::set_error("stream_wait_stream: hipGetDevice failed"); return -1; }
+  // the event must belong to the device that OWNS the streams, which need not be the calling thread's current device (ADVICE r05:
+  // FlatAdam or the reducer running under another device guard); a null handle is the legacy default stream of the current device
+  int cur = 0, dev = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipGetDevice failed"); return -1; }
+  hipStream_t probe = signaler ? (hipStream_t)signaler : (hipStream_t)waiter;
+  if (!probe || hipStreamGetDevice(probe, &dev) != hipSuccess) { (void)hipGetLastError(); dev = cur; }
+  if (dev < 0 || dev >= 64) { pnsfm::set_error("stream_wait_stream: bad device %d", dev); return -1; }
+  if (signaler && waiter) {
+    int dw = -1;
+    if (hipStreamGetDevice((hipStream_t)waiter, &dw) == hipSuccess && dw != dev) {
+      pnsfm::set_error("stream_wait_stream: the two streams live on different devices (%d, %d)", dw, dev);
+      return -1;
+    }
+    (void)hipGetLastError();
+  }
+  struct DevGuard { int prev, now; DevGuard(int p, int n) : prev(p), now(n) { if (p != n) (void)hipSetDevice(n); } ~DevGuard() { if (prev != now) (void)hipSetDevice(prev); } } guard(cur, dev);
   hipEvent_t ev;
   {
     std::lock_guard<std::mutex> lk(mu);

@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "conv2d.hip", "conv2d_wgrad2.hip", "conv2d_wgrad3.hip", "conv2d_wgrad4.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "invdepth.hip", "loss.hip", "supervised.hip", "augment.hip", "nrs.hip", "sparse.hip"]
+SOURCES = ["api.hip", "conv2d.hip", "conv2d_wgrad2.hip", "conv2d_wgrad3.hip", "conv2d_wgrad4.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "invdepth.hip", "loss.hip", "supervised.hip", "augment.hip", "nrs.hip", "sparse.hip", "calib.hip"]
 LIB = os.path.join(HERE, "libpnsfm_hip.so")
 
 

@@ -118,6 +118,8 @@ SIGNATURES = {
     "pnsfm_set_wgrad_variant": (_i, [_i]),
     "pnsfm_tune_set": (_i, [ctypes.POINTER(ctypes.c_int), _i, _i]),
     "pnsfm_conv2d_last_config": (_i, [ctypes.POINTER(ctypes.c_int)]),
+    "pnsfm_calib_mfma": (_i, [_p, _i, _i, _p]),
+    "pnsfm_calib_copy": (_i, [_p, _p, _sz, _p]),
     "pnsfm_prof_enable": (_i, [_i]),
     "pnsfm_prof_reset": (_i, []),
     "pnsfm_prof_collect": (_i, [_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

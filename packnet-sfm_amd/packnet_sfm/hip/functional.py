@@ -308,7 +308,7 @@ class _WgradStream:
         if pure and _FAST_FORK:
             main_raw, side_raw = ops.current_raw_stream(dev), side.cuda_stream
             ops.stream_wait_stream(side_raw, main_raw)
-            with ops.stream_override(side_raw):
+            with ops.stream_override(side_raw, dev.index):
                 out = fn()
             for t in tensors:
                 t.record_stream(side)       # inputs live in the compute stream's pool but are read here

@@ -4,6 +4,7 @@ Every wrapper validates dtype / contiguity / device, allocates outputs with torc
 allocator and stream owner -- plumbing, not compute) and enqueues the HIP kernels on torch's current stream.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -16,7 +17,10 @@ except AttributeError:                                      # pragma: no cover
     _raw_stream = None
 
 
-_STREAM_OVERRIDE = [None]      # a raw hipStream_t (int): every launch goes there instead of torch's current stream (stream_override)
+# a raw hipStream_t (int) and the device index it belongs to: every launch of THIS THREAD on THAT device goes there instead of torch's
+# current stream (stream_override).  Per thread (a process-global override also redirected launches of another thread --
+# a second device's autograd worker, a prefetch thread -- onto the wrong stream, even a stream of another device).
+_TLS = threading.local()
 
 
 class stream_override:
@@ -24,16 +28,16 @@ class stream_override:
     (torch.cuda.stream costs ~20 us per enter / exit).  Only for code that calls nothing but these ops: a torch operation inside would
     still go to torch's current stream.  Allocations stay in the current stream's pool: the caller orders their reuse (functional.py)."""
 
-    def __init__(self, raw):
-        self.raw = raw
+    def __init__(self, raw, device_index=None):
+        self.ov = (raw, device_index)
 
     def __enter__(self):
-        self.prev = _STREAM_OVERRIDE[0]
-        _STREAM_OVERRIDE[0] = self.raw
+        self.prev = getattr(_TLS, 'ov', None)
+        _TLS.ov = self.ov
         return self
 
     def __exit__(self, *exc):
-        _STREAM_OVERRIDE[0] = self.prev
+        _TLS.ov = self.prev
         return False
 
 
@@ -53,8 +57,9 @@ def _stream(t):
     query costs ~0.3 us against ~5 us for torch.cuda.current_stream(...).cuda_stream (round 5 host profile)."""
     if not t.is_cuda:
         return ctypes.c_void_p(0)
-    if _STREAM_OVERRIDE[0] is not None:
-        return ctypes.c_void_p(_STREAM_OVERRIDE[0])
+    ov = getattr(_TLS, 'ov', None)
+    if ov is not None and (ov[1] is None or ov[1] == t.device.index):
+        return ctypes.c_void_p(ov[0])
     if _raw_stream is not None:
         return ctypes.c_void_p(_raw_stream(t.device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -1013,6 +1018,21 @@ def region_ops(items):
 
 
 # ---------------------------------------------------------------------------------------------- prof
+def calib_mfma(sink, blocks, iters):
+    """The bare six-product bf16 MFMA stream (csrc/calib.hip); returns the bf16 flops of the launch."""
+    _chk(sink); _f32(sink)
+    assert sink.numel() >= blocks * 256
+    _lib.check(_lib.get().pnsfm_calib_mfma(_ptr(sink), blocks, iters, _stream(sink)), "calib_mfma")
+    return blocks * 4.0 * iters * 24.0 * (2.0 * 32 * 32 * 16)
+
+
+def calib_copy(src, dst):
+    _chk(src, dst); _f32(src, dst)
+    assert src.numel() == dst.numel()
+    _lib.check(_lib.get().pnsfm_calib_copy(_ptr(src), _ptr(dst), src.numel(), _stream(src)), "calib_copy")
+    return 2.0 * 4.0 * src.numel()
+
+
 def prof_enable(on):
     _lib.get().pnsfm_prof_enable(1 if on else 0)
 

@@ -10,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.abspath(os.path.join(HERE, "..", "..", "packnet-sfm_amd", "csrc"))
-SOURCES = ["api.hip", "conv2d.hip", "conv2d_wgrad2.hip", "conv2d_wgrad3.hip", "conv2d_wgrad4.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "invdepth.hip", "loss.hip", "supervised.hip", "augment.hip", "nrs.hip", "sparse.hip"]
+SOURCES = ["api.hip", "conv2d.hip", "conv2d_wgrad2.hip", "conv2d_wgrad3.hip", "conv2d_wgrad4.hip", "groupnorm.hip", "pack3d.hip", "elementwise.hip", "invdepth.hip", "loss.hip", "supervised.hip", "augment.hip", "nrs.hip", "sparse.hip", "calib.hip"]
 LIB = os.path.join(HERE, "libpnsfm_emu.so")
 
 

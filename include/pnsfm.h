@@ -207,6 +207,11 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
                                  const float* gamma, const float* beta, const float* mean, const float* rstd,
                                  float* dx, float* dgamma, float* dbeta, double* red_ws,
                                  int B, int C, int HW, int G, int act, void* stream);
+/* Round 6: when a (sample, group) slab -- (C / G) * HW contiguous floats -- is at most 64 K floats and HW % 4 == 0, the two entry
+ * points above run ONE launch each (forward: slab in registers, statistics + normalise + activation; backward: slab blocks write dx,
+ * channel blocks write dgamma / dbeta; csrc/groupnorm.hip) instead of two; stats_ws / red_ws are then not touched.
+ * pnsfm_set_gn_fused(0) (or PNSFM_GN_FUSED=0 in the environment) keeps the two-launch form everywhere; returns the previous setting. */
+int pnsfm_set_gn_fused(int on);
 
 /* ---- packing / unpacking data movement ------------------------------------------------------
  * space_to_depth == `packing(x, r=2)` layers01.py:126-148 (== F.pixel_unshuffle):

@@ -24,13 +24,29 @@
 
 namespace pnsfm {
 
+// exp(z) - 1 for z <= 0 (round 6: ocml's expm1f is ~30 instructions and the one-launch kernels below are VALU-bound -- a slab's
+// workgroup does all of its arithmetic on ONE CU): a degree-7 Taylor polynomial on (-1/4, 0] (truncation < 4e-10 of |z|) and the
+// hardware exponential minus one below that (result in [-1, -0.22): the exponential's 1-2 ulp are < 2e-7 of it).
+__device__ __forceinline__ float gn_expm1_neg(float z) {
+  if (z > -0.25f) {
+    float p = 1.f / 5040.f;
+    p = fmaf(p, z, 1.f / 720.f);
+    p = fmaf(p, z, 1.f / 120.f);
+    p = fmaf(p, z, 1.f / 24.f);
+    p = fmaf(p, z, 1.f / 6.f);
+    p = fmaf(p, z, 0.5f);
+    p = fmaf(p, z, 1.f);
+    return p * z;
+  }
+  return __expf(z) - 1.f;
+}
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == 1) return z > 0.f ? z : expm1f(z);
+  if (act == 1) return z > 0.f ? z : gn_expm1_neg(z);
   if (act == 2) return z > 0.f ? z : 0.f;
   return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
-  if (act == 1) return z > 0.f ? 1.f : expf(z);
+  if (act == 1) return z > 0.f ? 1.f : __expf(z);
   if (act == 2) return z > 0.f ? 1.f : 0.f;
   return 1.f;
 }
@@ -292,6 +308,309 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- round 6: ONE launch per direction when a (sample, group) slab fits one workgroup's reach ----------------------------------
+// The channels of a group are consecutive in NCHW, so a slab is ONE contiguous run of n = (C / G) * HW floats.  On the maps of
+// <= 48x160 (every layer of PackNet01 below the 96x320 level and all of PoseNet: ~40 of the step's GroupNorms) a slab is <= 240 KB and
+// the two-launch forms above are latency: 8-15 us per launch for a few MB.  Here a workgroup of 1024 (256) threads owns a slab:
+//   forward:  the slab is read ONCE into registers (NV float4 per thread), summed (fp32 over 16 elements, fp64 beyond), reduced across
+//             the workgroup (shuffles + LDS), normalised, activated and stored -- one launch instead of two;
+//   backward: blocks [0, B*G*S) own a slab: pass 1 forms A = sum gamma dz and Bq = sum gamma dz xhat of their slab, pass 2 re-reads x and
+//             dy (L2-resident: the same workgroup touched them a moment ago) and writes dx; the blocks behind them own a few CHANNELS
+//             each and form dgamma / dbeta over all samples -- every per-element quantity they need (mean, rstd, gamma, beta, x, dy) is
+//             known without the slab sums, so nothing is handed from workgroup to workgroup: no atomics, no fences, a fixed order.
+// A slab's arithmetic sits on ONE compute unit and is VALU-bound there (first build: 19.5 us forward / 35-45 us backward on the 48x160
+// maps against 21 / 32 for the two-launch form, rocprofv3), hence (i) the cheap exponentials above, per-channel scale / shift from LDS,
+// incremental channel indices, fp32 partial sums; (ii) S workgroups per slab on the larger slabs: each forms the slab's sums itself
+// (identical order: identical bits) and normalises 1 / S of it -- the S parts of a slab land on one XCD (shared L2).
+// Results agree with the two-launch form to summation order; each form is deterministic.  pnsfm_set_gn_fused(0) / PNSFM_GN_FUSED=0
+// keeps the two-launch form everywhere.
+constexpr int GNF_MAXCPG = 128;
+
+__device__ __forceinline__ void gnf_block_sum2(double& a, double& b, double (*red)[16]) {
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+  const int nw = (int)blockDim.x >> 6, w = (int)threadIdx.x >> 6;
+  if (nw == 1) return;
+  __syncthreads();                      // (a previous use of `red` is over)
+  if ((threadIdx.x & 63) == 0) { red[0][w] = a; red[1][w] = b; }
+  __syncthreads();
+  double sa = 0.0, sb = 0.0;
+  for (int k = 0; k < nw; ++k) { sa += red[0][k]; sb += red[1][k]; }
+  a = sa; b = sb;
+}
+
+// logical (slab, part) of a block: with S parts per slab and a slab count that is a multiple of 8, the parts of a slab are 8 blocks
+// apart -- workgroups are dealt to the 8 XCDs round-robin, so they share an L2
+__device__ __forceinline__ void gnf_slab_part(int blk, int S, int nslab, int& slab, int& part) {
+  if (S > 1 && (nslab & 7) == 0) {
+    const int q = blk / (8 * S), r = blk - q * (8 * S);
+    part = r >> 3;
+    slab = q * 8 + (r & 7);
+  } else {
+    slab = blk / S;
+    part = blk - slab * S;
+  }
+}
+
+// dq / dr: T / HW4 and T % HW4 (the float4 index advances by T per k: channel += dq, position += dr with one carry)
+template <int NV, int S>
+__global__ void __launch_bounds__(1024) gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             float* __restrict__ y, int C, int HW, int G, int act, float eps, int nslab,
+                                                             int dq, int dr) {
+  __shared__ double red[2][16];
+  __shared__ float lsc[GNF_MAXCPG], lsh[GNF_MAXCPG];
+  const int tid = threadIdx.x, T = blockDim.x;
+  int bg, part;
+  gnf_slab_part((int)blockIdx.x, S, nslab, bg, part);
+  const int cpg = C / G, gi = bg % G;
+  const int HW4 = HW >> 2, n4 = cpg * HW4;
+  const size_t base4 = (size_t)bg * n4;
+  const float4* xp = reinterpret_cast<const float4*>(x) + base4;
+  const float4* rp = res ? reinterpret_cast<const float4*>(res) + base4 : nullptr;
+  float4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * T;
+    v[k] = i < n4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (rp) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = tid + k * T;
+      if (i < n4) { const float4 q = rp[i]; v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w; }
+    }
+  }
+  double s1 = 0.0, s2 = 0.0;
+  {
+    float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      f1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      f2 += fmaf(v[k].x, v[k].x, v[k].y * v[k].y) + fmaf(v[k].z, v[k].z, v[k].w * v[k].w);
+      if ((k & 3) == 3 || k == NV - 1) { s1 += (double)f1; s2 += (double)f2; f1 = 0.f; f2 = 0.f; }
+    }
+  }
+  gnf_block_sum2(s1, s2, red);
+  const double n = (double)cpg * (double)HW;
+  const double m = s1 / n;
+  double var = s2 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid == 0 && part == 0) { mean_out[bg] = mu; rstd_out[bg] = rs; }
+  if (tid < cpg) {
+    const float sc = rs * gamma[gi * cpg + tid];
+    lsc[tid] = sc;
+    lsh[tid] = beta[gi * cpg + tid] - mu * sc;
+  }
+  __syncthreads();
+  float4* yp = reinterpret_cast<float4*>(y) + base4;
+  int ch = tid / HW4, pos = tid - ch * HW4;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * T;
+    // part p normalises the k-range [p NV / S, (p + 1) NV / S)  (NV % S == 0 whenever S > 1)
+    if ((S == 1 || k / (NV / S) == part) && i < n4) {
+      const float sc = lsc[ch], sh = lsh[ch];
+      float4 o;
+      o.x = act_fwd(fmaf(v[k].x, sc, sh), act); o.y = act_fwd(fmaf(v[k].y, sc, sh), act);
+      o.z = act_fwd(fmaf(v[k].z, sc, sh), act); o.w = act_fwd(fmaf(v[k].w, sc, sh), act);
+      yp[i] = o;
+    }
+    ch += dq; pos += dr;
+    if (pos >= HW4) { pos -= HW4; ++ch; }
+  }
+}
+
+// TPC: threads per channel of a parameter block (power of two, 64 <= TPC <= blockDim); S: workgroups per slab
+__global__ void __launch_bounds__(1024) gn_fused_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ res, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C,
+                                                             int HW, int G, int act, int TPC, int S, int dq, int dr) {
+  __shared__ double red[2][16];
+  __shared__ float lga[GNF_MAXCPG], lbe[GNF_MAXCPG];
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int cpg = C / G, HW4 = HW >> 2;
+  const int nslab = B * G;
+  if ((int)blockIdx.x < nslab * S) {
+    int bg, part;
+    gnf_slab_part((int)blockIdx.x, S, nslab, bg, part);
+    const int gi = bg % G;
+    const int n4 = cpg * HW4;
+    const size_t base4 = (size_t)bg * n4;
+    const float4* xp = reinterpret_cast<const float4*>(x) + base4;
+    const float4* rp = res ? reinterpret_cast<const float4*>(res) + base4 : nullptr;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base4;
+    const float mu = mean[bg], rs = rstd[bg];
+    const float nmr = -mu * rs;                    // xhat = v * rs + nmr
+    if (tid < cpg) { lga[tid] = gamma[gi * cpg + tid]; lbe[tid] = beta[gi * cpg + tid]; }
+    __syncthreads();
+    double A = 0.0, Bq = 0.0;
+    {
+      int ch = tid / HW4, pos = tid - ch * HW4;
+      for (int i0 = tid; i0 < n4; i0 += 4 * T) {
+        float4 v[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * T;
+          if (i < n4) { v[u] = xp[i]; d[u] = dp[i]; }
+        }
+        if (rp) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * T;
+            if (i < n4) { const float4 q = rp[i]; v[u].x += q.x; v[u].y += q.y; v[u].z += q.z; v[u].w += q.w; }
+          }
+        }
+        float fa = 0.f, fb = 0.f;                  // fp32 over the 16 elements of this trip, fp64 beyond
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * T;
+          if (i < n4) {
+            const float ga = lga[ch], be = lbe[ch];
+            const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float xh = fmaf(vv[k], rs, nmr);
+              const float dz = dd[k] * act_grad(fmaf(xh, ga, be), act);
+              a1 += dz;
+              a2 = fmaf(dz, xh, a2);
+            }
+            fa = fmaf(ga, a1, fa);
+            fb = fmaf(ga, a2, fb);
+          }
+          ch += dq; pos += dr;
+          if (pos >= HW4) { pos -= HW4; ++ch; }
+        }
+        A += (double)fa;
+        Bq += (double)fb;
+      }
+    }
+    gnf_block_sum2(A, Bq, red);
+    const double n = (double)cpg * (double)HW;
+    const float mA = (float)(A / n), mB = (float)(Bq / n);
+    float4* op = reinterpret_cast<float4*>(dx) + base4;
+    // this part's share of the slab: a contiguous range of float4 (whole multiples of T except the last)
+    const int per = ((n4 + S - 1) / S + T - 1) / T * T;
+    const int lo = part * per;
+    int hi = lo + per;
+    if (hi > n4) hi = n4;
+    for (int i0 = lo + tid; i0 < hi; i0 += 4 * T) {
+      float4 v[4], d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * T;
+        if (i < hi) { v[u] = xp[i]; d[u] = dp[i]; }
+      }
+      if (rp) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * T;
+          if (i < hi) { const float4 q = rp[i]; v[u].x += q.x; v[u].y += q.y; v[u].z += q.z; v[u].w += q.w; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * T;
+        if (i < hi) {
+          const int ch = i / HW4;
+          const float ga = lga[ch], be = lbe[ch];
+          const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+          float oo[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xh = fmaf(vv[k], rs, nmr);
+            const float dz = dd[k] * act_grad(fmaf(xh, ga, be), act);
+            oo[k] = rs * (dz * ga - mA - xh * mB);
+          }
+          op[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        }
+      }
+    }
+    return;
+  }
+  // ---- parameter block: channels c0 + r, r = tid / TPC; TPC lanes walk the channel's B x HW elements; dbeta = sum dz, dgamma = sum dz xhat
+  const int CPB = T / TPC;
+  const int r = tid / TPC, l = tid - r * TPC;
+  const int c_raw = ((int)blockIdx.x - nslab * S) * CPB + r;
+  const bool valid = c_raw < C;
+  const int c = valid ? c_raw : C - 1;          // surplus rows shadow a real channel: the barriers below stay uniform
+  const int gi = c / cpg;
+  const float ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  const int per = B * HW4;
+  for (int e0 = l; e0 < per; e0 += 4 * TPC) {
+    float4 v[4], d[4];
+    float rs[4], nmr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * TPC;
+      if (e < per) {
+        const int b = e / HW4, i = e - b * HW4;
+        const size_t o4 = ((size_t)b * C + c) * HW4 + i;
+        v[u] = reinterpret_cast<const float4*>(x)[o4];
+        d[u] = reinterpret_cast<const float4*>(dy)[o4];
+        if (res) { const float4 q = reinterpret_cast<const float4*>(res)[o4]; v[u].x += q.x; v[u].y += q.y; v[u].z += q.z; v[u].w += q.w; }
+        rs[u] = rstd[b * G + gi];
+        nmr[u] = -mean[b * G + gi] * rs[u];
+      }
+    }
+    float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * TPC;
+      if (e < per) {
+        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = fmaf(vv[k], rs[u], nmr[u]);
+          const float dz = dd[k] * act_grad(fmaf(xh, ga, be), act);
+          f1 += dz;
+          f2 = fmaf(dz, xh, f2);
+        }
+      }
+    }
+    s1 += (double)f1;
+    s2 += (double)f2;
+  }
+  // sum over the TPC lanes of the row: inside the wave, then across the row's waves through LDS
+  for (int d = 32; d >= 1; d >>= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
+  if (TPC > 64) {
+    const int w = tid >> 6, wpr = TPC >> 6;
+    if ((tid & 63) == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    const int w0 = (w / wpr) * wpr;
+    double a = 0.0, b2 = 0.0;
+    for (int k = 0; k < wpr; ++k) { a += red[0][w0 + k]; b2 += red[1][w0 + k]; }
+    s1 = a; s2 = b2;
+  }
+  if (valid && l == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+}
+
+static int g_gn_fused = -1;      // -1: read PNSFM_GN_FUSED on first use (default on)
+static bool gn_fused_on() {
+  if (g_gn_fused < 0) { const char* e = getenv("PNSFM_GN_FUSED"); g_gn_fused = (e && e[0] == '0') ? 0 : 1; }
+  return g_gn_fused == 1;
+}
+// slabs a workgroup holds: float4 rows, <= 16 float4 per thread of a 1024-thread workgroup (64 K floats = 256 KB)
+static bool gn_fused_ok(int C, int HW, int G) {
+  if (!gn_fused_on() || HW % 4 != 0 || C / G > GNF_MAXCPG) return false;
+  const long n4 = (long)(C / G) * (HW / 4);
+  return n4 <= 16L * 1024;
+}
+static int gn_fused_threads(long n4) { return n4 > 2048 ? 1024 : 256; }
+// workgroups per slab: the normalisation (exponentials) is most of a slab's arithmetic; 4 on the slabs of >= 4 float4 per thread of a
+// 1024-thread workgroup (env PNSFM_GN_FUSED_S overrides: lab)
+static int gn_fused_parts(long n4, int T) {
+  static const int forced = [] { const char* e = getenv("PNSFM_GN_FUSED_S"); return e && e[0] ? atoi(e) : 0; }();
+  const long nv = (n4 + T - 1) / T;
+  if (forced == 1 || forced == 2 || forced == 4) return nv >= forced && T == 1024 ? forced : 1;
+  return (T == 1024 && nv >= 4) ? 4 : 1;
+}
+
 // Work split: T lanes per channel row so that a lane moves >= 4 float4 per pass when the map allows it; rows of one
 // workgroup are consecutive (b, c) channels; a row is cut into chunks only when B*C rows alone cannot give ~4 workgroups per CU.
 static GnGeom gn_geom(int BC, int HW, bool vec, int max_chunks) {
@@ -335,6 +654,22 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (HW % 4 == 0);
   const int BC = B * C, cpg = C / G;
+  if (gn_fused_ok(C, HW, G)) {
+    const long n4 = (long)cpg * (HW / 4);
+    const int T = gn_fused_threads(n4);
+    const int nv = (int)ceil_div_sz((size_t)n4, (size_t)T);
+    const int S = gn_fused_parts(n4, T);
+    const int HW4 = HW / 4, dq = T / HW4, dr = T % HW4, nslab = B * G;
+    const dim3 grid(nslab * S), block(T);
+#define PNSFM_GNF(NVv, Sv) PNSFM_LAUNCH((gn_fused_fwd_kernel<NVv, Sv>), grid, block, 0, s, x, res, gamma, beta, mean, rstd, y, C, HW, G, act, eps, nslab, dq, dr)
+    if (nv <= 1) PNSFM_GNF(1, 1);
+    else if (nv <= 2) PNSFM_GNF(2, 1);
+    else if (nv <= 4) { if (S == 4) PNSFM_GNF(4, 4); else if (S == 2) PNSFM_GNF(4, 2); else PNSFM_GNF(4, 1); }
+    else if (nv <= 8) { if (S == 4) PNSFM_GNF(8, 4); else if (S == 2) PNSFM_GNF(8, 2); else PNSFM_GNF(8, 1); }
+    else { if (S == 4) PNSFM_GNF(16, 4); else if (S == 2) PNSFM_GNF(16, 2); else PNSFM_GNF(16, 1); }
+#undef PNSFM_GNF
+    return check_launch("gn_fused_fwd");
+  }
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
   dim3 grid(ceil_div(BC, g.rows), g.nchunk);
   if (vec) PNSFM_LAUNCH((gn_stats_kernel<true>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
@@ -371,6 +706,19 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (HW % 4 == 0);
   const int BC = B * C;
+  if (gn_fused_ok(C, HW, G)) {
+    const long n4 = (long)(C / G) * (HW / 4);
+    const int T = gn_fused_threads(n4);
+    // threads per channel of the parameter blocks: <= 8 float4 per lane where the block allows it
+    int TPC = 64;
+    while (TPC < T && (long)B * (HW / 4) > 8L * TPC) TPC <<= 1;
+    const int nparam = ceil_div(C, T / TPC);
+    const int S = gn_fused_parts(n4, T);
+    const int HW4 = HW / 4;
+    PNSFM_LAUNCH(gn_fused_bwd_kernel, dim3(B * G * S + nparam), dim3(T), 0, s, dy, x, res, gamma, beta, mean, rstd, dx, dgamma, dbeta, B, C, HW, G,
+                 act, TPC, S, T / HW4, T % HW4);
+    return check_launch("gn_fused_bwd");
+  }
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
   dim3 grid(ceil_div(BC, g.rows), g.nchunk);
   int e = 0;
@@ -382,6 +730,13 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   if (vec) PNSFM_LAUNCH((gn_bwd_apply_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const double*)red_ws, dx, dgamma, dbeta, B, C, HW, G, act, n, g);
   else PNSFM_LAUNCH((gn_bwd_apply_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, (const double*)red_ws, dx, dgamma, dbeta, B, C, HW, G, act, n, g);
   return check_launch("gn_bwd_apply");
+}
+
+/* 1 (default): slabs a workgroup can hold run the one-launch kernels; 0: the two-launch form everywhere.  Returns the previous setting. */
+int pnsfm_set_gn_fused(int on) {
+  const int prev = gn_fused_on() ? 1 : 0;
+  g_gn_fused = on ? 1 : 0;
+  return prev;
 }
 
 }  // extern "C"

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pnsfm_groupnorm_act_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pnsfm_set_gn_fused": (_i, [_i]),
     "pnsfm_space_to_depth": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "pnsfm_space_to_depth_strided": (_i, [_p, _p, _i, _i, _i, _i, _sz, _p]),
     "pnsfm_depth_to_space": (_i, [_p, _p, _i, _i, _i, _i, _p]),

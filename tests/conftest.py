@@ -48,5 +48,6 @@ def emulated_kernels():
     lib.pnsfm_set_conv_variant(0)
     lib.pnsfm_set_conv_variant(3)
     lib.pnsfm_set_wgrad_variant(-1)
+    lib.pnsfm_set_gn_fused(1)
     yield
     _lib._LIB, _lib.REQUIRE_CUDA = saved

@@ -226,3 +226,49 @@ def test_pingpong_repeated_launches_are_bit_identical(shape, NT, tm, split):
         lib.pnsfm_set_conv_variant(3)
     # and the first launch is right
     P.check(y0, F.conv2d(x, w, b, padding=ks // 2), 2e-5, 'fwd')
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm, one launch per direction
+GN_SHAPES = [(4, 256, 24, 80), (4, 128, 48, 160), (4, 512, 12, 40), (4, 512, 6, 20), (4, 32, 96, 320), (4, 64, 24, 80), (2, 512, 24, 80),
+             (4, 16, 96, 320), (4, 256, 3, 10), (3, 48, 6, 20)]
+
+
+@pytest.mark.parametrize('fused', [1, 0])
+@pytest.mark.parametrize('shape', GN_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('act,use_res', [(1, False), (1, True), (2, False)])
+def test_groupnorm_one_launch_form_gpu(shape, act, use_res, fused):
+    """csrc/groupnorm.hip, round 6: slabs of <= 64 K floats run statistics + normalise + activation in ONE launch and the whole
+    backward in ONE launch (slab blocks: dx; channel blocks: dgamma / dbeta).  Both forms (fused = 1 / 0) against torch's group_norm
+    on the CPU at the real PackNet01 / PoseNet layer shapes below the 96x320 level (reference layers01.py:31-37, 61-72;
+    networks/pose/PoseNet.py:28-34)."""
+    from packnet_sfm.hip import _lib
+    lib = _lib.get()
+    prev = lib.pnsfm_set_gn_fused(fused)
+    try:
+        P.case_groupnorm(DEV, shape, act, use_res, tol=2e-5)
+    finally:
+        lib.pnsfm_set_gn_fused(prev)
+
+
+def test_groupnorm_one_launch_form_is_deterministic_and_close_to_the_two_launch_form():
+    """Two runs of the one-launch kernels return the same bits; against the two-launch kernels only the fp64 summation ORDER differs."""
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 4, 256, 24, 80
+    x, res, dy = (torch.randn(B, C, H, W, generator=g).to(DEV) for _ in range(3))
+    ga, be = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    out = {}
+    prev = lib.pnsfm_set_gn_fused(1)
+    try:
+        for fused in (1, 1, 0):
+            lib.pnsfm_set_gn_fused(fused)
+            y, mean, rstd = ops.groupnorm_act_forward(x, res, ga, be, 16, 1e-5, ops.ACT_ELU)
+            dx, dga, dbe = ops.groupnorm_act_backward(dy, x, res, ga, be, mean, rstd, 16, ops.ACT_ELU)
+            out.setdefault(fused, []).append((y, mean, rstd, dx, dga, dbe))
+    finally:
+        lib.pnsfm_set_gn_fused(prev)
+    for a, b in zip(out[1][0], out[1][1]):
+        assert torch.equal(a, b)
+    for a, b, name in zip(out[1][0], out[0][0], ('y', 'mean', 'rstd', 'dx', 'dgamma', 'dbeta')):
+        P.check(a, b, 2e-6, 'one-launch vs two-launch ' + name)

@@ -1051,29 +1051,23 @@ def test_groupnorm_two_launch_form(emulated_kernels, shape, act, use_res):
     csrc/groupnorm.hip: one lane per row with surplus rows in the workgroup (2x4 maps), scalar loads (5x7), rows cut into chunks
     (64x80), rows of 128/256 lanes (barrier-based row sums), many channels per group -- since round 3 the apply kernels add the
     partial slots themselves (no gn_finish / gn_bwd_group launches)."""
-    import torch.nn.functional as F
-    from packnet_sfm.hip import functional as HF
-    B, C, H, W = shape
-    g = torch.Generator().manual_seed(sum(shape) + act)
-    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
-    res = torch.randn(B, C, H, W, generator=g) if use_res else None
-    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
-    dy = torch.randn(B, C, H, W, generator=g)
-    fn = {0: lambda t: t, 1: F.elu, 2: F.relu}[act]
-    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    rr = res.clone().requires_grad_(True) if use_res else None
-    yr = fn(F.group_norm(xr + rr if use_res else xr, 16, gr, br, 1e-5))
-    yr.backward(dy)
-    xh, gh, bh = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    rh = res.clone().requires_grad_(True) if use_res else None
-    y = HF.groupnorm_act(xh, gh, bh, 16, 1e-5, act, res=rh)
-    y.backward(dy)
-    P.check(y, yr, 1e-5, 'forward')
-    P.check(xh.grad, xr.grad, 2e-5, 'dx')
-    if use_res:
-        P.check(rh.grad, rr.grad, 2e-5, 'dres')
-    P.check(gh.grad, gr.grad, 2e-5, 'dgamma')
-    P.check(bh.grad, br.grad, 2e-5, 'dbeta')
+    from packnet_sfm.hip import _lib
+    _lib.get().pnsfm_set_gn_fused(0)          # the two-launch kernels (the large maps' path), also on the slabs the one-launch form takes
+    P.case_groupnorm('cpu', shape, act, use_res)
+
+
+# slab = (C / 16) * H * W floats: one float4 per thread of a 256-thread workgroup up to 16 per thread of a 1024-thread one; parameter
+# blocks with 64 .. 1024 threads per channel and surplus rows (C = 48: three channels per group)
+@pytest.mark.parametrize('shape', [(3, 16, 2, 4), (2, 32, 4, 6), (2, 64, 12, 40), (5, 32, 24, 80), (2, 48, 6, 20), (1, 16, 96, 320),
+                                   (3, 128, 12, 40), (1, 32, 130, 128)])
+@pytest.mark.parametrize('act,use_res', [(1, False), (2, True), (0, True)])
+def test_groupnorm_one_launch_form(emulated_kernels, shape, act, use_res):
+    """Round 6 (csrc/groupnorm.hip: gn_fused_fwd_kernel / gn_fused_bwd_kernel): a workgroup owns a (sample, group) slab -- statistics,
+    normalisation and activation in ONE launch, backward with slab blocks (dx) and channel blocks (dgamma, dbeta) in one launch --
+    forward AND backward vs torch, the tolerances of the two-launch form."""
+    from packnet_sfm.hip import _lib
+    assert _lib.get().pnsfm_set_gn_fused(1) in (0, 1)
+    P.case_groupnorm('cpu', shape, act, use_res)
 
 
 def _check_conv2d_cat(device, B, Cs, Cout, H, W, ks, seed):

@@ -69,6 +69,11 @@ prof)
   f=$(find $O/prof_r06b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r06_bench_kernel_stats_384x1280.csv
   t=$(find $O/prof_r06b -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r06_step_breakdown_384x1280.txt 2>&1 && head -4 $O/r06_step_breakdown_384x1280.txt
   rm -rf $O/prof_r06b ;;
+proflite)
+  # rocprofv3 kernel trace of a short run (side streams off: every kernel alone) -> step breakdown only
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r06l -o bench -- python $R/bench.py --steps 4 --warmup 2 $BARGS --no-prof --no-calibration > $O/r06_rocprof_lite.log 2>&1)
+  t=$(find $O/prof_r06l -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 5 "${LITE_RE:-^$}" > $O/r06_step_breakdown_lite.txt 2>&1 && head -${LITE_LINES:-40} $O/r06_step_breakdown_lite.txt
+  rm -rf $O/prof_r06l ;;
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)

@@ -35,3 +35,16 @@ tot = sum(v[1] for v in agg.values()) / 1e6
 print('step %d of %d: wall' % (K, len(bursts)) + ' wall %.2f ms, kernel-sum %.2f ms, %d launches' % (wall, tot, len(win)))
 for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print('%7.3f ms %5d  %s' % (v[1] / 1e6, v[0], n))
+# optional 4th argument: a regular expression -- every launch of the step whose kernel name matches, one line each
+if len(sys.argv) > 4:
+    pat = re.compile(sys.argv[4])
+    print('-- launches matching %r in this step (name, workgroups x threads, us)' % sys.argv[4])
+    for r in win:
+        if pat.search(r['Kernel_Name']):
+            n = re.sub(r'^void ', '', re.sub(r'\(.*', '', r['Kernel_Name']))[:60]
+            try:
+                wg = int(r['Workgroup_Size_X']) * int(r.get('Workgroup_Size_Y', 1) or 1)
+                nb = int(r['Grid_Size_X']) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1) // max(wg, 1)
+            except (KeyError, ValueError):
+                wg = nb = -1
+            print('%-60s %6d x %4d  %8.2f' % (n, nb, wg, (r['e'] - r['s']) / 1e3))

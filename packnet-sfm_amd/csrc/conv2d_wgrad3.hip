@@ -397,70 +397,80 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 }
 
 // second stage of a pixel-split launch: dW[co][ci][ky][kx] = sum over the Z partial tensors, in a fixed order (deterministic).
-// One workgroup per (co, CIB input channels), CIB = 4 << lshift chosen by the host so that the (tap, 4-channel column) items of a
-// block fit its 256 threads in one pass where they can (3x3: 64 channels = 144 items, 5x5: 32, 7x7: 16; 1x1: 128).  The partials
-// are [z][ky][COP][kx][CIP] with ci fastest: an item is one 16-byte load per partial, added in ascending z with EIGHT loads in
-// flight (the kernel is latency-bound: the partials were written a moment ago and mostly sit in the MALL) -- no cross-thread
-// reduction at all; the sums go through an LDS tile [ci][tap] so that dW leaves as one contiguous (ci, tap) run per block.
-// (Round 2: 128-byte runs with 4-byte loads, meeting in LDS per tap: 0.39 TB/s, 0.72 ms per step.  Round 3: 128 channels per block,
-// thread group g owned taps g, g + 8, ...: a 3x3 layer's ninth tap doubled the time of 32 threads, four loads in flight.)
+// The partials are [z][ky][COP][kx][CIP] with ci fastest: an item = (tap, 4-channel column) is one 16-byte load per partial.
+// Round 6: a block owns one co and `ncol` columns (items = KK * ncol <= 256) and its 256 threads are ZG = 256 / items GROUPS that share
+// the z range -- group g adds partials g, g + ZG, ... (all loads of a thread independent: <= 8 per thread where the shape allows) --
+// and the groups' sums meet in LDS in ascending group order; the result goes through an LDS tile [ci][tap] so that dW leaves as one
+// contiguous (ci, tap) run per block.  History: round 2 128-byte runs with 4-byte loads (0.72 ms per step); round 3-5 one thread per
+// item walking ALL z with eight loads in flight and 64-256 blocks per launch: latency-bound, 21 us for the four 64 -> 64 @ 96x320
+// layers (Z = 69), 77 us for 129 -> 64 @ 192x640 (Z = 237), 0.61 ms per step (profiles/r05_step_breakdown.txt).
 __global__ void __launch_bounds__(256) wgrad3_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_bias,
                                                             float* __restrict__ dw, float* __restrict__ dbias, int Z, int KS,
-                                                            int COP, int CIP, int Cin, int Cout, int lshift) {
-  __shared__ float tile[128 * 49 + 4];
-  const int LPT = 1 << lshift, CIB = 4 * LPT;              // lanes per tap, input channels per block
-  const int co = blockIdx.x, ci0 = blockIdx.y * CIB, KK = KS * KS;
+                                                            int COP, int CIP, int Cin, int Cout, int ncol, int ZG) {
+  __shared__ float4 part[256];
+  __shared__ float tile[4 * 256 + 4];
+  const int KK = KS * KS, items = KK * ncol, CIB = 4 * ncol;
+  const int co = blockIdx.x, ci0 = blockIdx.y * CIB;
+  const int t = threadIdx.x;
+  const int zg = t / items, item = t - zg * items;
+  const int tap = item / ncol, j = item - tap * ncol;
+  const int ci = ci0 + 4 * j;
   const size_t zstride = (size_t)KS * COP * KS * CIP;
-  for (int item = threadIdx.x; item < KK * LPT; item += 256) {
-    const int tap = item >> lshift, j = item & (LPT - 1);
-    const int ci = ci0 + 4 * j;
-    if (ci >= CIP) continue;
+  const bool live = zg < ZG && ci < CIP;
+  if (live) {
     const int ky = tap / KS, kx = tap - ky * KS;
     const float* p = ws + (((size_t)ky * COP + co) * KS + kx) * CIP + ci;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 8 <= Z; z += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u) * zstride);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
-    }
-    if (z + 4 <= Z) {
+    int z = zg;
+    for (; z + 3 * ZG < Z; z += 4 * ZG) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u) * zstride);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u * ZG) * zstride);
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
-      z += 4;
     }
-    for (; z < Z; ++z) {
+    for (; z < Z; z += ZG) {
       const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * zstride);
       s0 += a.x; s1 += a.y; s2 += a.z; s3 += a.w;
     }
-    float* t = tile + (4 * j) * KK + tap;
-    t[0] = s0; t[KK] = s1; t[2 * KK] = s2; t[3 * KK] = s3;
+    part[t] = make_float4(s0, s1, s2, s3);
+  }
+  __syncthreads();
+  if (zg == 0 && ci < CIP) {
+    float4 s = part[item];
+    for (int g = 1; g < ZG; ++g) { const float4 q = part[g * items + item]; s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w; }
+    float* tl = tile + (4 * j) * KK + tap;
+    tl[0] = s.x; tl[KK] = s.y; tl[2 * KK] = s.z; tl[3 * KK] = s.w;
   }
   __syncthreads();
   int nci = Cin - ci0;
   if (nci > CIB) nci = CIB;
   float* out = dw + ((size_t)co * Cin + ci0) * KK;
-  for (int e = threadIdx.x; e < nci * KK; e += 256) out[e] = tile[e];
-  if (dbias && blockIdx.y == 0 && threadIdx.x == 0) {
+  for (int e = t; e < nci * KK; e += 256) out[e] = tile[e];
+  if (dbias && blockIdx.y == 0 && t < 64) {       // the bias partials: 64 lanes share the z range, a fixed shuffle tree
     float sum = 0.f;
-    for (int z = 0; z < Z; ++z) sum += ws_bias[(size_t)z * COP + co];
-    dbias[co] = sum;
+    for (int z = t; z < Z; z += 64) sum += ws_bias[(size_t)z * COP + co];
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (t == 0) dbias[co] = sum;
   }
 }
 
 // the second stage on its own (conv2d_wgrad4.hip writes the same partial-tensor layout)
 int launch_wgrad3_reduce(const float* ws, const float* ws_bias, float* dw, float* dbias, int Z, int KS, int COP, int CIP, int Cin,
                          int Cout, hipStream_t s) {
-  // channels per block: the (tap, 4-channel column) items of a block in one pass of its 256 threads where possible
-  int lshift = 5;                                            // 128 channels (1x1)
-  while (lshift > 2 && KS * KS * (1 << lshift) > 256) --lshift;
-  PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 4 << lshift)), dim3(256), 0, s, ws, ws_bias, dw, dbias, Z, KS, COP, CIP,
-               Cin, Cout, lshift);
+  // z groups so that a thread adds <= ~8 partials; columns per block from what is left of the 256 threads (1x1 layers: <= 32 columns)
+  const int KK = KS * KS;
+  int zg_want = ceil_div(Z, 8);
+  if (zg_want > 256 / KK) zg_want = 256 / KK;
+  if (zg_want < 1) zg_want = 1;
+  int ncol = (256 / zg_want) / KK;
+  if (ncol < 1) ncol = 1;
+  if (ncol > 32) ncol = 32;
+  if (ncol > ceil_div(CIP, 4)) ncol = ceil_div(CIP, 4);
+  int ZG = 256 / (KK * ncol);
+  if (ZG > Z) ZG = Z;
+  PNSFM_LAUNCH(wgrad3_reduce_kernel, dim3(Cout, ceil_div(Cin, 4 * ncol)), dim3(256), 0, s, ws, ws_bias, dw, dbias, Z, KS, COP, CIP,
+               Cin, Cout, ncol, ZG);
   return check_launch("conv2d_backward_weight (split-bf16, reduction)");
 }
 

@@ -46,6 +46,11 @@ struct Wgrad3Args {
   int ci_tiles;      // logical grid x = ci_tiles * KS
   int gx, gy, bmap;  // 1-D launch: ci tiles * KS, co groups, block order (pnsfm_common.h: block_map_mode)
 };
+#ifdef PNSFM_WG_ABLATE          // compile-time what-if mask (see conv2d_wgrad4.hip)
+#define PNSFM_WG_ABL(a) (PNSFM_WG_ABLATE)
+#else
+#define PNSFM_WG_ABL(a) 0
+#endif
 
 #ifdef PNSFM_EMU
 static inline unsigned w3_alignbit16(unsigned hi, unsigned lo) { return (lo >> 16) | (hi << 16); }
@@ -217,6 +222,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
   // spilled) -- and each shifted operand feeds the A pieces it pairs with, so every accumulator still sees its smallest products
   // first: (h,l) | (m,m) (h,m) | (l,h) (m,h) (h,h) [A piece, B piece]; +4.5 % on the two 7x7 layers.  3x3 / 5x5 keep all three
   // windows and finish one tap (6 MFMAs on one accumulator) at a time: the piece-major form measured 4-8 % slower on 5x5.
+  constexpr int abl = PNSFM_WG_ABL(a);
   auto kstep = [&](const pnsfm_u32x4 (&A)[3], int q) {
     const int koff = ((q / SEG) * RS + 16 * (q % SEG)) * 2;
 #pragma unroll
@@ -230,10 +236,15 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
           for (int d = 0; d < 4; ++d) Wd[4 + d] = c[d];
           if (KS > 1) {
+            if (abl & 2) {
+#pragma unroll
+              for (int d = 0; d < 4; ++d) { Wd[d] = c[(d + 1) & 3]; Wd[8 + d] = c[(d + 2) & 3]; }
+            } else {
             const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
             const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
 #pragma unroll
             for (int d = 0; d < 4; ++d) { Wd[d] = pv[d]; Wd[8 + d] = nx[d]; }
+            }
           }
 #pragma unroll
           for (int kx = 0; kx < KS; ++kx) {
@@ -244,9 +255,10 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
               if ((sh & 1) == 0) Bv[d] = Wd[4 + d + sh / 2];
               else {
                 const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
-                Bv[d] = w3_alignbit16(Wd[lo + 1], Wd[lo]);
+                Bv[d] = (abl & 4) ? (Wd[lo + 1] ^ Wd[lo]) : w3_alignbit16(Wd[lo + 1], Wd[lo]);
               }
             }
+            if (abl & 16) { acc[nt][kx][0] += __builtin_bit_cast(float, Bv[0] ^ Bv[1] ^ Bv[2] ^ Bv[3] ^ A[0][0] ^ A[1][1] ^ A[2][2]); continue; }
 #pragma unroll
             for (int sa = 2 - s; sa >= 0; --sa) acc[nt][kx] = pnsfm_mfma_bf16(A[sa], Bv, acc[nt][kx]);
           }
@@ -261,10 +273,15 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
 #pragma unroll
           for (int d = 0; d < 4; ++d) Wd[s][4 + d] = c[d];
           if (KS > 1) {
+            if (abl & 2) {
+#pragma unroll
+              for (int d = 0; d < 4; ++d) { Wd[s][d] = c[(d + 1) & 3]; Wd[s][8 + d] = c[(d + 2) & 3]; }
+            } else {
             const pnsfm_u32x4 pv = *reinterpret_cast<const pnsfm_u32x4*>(p - 16);
             const pnsfm_u32x4 nx = *reinterpret_cast<const pnsfm_u32x4*>(p + 16);
 #pragma unroll
             for (int d = 0; d < 4; ++d) { Wd[s][d] = pv[d]; Wd[s][8 + d] = nx[d]; }
+            }
           }
         }
 #pragma unroll
@@ -278,9 +295,10 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
               if ((sh & 1) == 0) Bv[s][d] = Wd[s][4 + d + sh / 2];
               else {
                 const int lo = 4 + d + (sh - 1) / 2;     // (sh - 1) is even: exact division also for negative shifts
-                Bv[s][d] = w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
+                Bv[s][d] = (abl & 4) ? (Wd[s][lo + 1] ^ Wd[s][lo]) : w3_alignbit16(Wd[s][lo + 1], Wd[s][lo]);
               }
             }
+          if (abl & 16) { acc[nt][kx][0] += __builtin_bit_cast(float, Bv[0][0] ^ Bv[1][1] ^ Bv[2][2] ^ Bv[0][3] ^ Bv[1][2] ^ Bv[2][0] ^ A[0][0] ^ A[1][1] ^ A[2][2]); continue; }
           // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
           acc[nt][kx] = pnsfm_mfma_bf16(A[2], Bv[0], acc[nt][kx]);
           acc[nt][kx] = pnsfm_mfma_bf16(A[0], Bv[2], acc[nt][kx]);
@@ -308,21 +326,31 @@ __global__ void __launch_bounds__(256, OCC) conv2d_wgrad3_kernel(Wgrad3Args a) {
     for (int par = 0; par < 2; ++par) {
       const int t = t0 + par;
       if (t < t_end) {
+        if (!(abl & 8) || t == t_begin) {
         __syncthreads();           // every wave is done with the previous tile's patch
         write_patch(raw[par % PDX]);
         __syncthreads();
         if (t + PDX < t_end) load_patch(raw[par % PDX], cur[PDX]);
+        }
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
           const int slot = (par * KPW + i) % RD;
           pnsfm_u32x4 A[3];
+          if (abl & 1) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              A[0][d] = __builtin_bit_cast(unsigned, araw[slot][d]);
+              A[1][d] = __builtin_bit_cast(unsigned, araw[slot][4 + d]);
+              A[2][d] = __builtin_bit_cast(unsigned, araw[slot][(d + 2) & 7]);
+            }
+          } else
           w3_split8(araw[slot], A[0], A[1], A[2]);
           if (do_bias) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) bsum += araw[slot][u];
           }
           const int dt = (i + RD) / KPW, ni = (i + RD) % KPW;       // dt <= 2
-          if (t + dt < t_end) load_a(araw[slot], cur[dt], wk + WK * ni);
+          if (t + dt < t_end && !(abl & 32)) load_a(araw[slot], cur[dt], wk + WK * ni);
           kstep(A, wk + WK * i);
         }
         cur[0] = cur[1]; cur[1] = cur[2]; advance(cur[2]);

@@ -43,6 +43,14 @@ struct Wgrad4Args {
   int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
   int gx, gy, bmap;  // 1-D launch: ci tiles, co groups, block order (pnsfm_common.h: block_map_mode)
 };
+// what-if builds (tools/r6/wgrad_ablate.py; results wrong by construction): -DPNSFM_WG_ABLATE=<mask>, a COMPILE-TIME constant (a run-time
+// switch changed hipcc's register allocation: the 7x7 build ran 2x slower with every switch off) -- 1 no dY split, 2 no neighbour LDS
+// reads, 4 no shifted operands, 8 patch staged for the first tile only, 16 no MFMAs, 32 dY loaded once
+#ifdef PNSFM_WG_ABLATE
+#define PNSFM_WG_ABL(a) (PNSFM_WG_ABLATE)
+#else
+#define PNSFM_WG_ABL(a) 0
+#endif
 
 #ifdef PNSFM_EMU
 static inline unsigned w4_alignbit16(unsigned hi, unsigned lo) { return (lo >> 16) | (hi << 16); }
@@ -219,6 +227,7 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
 
   // one k-step: pieces of B in the order l, m, h so that every accumulator sees its smallest products first:
   // (h,l) | (m,m) (h,m) | (l,h) (m,h) (h,h)   [A piece, B piece]
+  constexpr int abl = PNSFM_WG_ABL(a);
   auto kstep = [&](const pnsfm_u32x4 (&A)[2][3], int q) {
     const int boff = (a_row[q] * RS + (a_col[q] & 0xffff)) * 2;
 #pragma unroll
@@ -227,14 +236,18 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
       for (int ky = 0; ky < 3; ++ky) {
         const unsigned char* p = bbase + boff + (ky * RS + sb * PIECE) * 2;
         const pnsfm_u32x4 c = *reinterpret_cast<const pnsfm_u32x4*>(p);
-        const unsigned pv = *reinterpret_cast<const unsigned*>(p - 4);      // elements -2, -1
-        const unsigned nx = *reinterpret_cast<const unsigned*>(p + 16);     // elements 8, 9
+        const unsigned pv = (abl & 2) ? c[1] : *reinterpret_cast<const unsigned*>(p - 4);      // elements -2, -1
+        const unsigned nx = (abl & 2) ? c[2] : *reinterpret_cast<const unsigned*>(p + 16);     // elements 8, 9
         pnsfm_u32x4 Bt[3];
+        if (abl & 4) { Bt[0] = c; Bt[2] = c; Bt[0][0] ^= pv; Bt[2][3] ^= nx; }
+        else {
         Bt[0][0] = w4_alignbit16(c[0], pv);   Bt[0][1] = w4_alignbit16(c[1], c[0]);
         Bt[0][2] = w4_alignbit16(c[2], c[1]); Bt[0][3] = w4_alignbit16(c[3], c[2]);
-        Bt[1] = c;
         Bt[2][0] = w4_alignbit16(c[1], c[0]); Bt[2][1] = w4_alignbit16(c[2], c[1]);
         Bt[2][2] = w4_alignbit16(c[3], c[2]); Bt[2][3] = w4_alignbit16(nx, c[3]);
+        }
+        Bt[1] = c;
+        if (abl & 16) { acc[0][ky][0][0] += __builtin_bit_cast(float, Bt[0][0] ^ Bt[2][3] ^ A[0][0][0] ^ A[1][2][3] ^ A[0][1][1] ^ A[1][1][2] ^ A[1][0][0] ^ A[0][2][3]); continue; }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -252,22 +265,35 @@ __global__ void __launch_bounds__(256, 2) conv2d_wgrad4_kernel(Wgrad4Args a) {
     if (t_begin < t_end) load_a(araw[L], cur[0], L);
   if (t_begin < t_end) load_patch(cur[0]);
   for (int t = t_begin; t < t_end; ++t) {
+    if (!(abl & 8) || t == t_begin) {
     __syncthreads();           // every wave is done with the previous tile's patch
     write_patch();
     __syncthreads();
     if (t + 1 < t_end) load_patch(cur[1]);
+    }
 #pragma unroll
     for (int q = 0; q < KSTEPS; ++q) {
       const int slot = q % RD;
       pnsfm_u32x4 A[2][3];
+      if (abl & 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            A[s2][0][d] = __builtin_bit_cast(unsigned, araw[slot][s2][d]);
+            A[s2][1][d] = __builtin_bit_cast(unsigned, araw[slot][s2][4 + d]);
+            A[s2][2][d] = __builtin_bit_cast(unsigned, araw[slot][s2][(d + 2) & 7]);
+          }
+      } else {
       w4_split8(araw[slot][0], A[0][0], A[0][1], A[0][2]);
       w4_split8(araw[slot][1], A[1][0], A[1][1], A[1][2]);
+      }
       if (do_bias) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { bsum0 += araw[slot][0][u]; bsum1 += araw[slot][1][u]; }
       }
       const int dt = (q + RD) / KSTEPS, nq = (q + RD) % KSTEPS;      // dt <= 1 (RD <= KSTEPS)
-      if (t + dt < t_end) load_a(araw[slot], cur[dt], nq);
+      if (t + dt < t_end && !(abl & 32)) load_a(araw[slot], cur[dt], nq);
       kstep(A, q);
     }
     cur[0] = cur[1]; cur[1] = cur[2]; advance(cur[2]);

@@ -210,7 +210,8 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
 /* Round 6: when a (sample, group) slab -- (C / G) * HW contiguous floats -- is at most 64 K floats and HW % 4 == 0, the two entry
  * points above run ONE launch each (forward: slab in registers, statistics + normalise + activation; backward: slab blocks write dx,
  * channel blocks write dgamma / dbeta; csrc/groupnorm.hip) instead of two; stats_ws / red_ws are then not touched.
- * pnsfm_set_gn_fused(0) (or PNSFM_GN_FUSED=0 in the environment) keeps the two-launch form everywhere; returns the previous setting. */
+ * pnsfm_set_gn_fused(0) (or PNSFM_GN_FUSED=0 in the environment) keeps the two-launch form everywhere; returns the previous setting.
+ * stats_ws / red_ws may be null: the two-launch form then keeps its partial sums in the stream's scratch buffer. */
 int pnsfm_set_gn_fused(int on);
 
 /* ---- packing / unpacking data movement ------------------------------------------------------

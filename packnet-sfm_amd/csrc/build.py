@@ -50,5 +50,32 @@ def build_hip(force=False, verbose=True):
     return LIB
 
 
+SEQ_SRC = os.path.join(HERE, "seq", "pnsfm_seq.cpp")
+SEQ_LIB = os.path.abspath(os.path.join(HERE, "..", "packnet_sfm", "hip", "_pnsfm_seq.so"))
+
+
+def build_seq(force=False, verbose=True):
+    """The block sequencer (csrc/seq/pnsfm_seq.cpp): a host-only torch C++ extension (g++, no device code) that holds the bodies of
+    the hot autograd nodes; it reaches the kernels through function pointers into libpnsfm_hip.so handed over at import time
+    (packnet_sfm/hip/_seq.py), so it links against torch only.  In-tree, next to the Python it serves."""
+    deps = [SEQ_SRC, os.path.join(HERE, "..", "..", "include", "pnsfm.h")]
+    if not force and not _stale(SEQ_LIB, deps):
+        return SEQ_LIB
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    libdirs = ce.library_paths()
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DTORCH_EXTENSION_NAME=_pnsfm_seq",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           SEQ_SRC, "-o", SEQ_LIB, "-I" + sysconfig.get_paths()["include"]]
+    cmd += ["-I" + i for i in ce.include_paths()] + ["-L" + d for d in libdirs]
+    cmd += ["-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"] + ["-Wl,-rpath," + d for d in libdirs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return SEQ_LIB
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv))
+    print(build_seq(force="--force" in sys.argv))

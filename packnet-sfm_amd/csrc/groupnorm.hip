@@ -672,6 +672,9 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
   }
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
   dim3 grid(ceil_div(BC, g.rows), g.nchunk);
+  // stats_ws == null: the partial sums live in the stream's scratch buffer (they are dead when this call's second launch has run)
+  ScratchLease lease(s, stats_ws ? 0 : pnsfm_groupnorm_ws_doubles(B, C, G) * sizeof(double));
+  if (!stats_ws) { stats_ws = lease.as<double>(); if (!stats_ws) return -1; }
   if (vec) PNSFM_LAUNCH((gn_stats_kernel<true>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
   else PNSFM_LAUNCH((gn_stats_kernel<false>), grid, dim3(256), 0, s, x, res, stats_ws, BC, C, HW, G, g);
   int e = check_launch("gn_stats");
@@ -721,6 +724,8 @@ int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* r
   }
   const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
   dim3 grid(ceil_div(BC, g.rows), g.nchunk);
+  ScratchLease lease(s, red_ws ? 0 : pnsfm_groupnorm_ws_doubles(B, C, G) * sizeof(double));
+  if (!red_ws) { red_ws = lease.as<double>(); if (!red_ws) return -1; }
   int e = 0;
   if (vec) PNSFM_LAUNCH((gn_bwd_reduce_kernel<true>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);
   else PNSFM_LAUNCH((gn_bwd_reduce_kernel<false>), grid, dim3(256), 0, s, dy, x, res, gamma, beta, mean, rstd, red_ws, BC, C, HW, G, act, g);

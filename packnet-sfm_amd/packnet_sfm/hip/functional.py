@@ -11,6 +11,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
+from . import _seq
 from ._lib import HipError as _HipError
 
 # bumped by optimizers that update parameters through raw pointers (bypassing tensor._version)
@@ -349,6 +350,18 @@ class _WgradStream:
 _FAST_FORK = os.environ.get('PNSFM_FAST_FORK', '1') != '0'
 
 
+def _seq_streams(dy, want_w):
+    """(main raw stream, side raw stream or 0, side torch Stream or None) for a sequencer backward body: the weight gradient goes to the
+    side stream under exactly the conditions _WgradStream.run(pure=True) takes the one-call fork."""
+    if not dy.is_cuda:
+        return 0, 0, None
+    main_raw = ops.launch_stream_raw(dy.device)
+    if want_w and _FAST_FORK and _WgradStream.use_for(dy):
+        side = _WgradStream.get(dy.device)
+        return main_raw, side.cuda_stream, side
+    return main_raw, 0, None
+
+
 def set_wgrad_stream(on):
     _WgradStream.enabled = bool(on)
 
@@ -485,7 +498,11 @@ class Conv2dFn(Function):
         Cout, Cin, ks, _ = weight.shape
         if x.shape[1] != Cin:
             raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], Cin))
-        y = ops.conv2d_forward(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
+        sq = _seq.get()
+        if sq is not None:
+            y = sq.conv2d_forward([x], wp_fwd, bias, Cin, Cout, ks, ops.launch_stream_raw(x.device))
+        else:
+            y = ops.conv2d_forward(x, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
         ctx.save_for_backward(x, wp_bwd if wp_bwd is not None else x.new_empty(0))
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
@@ -509,6 +526,14 @@ class Conv2dFn(Function):
         want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
         detached = _WgradStream.side_ok(*ctx.params)
         sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[1])
+        sq = _seq.get()
+        if sq is not None and (g_tap is None or get_conv_math() == 'bx3'):
+            main_raw, side_raw, side = _seq_streams(dy, want_w)
+            dx, dw, db = sq.conv2d_backward(dy, [x], wp_bwd, Cin, Cout, ks, has_bias, bool(ctx.needs_input_grad[0]), bool(want_w), sw, sb, g_tap,
+                                            main_raw, side_raw, bool(detached), side)
+            if side is not None and detached:
+                _WgradStream._pending.add(dy.device)
+            return dx, dw, db, None, None, None
         wait = None
         if want_w and _WgradStream.use_for(dy):
             r = _WgradStream.run(lambda: ops.conv2d_backward_weight(x, dy, ks, want_bias=has_bias, dw_out=sw, db_out=sb), x, dy,
@@ -584,7 +609,11 @@ class Conv2dCatFn(Function):
         Cout, Cin, ks, _ = weight.shape
         if sum(t.shape[1] for t in xs) != Cin:
             raise RuntimeError("conv2d_cat: inputs have %d channels, weight expects %d" % (sum(t.shape[1] for t in xs), Cin))
-        y = ops.conv2d_forward_cat(xs, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
+        sq = _seq.get()
+        if sq is not None:
+            y = sq.conv2d_forward(list(xs), wp_fwd, bias, Cin, Cout, ks, ops.launch_stream_raw(xs[0].device))
+        else:
+            y = ops.conv2d_forward_cat(xs, wp_fwd, bias.detach() if bias is not None else None, Cout, ks)
         ctx.save_for_backward(wp_bwd if wp_bwd is not None else xs[0].new_empty(0), *xs)
         ctx.meta = (Cin, Cout, ks, bias is not None)
         ctx.params = (weight, bias)
@@ -602,6 +631,21 @@ class Conv2dCatFn(Function):
         detached = _WgradStream.side_ok(*ctx.params)
         sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[0])
         want_w = ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1])
+        sq = _seq.get()
+        if sq is not None and (not want_w or (ctx.cat_wgrad and get_conv_math() == 'bx3')):
+            need_dx = any(ctx.needs_input_grad[5:])
+            main_raw, side_raw, side = _seq_streams(dy, want_w)
+            dx, dw, db = sq.conv2d_backward(dy, list(xs), wp_bwd, Cin, Cout, ks, has_bias, need_dx, bool(want_w), sw, sb, None, main_raw, side_raw,
+                                            bool(detached), side)
+            if side is not None and detached:
+                _WgradStream._pending.add(dy.device)
+            if need_dx:
+                c0 = 0
+                for i, t in enumerate(xs):
+                    if ctx.needs_input_grad[5 + i]:
+                        dxs[i] = dx[:, c0:c0 + t.shape[1]]
+                    c0 += t.shape[1]
+            return (dw, db, None, None, None) + tuple(dxs)
 
         def wgrad():
             # (the envelope was decided at forward time under the arithmetic mode in force THEN; a set_conv_math('f32') between
@@ -657,12 +701,8 @@ class ConvGnActFn(Function):
     (layers01.py:28-37).  xs: 1..3 tensors (the decoder's concatenations stay folded into the K loop).  One node instead of two halves
     the autograd / Python overhead of the block (profiles/r05_host_profile.txt: ~35 us per Function.apply, the host needs 16-18 ms
     to enqueue a 24 ms step).
-    PNSFM_CONV_GN_STATS=1 (off by default): the conv kernel's epilogue also leaves the GroupNorm statistics of its output behind
-    (ops.conv2d_forward_gn) and the block runs two launches instead of three.  Built, parity-tested and measured NEUTRAL to slightly
-    negative (profiles/r05_ab_conv_gn_stats.txt: 164.6 / 165.4 vs 164.5 / 165.4 img/s at 192x640, 48.9 vs 48.7 at 384x1280): the
-    statistics kernel it removes re-reads y at the HBM roof (0.25 ms per step over the ~32 layers that qualify), but per-(tile, wave)
-    partials are 1 920 - 7 680 slots per (sample, group) on the full-resolution maps, which every row of gn_apply adds up again
-    (gn_stats hands it <= 256), and the epilogue's shuffle tree costs the conv kernels 0.8 %."""
+    Round 6: both bodies are ONE call into the block sequencer (csrc/seq/pnsfm_seq.cpp) when it is loaded.  (The conv epilogue that
+    also left the GroupNorm statistics behind -- round 5, measured neutral twice, profiles/r05_ab_conv_gn_stats.txt -- is gone.)"""
 
     @staticmethod
     def forward(ctx, weight, bias, gamma, beta, cache, recording, cat_wgrad, G, eps, act, tap, *xs):
@@ -674,16 +714,16 @@ class ConvGnActFn(Function):
         if sum(t.shape[1] for t in xs) != Cin:
             raise RuntimeError("conv_gn_act: inputs have %d channels, weight expects %d" % (sum(t.shape[1] for t in xs), Cin))
         bias_d = bias.detach() if bias is not None else None
-        if _CONV_GN_STATS:
-            y, ws, nslot = ops.conv2d_forward_gn(xs, wp_fwd, bias_d, Cout, ks, G)
+        sq = _seq.get()
+        if sq is not None:
+            # ONE call: conv -> GroupNorm statistics -> normalise + activation (csrc/seq/pnsfm_seq.cpp)
+            out, y, ms = sq.conv_gn_act_forward(list(xs), wp_fwd, bias_d, gamma, beta, Cin, Cout, ks, G, float(eps), act,
+                                                ops.launch_stream_raw(xs[0].device))
         else:
             y = ops.conv2d_forward(xs[0], wp_fwd, bias_d, Cout, ks) if len(xs) == 1 else ops.conv2d_forward_cat(xs, wp_fwd, bias_d, Cout, ks)
-            ws, nslot = None, 0
-        if nslot > 0:
-            out, mean, rstd = ops.groupnorm_act_apply(y, gamma.detach(), beta.detach(), ws, nslot, G, eps, act)
-        else:
             out, mean, rstd = ops.groupnorm_act_forward(y, None, gamma.detach(), beta.detach(), G, eps, act)
-        ctx.save_for_backward(wp_bwd if wp_bwd is not None else y.new_empty(0), y, gamma, beta, mean, rstd, *xs)
+            ms = mean._base        # [mean | rstd]: one allocation (ops.groupnorm_act_forward)
+        ctx.save_for_backward(wp_bwd if wp_bwd is not None else y.new_empty(0), y, gamma, beta, ms, *xs)
         ctx.meta = (Cin, Cout, ks, bias is not None, G, act)
         ctx.params = (weight, bias)
         _WgradStream.note_use(recording, weight, bias)
@@ -698,14 +738,35 @@ class ConvGnActFn(Function):
     def backward(ctx, dout, g_tap=None):
         if dout is None:       # only the tap was used: its gradient passes straight through
             return (None,) * 11 + (g_tap,)
-        wp_bwd, y, gamma, beta, mean, rstd, *xs = ctx.saved_tensors
+        wp_bwd, y, gamma, beta, ms, *xs = ctx.saved_tensors
         Cin, Cout, ks, has_bias, G, act = ctx.meta
-        dy, dgamma, dbeta = ops.groupnorm_act_backward(dout.contiguous(), y, None, gamma.detach(), beta.detach(), mean, rstd, G, act)
         dxs = [None] * len(xs)
         dw = db = None
         detached = _WgradStream.side_ok(*ctx.params)
         sw, sb = _slots_for(ctx.params[0], ctx.params[1], detached and ctx.needs_input_grad[0])
         want_w = ctx.needs_input_grad[0] or (has_bias and ctx.needs_input_grad[1])
+        sq = _seq.get()
+        if sq is not None and (not want_w or len(xs) == 1 or (ctx.cat_wgrad and get_conv_math() == 'bx3')) and \
+                (g_tap is None or get_conv_math() == 'bx3'):
+            # ONE call: GroupNorm backward -> fork -> weight gradient (side stream) -> backward-data (+ tap) [-> join]
+            need_dx = any(ctx.needs_input_grad[11:])
+            main_raw, side_raw, side = _seq_streams(dout, want_w)
+            dx, dw, db, dgamma, dbeta = sq.conv_gn_act_backward(dout, y, gamma, beta, ms, list(xs), wp_bwd, Cin, Cout, ks, G, act, has_bias, need_dx,
+                                                                bool(want_w), sw, sb, g_tap if len(xs) == 1 else None, main_raw, side_raw,
+                                                                bool(detached), side)
+            if side is not None and detached:
+                _WgradStream._pending.add(dout.device)
+            if need_dx:
+                if len(xs) == 1:
+                    dxs[0] = dx
+                else:
+                    c0 = 0
+                    for i, t in enumerate(xs):
+                        if ctx.needs_input_grad[11 + i]:
+                            dxs[i] = dx[:, c0:c0 + t.shape[1]]
+                        c0 += t.shape[1]
+            return (dw, db, dgamma, dbeta, None, None, None, None, None, None, None) + tuple(dxs)
+        dy, dgamma, dbeta = ops.groupnorm_act_backward(dout.contiguous(), y, None, gamma.detach(), beta.detach(), ms[0], ms[1], G, act)
 
         def wgrad():
             if len(xs) == 1:
@@ -738,14 +799,6 @@ class ConvGnActFn(Function):
 
 
 _CONV_GN_FUSE = os.environ.get('PNSFM_CONV_GN_FUSE', '1') != '0'
-_CONV_GN_STATS = os.environ.get('PNSFM_CONV_GN_STATS', '0') == '1'
-
-
-def set_conv_gn_stats(on):
-    global _CONV_GN_STATS
-    _CONV_GN_STATS = bool(on)
-
-
 
 def set_conv_gn_fuse(on):
     global _CONV_GN_FUSE
@@ -828,20 +881,29 @@ class GroupNormActFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, G, eps, act):
-        x = x.contiguous()
-        res = res.contiguous() if res is not None else None
-        y, mean, rstd = ops.groupnorm_act_forward(x, res, gamma.detach(), beta.detach(), G, eps, act)
-        ctx.save_for_backward(x, res if res is not None else x.new_empty(0), gamma, beta, mean, rstd)
+        sq = _seq.get()
+        if sq is not None:
+            y, ms, x, res = sq.gn_act_forward(x, res, gamma, beta, G, float(eps), act, ops.launch_stream_raw(x.device))
+        else:
+            x = x.contiguous()
+            res = res.contiguous() if res is not None else None
+            y, mean, rstd = ops.groupnorm_act_forward(x, res, gamma.detach(), beta.detach(), G, eps, act)
+            ms = mean._base
+        ctx.save_for_backward(x, res if res is not None else x.new_empty(0), gamma, beta, ms)
         ctx.meta = (G, act, res is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, res, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, res, gamma, beta, ms = ctx.saved_tensors
         G, act, has_res = ctx.meta
-        dx, dgamma, dbeta = ops.groupnorm_act_backward(dy.contiguous(), x, res if has_res else None, gamma.detach(), beta.detach(),
-                                                       mean, rstd, G, act)
+        sq = _seq.get()
+        if sq is not None:
+            dx, dgamma, dbeta = sq.gn_act_backward(dy, x, res if has_res else None, gamma, beta, ms, G, act, ops.launch_stream_raw(x.device))
+        else:
+            dx, dgamma, dbeta = ops.groupnorm_act_backward(dy.contiguous(), x, res if has_res else None, gamma.detach(), beta.detach(),
+                                                           ms[0], ms[1], G, act)
         return dx, (dx if has_res else None), dgamma, dbeta, None, None, None
 
 

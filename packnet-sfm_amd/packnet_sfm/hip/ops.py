@@ -48,6 +48,19 @@ def current_raw_stream(device):
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
+def launch_stream_raw(device):
+    """The raw stream (int) a launch for `device` goes to right now: this thread's override, else torch's current stream; 0 for the
+    host-emulated build's CPU tensors."""
+    if device.type != 'cuda':
+        return 0
+    ov = getattr(_TLS, 'ov', None)
+    if ov is not None and (ov[1] is None or ov[1] == device.index):
+        return ov[0]
+    if _raw_stream is not None:
+        return int(_raw_stream(device.index))
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
 def stream_wait_stream(waiter_raw, signaler_raw):
     _lib.check(_lib.get().pnsfm_stream_wait_stream(ctypes.c_void_p(waiter_raw), ctypes.c_void_p(signaler_raw)), "stream_wait_stream")
 
@@ -313,9 +326,9 @@ def groupnorm_act_forward(x, res, gamma, beta, G, eps, act):
     y = torch.empty_like(x)
     ms = torch.empty((2, B * G), dtype=torch.float32, device=x.device)       # mean | rstd in one allocation
     mean, rstd = ms[0], ms[1]
-    ws = torch.empty((_gn_ws_doubles(B, C, G),), dtype=torch.float64, device=x.device)
+    # (no workspace tensor: the two-launch form keeps its partial sums in the stream's scratch buffer, the one-launch form has none)
     rc = _lib.get().pnsfm_groupnorm_act_forward(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
-                                                _ptr(ws), B, C, HW, G, float(eps), act, _stream(x))
+                                                None, B, C, HW, G, float(eps), act, _stream(x))
     _lib.check(rc, "groupnorm_act_forward")
     return y, mean, rstd
 
@@ -341,9 +354,8 @@ def groupnorm_act_backward(dy, x, res, gamma, beta, mean, rstd, G, act):
     dx = torch.empty_like(x)
     dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)          # dgamma | dbeta in one allocation
     dgamma, dbeta = dgb[0].view_as(gamma), dgb[1].view_as(beta)
-    ws = torch.empty((_gn_ws_doubles(B, C, G),), dtype=torch.float64, device=x.device)
     rc = _lib.get().pnsfm_groupnorm_act_backward(_ptr(dy), _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
-                                                 _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), B, C, HW, G, act, _stream(x))
+                                                 _ptr(dx), _ptr(dgamma), _ptr(dbeta), None, B, C, HW, G, act, _stream(x))
     _lib.check(rc, "groupnorm_act_backward")
     return dx, dgamma, dbeta
 
@@ -993,6 +1005,11 @@ def region_ops(items):
     if not items:
         return
     ref = items[0][1]
+    from . import _seq
+    sq = _seq.get()
+    if sq is not None:
+        sq.region_ops([(int(op), dst, src) for op, dst, src in items], launch_stream_raw(ref.device))
+        return
     for i0 in range(0, len(items), MAX_REGION_OPS):
         chunk = items[i0:i0 + MAX_REGION_OPS]
         arr = (_RegionOp * len(chunk))()

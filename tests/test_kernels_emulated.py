@@ -688,10 +688,9 @@ def test_flat_adam_matches_torch_adam(emulated_kernels):
 @pytest.mark.parametrize('shape,variant', [(sh, v) for sh in [(2, 32, 64, 5, 32, 3), (1, 16, 128, 6, 20, 3), (1, 20, 64, 7, 40, 5)] for v in (3, 6, 7, 0)] +
                          [(sh, v) for sh in [(1, 48, 256, 5, 24, 3), (1, 32, 512, 4, 32, 1)] for v in (3, 7)])
 def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
-    """Round 5: the Conv2D block as one autograd node whose conv epilogue leaves the GroupNorm statistics behind
-    (hip.functional.ConvGnActFn, csrc/conv2d.hip: conv_epilogue, pnsfm_groupnorm_act_apply) against the two-node form (conv, then
-    statistics + apply) and against torch: output and every gradient.  Channels per group 4 / 8 / 16 / 32 (the four lane layouts of the
-    epilogue reduction), ragged tiles, the ping-pong kernel (7), three workgroups per CU (6), the f32 kernels (0)."""
+    """The Conv2D block as one autograd node (hip.functional.ConvGnActFn; since round 6 its two bodies are single calls into the block
+    sequencer, csrc/seq/pnsfm_seq.cpp) against the two-node form (conv, then GroupNorm + activation) and against torch: output and every
+    gradient.  Channels per group 4 / 8 / 16 / 32, ragged tiles, the ping-pong kernel (7), three workgroups per CU (6), the f32 kernels (0)."""
     import ctypes
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, functional as HF, ops
@@ -711,7 +710,6 @@ def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
     gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
     dout = torch.randn(B, Cout, H, W, generator=g)
     res = {}
-    HF.set_conv_gn_stats(True)          # (off by default: measured neutral; the kernels stay covered here)
     for fused in (True, False):
         HF.set_conv_gn_fuse(fused)
         leaves = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
@@ -729,15 +727,6 @@ def test_conv_gn_act_fused_block(emulated_kernels, shape, variant):
             continue
         P.check(a, c, 2e-5, n + ' fused vs two nodes')
         P.check(a, r, 1e-4, n + ' vs torch')
-    # the epilogue statistics themselves: produced (these shapes do not split K), and equal to the sums over y per (sample, group)
-    wf, _ = ops.conv2d_pack(w, want_bwd=False)
-    y, ws, nslot = ops.conv2d_forward_gn((x,), wf, b, Cout, ks, 16)
-    assert nslot > 0 and nslot % 4 == 0
-    st = ws[:B * 16 * nslot * 2].view(B, 16, nslot, 2).sum(2)
-    yg = y.double().view(B, 16, -1)
-    P.check(st[..., 0], yg.sum(2), 1e-5, 'epilogue sum', floor=1e-3 * float(yg.abs().sum(2).max()))
-    P.check(st[..., 1], (yg * yg).sum(2), 1e-5, 'epilogue sum of squares')
-    HF.set_conv_gn_stats(False)
     lib.pnsfm_set_conv_variant(0)
 
 

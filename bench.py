@@ -588,6 +588,7 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
     if sampler is not None:
         sampler.__exit__()
     exposed = reducer.exposed_ms() if reducer is not None else None
+    host_us = reducer.host_us_per_collective() if reducer is not None else None
     if reducer is not None:
         reducer.exposed_reset(False)
     if world > 1:
@@ -596,7 +597,8 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
         elapsed = float(t.item())
     res = {'elapsed': elapsed, 'loss': float(loss.detach().float().item()), 'timed': None, 'iso': None, 'nprof': 3,
            'clocks': sampler.summary() if sampler is not None else None,
-           'exposed_allreduce_ms_per_step': (round(exposed / steps, 4) if exposed is not None else None)}
+           'exposed_allreduce_ms_per_step': (round(exposed / steps, 4) if exposed is not None else None),
+           'host_us_per_collective': (round(host_us, 1) if host_us is not None else None)}
     # Host-issue headroom: wall time of the Python + ctypes + hipLaunchKernel work that ENQUEUES one step, measured
     # with an empty GPU queue in front of it (fence, then one step, clock stopped when the last launch call returns -- nothing in the
     # step synchronises, and one step's ~800 launches never fill the queue, so the GPU cannot push back).  If this approaches
@@ -780,7 +782,9 @@ def main():
                 'in_place_on_optimizer_arena': args.optimizer == 'flat',
                 'overlap_with_backward': bool(red.overlap),
                 # time the compute stream spent waiting for the communication stream at the end-of-backward join
-                'exposed_ms_per_step': m['exposed_allreduce_ms_per_step']}
+                'exposed_ms_per_step': m['exposed_allreduce_ms_per_step'],
+                # host time of one collective call (ProcessGroup enqueue + the communication stream's stream-ordered wait for it)
+                'host_us_per_collective': m['host_us_per_collective']}
         if world > ndev:
             result['config']['note'] = ('%d ranks share %d device(s): functional rehearsal of the N>1 path over gloo, not a '
                                         'scaling measurement' % (world, ndev))

@@ -207,19 +207,26 @@ int pnsfm_stream_wait_stream(void* waiter, void* signaler) {
   static int next[64] = {0};
   // the event must belong to the device that OWNS the streams, which need not be the calling thread's current device (ADVICE r05:
   // FlatAdam or the reducer running under another device guard); a null handle is the legacy default stream of the current device
-  int cur = 0, dev = -1;
-  if (hipGetDevice(&cur) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipGetDevice failed"); return -1; }
-  hipStream_t probe = signaler ? (hipStream_t)signaler : (hipStream_t)waiter;
-  if (!probe || hipStreamGetDevice(probe, &dev) != hipSuccess) { (void)hipGetLastError(); dev = cur; }
-  if (dev < 0 || dev >= 64) { pnsfm::set_error("stream_wait_stream: bad device %d", dev); return -1; }
-  if (signaler && waiter) {
-    int dw = -1;
-    if (hipStreamGetDevice((hipStream_t)waiter, &dw) == hipSuccess && dw != dev) {
-      pnsfm::set_error("stream_wait_stream: the two streams live on different devices (%d, %d)", dw, dev);
-      return -1;
+  // (the device of a stream handle is looked up once and remembered: this call runs ~90 times per training step)
+  static std::vector<std::pair<void*, int>> known;
+  auto device_of = [&](void* st, int fallback) -> int {
+    if (!st) return fallback;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto& e : known) if (e.first == st) return e.second;
     }
-    (void)hipGetLastError();
-  }
+    int d = -1;
+    if (hipStreamGetDevice((hipStream_t)st, &d) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (known.size() >= 64) known.clear();
+    known.emplace_back(st, d);
+    return d;
+  };
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) { pnsfm::set_error("stream_wait_stream: hipGetDevice failed"); return -1; }
+  const int dev = device_of(signaler, cur), dw = device_of(waiter, dev);
+  if (dev < 0 || dev >= 64) { pnsfm::set_error("stream_wait_stream: bad device %d", dev); return -1; }
+  if (dw != dev) { pnsfm::set_error("stream_wait_stream: the two streams live on different devices (%d, %d)", dw, dev); return -1; }
   struct DevGuard { int prev, now; DevGuard(int p, int n) : prev(p), now(n) { if (p != n) (void)hipSetDevice(n); } ~DevGuard() { if (prev != now) (void)hipSetDevice(prev); } } guard(cur, dev);
   hipEvent_t ev;
   {

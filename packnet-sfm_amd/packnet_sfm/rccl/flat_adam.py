@@ -297,13 +297,21 @@ class FlatAdam:
         """Make g['_grad'] hold the gradients: no copy for gradients that already live in their arena slice.  Returns the
         parameters that have NO gradient this step."""
         src, dst, missing = [], [], []
+        # address of every parameter's arena slice, computed once per arena (246 slice + view_as + data_ptr per step took the host
+        # ~1 ms: profiles/r06_host_profile.txt); a view is only built for the gradients that are NOT already in place
+        ptrs = g.get('_gptr')
+        base = g['_grad'].data_ptr()
+        if ptrs is None or ptrs[0] != base:
+            ptrs = g['_gptr'] = (base, {id(p): base + 4 * g['_offs'][id(p)] for p in g['_order']})
+        at = ptrs[1]
         for p in g['_order']:
-            view = self.grad_view(g, p)
-            if p.grad is None:
-                view.zero_()
+            gr = p.grad
+            if gr is None:
+                self.grad_view(g, p).zero_()
                 missing.append(p)
-            elif p.grad.data_ptr() != view.data_ptr():
-                src.append(p.grad.detach().reshape(view.shape))
+            elif gr.data_ptr() != at[id(p)]:
+                view = self.grad_view(g, p)
+                src.append(gr.detach().reshape(view.shape))
                 dst.append(view)
         if src:
             torch._foreach_copy_(dst, src)

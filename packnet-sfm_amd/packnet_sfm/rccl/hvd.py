@@ -69,8 +69,8 @@ class DistributedOptimizer:
     """optimizer.zero_grad() / backward() / optimizer.step() with gradient averaging across ranks in between.
     Gradients are reduced bucket-by-bucket on a side stream while backward is still running."""
 
-    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=32 << 20,
-                 force_collectives=False, overlap=None, chunk_bytes=64 << 20):
+    def __init__(self, optimizer, named_parameters=None, compression=None, bucket_bytes=96 << 20,
+                 force_collectives=False, overlap=None, chunk_bytes=512 << 20):
         self._opt = optimizer
         params = [p for g in optimizer.param_groups for p in g['params']]
         # an optimizer that keeps its gradients in a flat arena (rccl/flat_adam.py) lends its buckets: reduce + update in place

@@ -23,6 +23,7 @@ MI355X-first choices (not a translation of horovod's tensor-fusion queue):
     stream before the optimizer reads the gradients and applies the 1/world_size averaging.
 """
 import os
+import time as _time
 
 import torch
 import torch.distributed as dist
@@ -81,8 +82,8 @@ class GradBucketReducer:
     average : bool            divide by world size (horovod's `average=True` semantics)
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, average=True, force_collectives=False, buckets=None,
-                 overlap=None, chunk_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=96 << 20, process_group=None, average=True, force_collectives=False, buckets=None,
+                 overlap=None, chunk_bytes=512 << 20):
         self.group = process_group
         self.chunk_bytes = int(chunk_bytes)
         # overlap=False (or PNSFM_DDP_OVERLAP=0): no collective starts before synchronize() -- the A/B leg that shows what the
@@ -96,7 +97,10 @@ class GradBucketReducer:
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._fused_avg = bool(average) and backend == 'nccl'
         self._host_staged = False       # set below: gloo + device tensors -> stage each bucket through host memory
-        self._reduce_op = dist.ReduceOp.AVG if self._fused_avg else dist.ReduceOp.SUM
+        # (a ONE-rank group -- the single-GPU rehearsal of this path, PNSFM_FORCE_DDP=1 -- sums: the mean over one rank is the sum, and RCCL
+        # runs a real 32-workgroup kernel over the whole bucket for a one-rank AVG: 0.75 ms per step for 520 MB, rocprofv3,
+        # profiles/r06_ddp_probe.txt -- the "11 % rehearsal cost" of round 5 was that kernel, not the reducer)
+        self._reduce_op = dist.ReduceOp.AVG if (self._fused_avg and self.world > 1) else dist.ReduceOp.SUM
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError('GradBucketReducer: no trainable parameters')
@@ -139,10 +143,18 @@ class GradBucketReducer:
         self._next = 0          # index of the next bucket to launch
         self._synced = False
         self._exposed = None    # [(event before the join, event after it)] while bench.py measures the exposed all-reduce time
+        self._host_us = None    # host microseconds per collective call (enqueue + stream-ordered wait) while bench.py measures
 
     # ---- measurement: how long the compute stream waits for the communication stream at the end-of-backward join ---------
     def exposed_reset(self, on):
         self._exposed = [] if (on and self.side_stream is not None) else None
+        self._host_us = [] if (on and self.side_stream is not None) else None
+
+    def host_us_per_collective(self):
+        """Mean host time of one collective call (ProcessGroup enqueue + the stream-ordered wait) over the recorded steps, or None."""
+        if not self._host_us:
+            return None
+        return float(sum(self._host_us) / len(self._host_us))
 
     def exposed_ms(self):
         """Sum over the recorded steps of the time between reaching the join and passing it on the compute stream = the part
@@ -224,9 +236,20 @@ class GradBucketReducer:
                 c.copy_(host)
             bucket.work = None
         elif self.side_stream is not None:
-            self.side_stream.wait_stream(torch.cuda.current_stream(self.device))
+            # (the gather that precedes this call has already made the communication stream wait for the compute stream and the
+            # side streams: nothing was enqueued in between)
+            t0 = _time.perf_counter() if self._host_us is not None else 0.0
             with torch.cuda.stream(self.side_stream):
-                bucket.work = [dist.all_reduce(c, op=op, group=self.group, async_op=True) for c in chunks]
+                works = [dist.all_reduce(c, op=op, group=self.group, async_op=True) for c in chunks]
+                # Round 6: the COMMUNICATION stream waits for the collective right away (Work.wait() is stream-ordered: the host does not
+                # block), so that synchronize() needs ONE join of the compute stream with it.  Before, the compute stream itself waited for
+                # every Work at the end of backward: 15 cross-stream event waits in a row on the critical path, 1.5-1.9 ms per step on
+                # one GPU although a one-rank collective launches no kernel (profiles/r05_ddp_probe.txt).
+                for w in works:
+                    w.wait()
+            if self._host_us is not None:
+                self._host_us.append(1e6 * (_time.perf_counter() - t0) / len(chunks))
+            bucket.work = None
         else:
             bucket.work = [dist.all_reduce(c, op=op, group=self.group, async_op=True) for c in chunks]
 

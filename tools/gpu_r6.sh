@@ -42,6 +42,12 @@ ab_env)
     env $AB_VAR=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r06_abenv_$v.log 2>&1
     echo "$AB_VAR=$v: $(tail -1 $O/r06_abenv_$v.log | python -c "$SUMMARY")"
   done; done | tee $O/r06_ab_$AB_VAR.txt ;;
+ab_ddp)
+  # plain step vs the N > 1 code path on one GPU (1-rank RCCL group), alternating
+  for i in 1 2; do for v in 0 1; do
+    PNSFM_FORCE_DDP=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r06_ddp_$v.log 2>&1
+    echo "forced 1-rank collectives $v: $(tail -1 $O/r06_ddp_$v.log | python -c "$SUMMARY") $(tail -1 $O/r06_ddp_$v.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps((d["config"].get("allreduce") or {})))' | cut -c1-400)"
+  done; done | tee $O/r06_ab_forced_ddp.txt ;;
 ab_adam)
   for i in 1 2; do for v in 0 1; do
     PNSFM_ADAM_OVERLAP=$v PNSFM_TUNE_DB=$DB timeout 300 python bench.py --steps 20 --warmup 4 $BARGS > $O/r06_ao_$v.log 2>&1

@@ -628,15 +628,13 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
             ops.prof_enable(False)
             return ops.prof_collect(0), ops.prof_collect(1)
         res['timed'] = profiled(res['nprof'])
-        ws_on, br_on, sc_on = bool(HF._WgradStream.enabled), bool(HF._BRANCH_ON), bool(HF._SHORTCUT_ON)
-        if ws_on or br_on or sc_on:     # side streams (the default): measure the kernels alone as well
+        ws_on, br_on = bool(HF._WgradStream.enabled), bool(HF._BRANCH_ON)
+        if ws_on or br_on:     # side streams (the default): measure the kernels alone as well
             HF.set_wgrad_stream(False)
             HF.set_branch_stream(False)
-            HF.set_shortcut_stream(False)
             res['iso'] = profiled(res['nprof'])
             HF.set_wgrad_stream(ws_on)
             HF.set_branch_stream(br_on)
-            HF.set_shortcut_stream(sc_on)
         else:                           # every kernel already runs alone on the compute stream
             res['iso'] = res['timed']
         # the per-launch table is the ISOLATED pass's (the library's buffer holds the last profiled pass): with the side streams on, a
@@ -694,8 +692,6 @@ def main():
     ndev = torch.cuda.device_count()
     device = torch.device('cuda', hvd.local_rank() % ndev)
     torch.cuda.set_device(device)
-    if os.environ.get('PNSFM_MAIN_PRIORITY'):      # experiment: the step on a high-priority compute stream (profiles/r05_ab_side_priority.txt)
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ['PNSFM_MAIN_PRIORITY'])))
 
     H, W, B = args.height, args.width, args.batch
     model = build_model(device, args.depth_net)
@@ -751,7 +747,6 @@ def main():
                        'optimizer': ('FlatAdam (flat arenas = all-reduce buckets, conv weight gradients written in place)'
                                      if args.optimizer == 'flat' else 'torch.optim.Adam(fused=True)'),
                        'wgrad_side_stream': bool(HF._WgradStream.enabled), 'pose_branch_stream': bool(HF._BRANCH_ON),
-                       'shortcut_stream': bool(HF._SHORTCUT_ON),
                        'tuning': ('user database %s' % os.environ['PNSFM_TUNE_DB']) if os.environ.get('PNSFM_TUNE_DB') else
                                  ('shipped database (%d decisions) + autotune for unlisted shapes' % ops.tune_shipped_entries()
                                   if ops.tune_shipped_entries() else 'autotune during warm-up'),

@@ -58,16 +58,6 @@ int pnsfm_conv2d_pack_item_fill(void* item_host, const float* w, float* wp_fwd, 
 int pnsfm_conv2d_pack_table(const void* table_dev, int n_items, int total_blocks, void* stream);
 int pnsfm_conv2d_forward(const float* x, const float* wp_fwd, const float* bias /*nullable*/, float* y,
                          int B, int Cin, int Cout, int H, int W, int ks, void* stream);
-/* Forward convolution that also leaves the GroupNorm statistics of its OUTPUT behind (round 5; replaces nn.Conv2d + the first pass
- * of nn.GroupNorm in Conv2D, layers01.py:28-37): the epilogue of the conv kernel writes, per (sample, group), *nslot partial {sum, sum
- * of squares} pairs (doubles, [(b G + g)][slot][2]) into stats_ws[pnsfm_conv2d_gn_ws_doubles(B, G, H, W)], which
- * pnsfm_groupnorm_act_apply consumes -- the layer needs no statistics pass over y.  Inputs as pnsfm_conv2d_forward_cat (x1 / x2 may be
- * null with C1 = C2 = 0: a single tensor).  *nslot == 0 on return: this launch could not produce them (a K-split configuration, or
- * Cout / G not in {4, 8, 16, 32}); call pnsfm_groupnorm_act_forward instead. */
-size_t pnsfm_conv2d_gn_ws_doubles(int B, int G, int H, int W);
-int pnsfm_conv2d_forward_gn(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* wp_fwd,
-                            const float* bias, float* y, double* stats_ws, int G, int* nslot, int B, int Cout, int H, int W, int ks,
-                            void* stream);
 int pnsfm_conv2d_backward_data(const float* dy, const float* wp_bwd, float* dx,
                                int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 /* Round 5: dx = backward-data + addend.  A tensor with two consumers (the encoder feature that is also a decoder skip input,
@@ -199,10 +189,6 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res /*nullable*/, c
                                 const float* beta, float* y, float* mean, float* rstd, double* stats_ws,
                                 int B, int C, int HW, int G, float eps, int act, void* stream);
 /* red_ws: double[pnsfm_groupnorm_ws_doubles(B, C, G)] scratch. dx is the gradient w.r.t. x (and, identically, w.r.t. res). */
-/* The normalisation + activation pass alone, on statistics a convolution left behind (pnsfm_conv2d_forward_gn): stats
- * [(b G + g)][nslot][2] doubles; mean / rstd [B*G] are written for the backward pass as pnsfm_groupnorm_act_forward does. */
-int pnsfm_groupnorm_act_apply(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                              const double* stats, int nslot, int B, int C, int HW, int G, float eps, int act, void* stream);
 int pnsfm_groupnorm_act_backward(const float* dy, const float* x, const float* res /*nullable*/,
                                  const float* gamma, const float* beta, const float* mean, const float* rstd,
                                  float* dx, float* dgamma, float* dbeta, double* red_ws,
@@ -315,19 +301,6 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
 /* Variants that keep scalars on the device (round 4: no ATen launch between these kernels and autograd): forward_mean writes
  * loss_mean float[1] = loss_sum / (B*H*W); backward_dev multiplies grad_scale by upstream[0] (device scalar, nullable) and takes
  * clip = 0 | 1 (the byte layout of pnsfm_photometric_forward / _forward_clip). */
-/* Round 5: view synthesis fused into the photometric loss (reference: losses/multiview_photometric_loss.py:127-253 -- warp_ref_image,
- * SSIM, calc_photometric_loss, automask + reduce -- with geometry/camera.py:112-191 and camera_utils.py:27-59 inside): the kernels
- * warp the J context images `ref` [J][B][3][H][W] to the target view themselves (inv_depth [B][H][W], K / refK [B][3][3], T [J][B][4][4],
- * padding_mode 0 zeros | 1 border | 2 reflection), no `warped` tensor and no gradient of it ever exists.  loss_mean: float[1], the
- * pixel mean of the reduced map; argmin as pnsfm_photometric_forward.  Backward: d_inv_depth [B][H][W], dT [J][B][4][4].  No clipping,
- * ssim_weight > 0 (other configurations: pnsfm_view_synthesis_* + pnsfm_photometric_*). */
-int pnsfm_photometric_warp_forward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
-                                   const float* T, float* loss_mean, uint8_t* argmin, int J, int B, int H, int W, float ssim_weight,
-                                   float C1, float C2, int automask, int reduce_op, int padding_mode, void* stream);
-int pnsfm_photometric_warp_backward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
-                                    const float* T, const uint8_t* argmin, float* d_inv_depth, float* dT, float grad_scale,
-                                    const float* upstream, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
-                                    int automask, int reduce_op, int padding_mode, void* stream);
 int pnsfm_photometric_forward_mean(const float* warped, const float* ref, const float* target, float* loss_mean, uint8_t* argmin,
                                    int J, int B, int H, int W, float ssim_weight, float C1, float C2, int automask, int reduce_op,
                                    void* stream);

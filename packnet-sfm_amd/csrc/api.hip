@@ -102,8 +102,7 @@ void* scratch_get(hipStream_t stream, size_t bytes) {
 }
 
 int block_map_mode() {
-  static const int mode = [] { const char* e = getenv("PNSFM_BLOCK_MAP"); const int m = e ? atoi(e) : 2; return m < 0 || m > 2 ? 2 : m; }();
-  return mode;
+  return 2;      // one contiguous range of the operand-sharing logical order per XCD (rounds 2-3's orders 0 / 1 and their A/B switch are gone)
 }
 
 int ensure_lds_limit(const void* kernel, unsigned long long* mask, int bytes, const char* what) {

@@ -51,15 +51,8 @@ static int conv_math() {
   return g_conv_math;
 }
 // K-channels >= 16 (one bf16 MFMA k-step is 16 channels).  1x1 layers (the residual shortcuts) joined in round 3: on the f32
-// kernels they ran at 21-35 TFLOP/s -- one tap of 64-cycle MFMAs per staged chunk; PNSFM_BX3_1X1=0 keeps them there (A/B).
-static int g_bx3_1x1 = -1;
-bool conv_bx3_supported(int Kc, int ks) {
-  if (g_bx3_1x1 < 0) {
-    const char* e = getenv("PNSFM_BX3_1X1");
-    g_bx3_1x1 = (e && e[0] == '0') ? 0 : 1;
-  }
-  return Kc >= 16 && (ks >= 3 || (ks == 1 && g_bx3_1x1 == 1));
-}
+// kernels they ran at 21-35 TFLOP/s -- one tap of 64-cycle MFMAs per staged chunk.
+bool conv_bx3_supported(int Kc, int ks) { return Kc >= 16 && (ks >= 3 || ks == 1); }
 static bool conv_use_bx3(int Kc, int ks) { return conv_math() == 1 && conv_bx3_supported(Kc, ks); }
 
 static const size_t kMaxSmem = 64 * 1024;        // register-staged / patch-DMA variants (default dynamic-LDS limit)
@@ -377,11 +370,6 @@ struct ConvArgs {
   int PB;             // bx3 variants: patch buffers in LDS (1 | 2)
   int playout;        // bx3 variants: patch layout in LDS (1: half planes, conflict-free B fragments; 0: round 2's)
   int gx, gy, bmap;   // bx3 variants (1-D launch): pixel tiles, output-channel tiles, block order (pnsfm_common.h: block_map_mode)
-  // round 5: GroupNorm statistics of the OUTPUT from the epilogue (un-split launches only): per (sample, group, pixel tile, wave) the
-  // sum and the sum of squares of the wave's part of the tile, as doubles in gn_apply's slot layout [(b G + g)][slot][2],
-  // slot = tile-in-image * 4 + wave, gn_nslot = tiles_per_img * 4.  null: off.
-  double* gn_stats;
-  int gn_G, gn_nslot;
   // round 5: y = conv + bias + addend -- the other gradient of a tensor with two consumers (skip connection, 1x1 shortcut), added where
   // the backward-data result is in registers instead of by a separate elementwise pass (3 passes over the tensor and a launch each).
   // [B][Cout][H][W] with `addend_bs` floats between samples (a channel slice of a wider tensor is fine).  null: off.
@@ -466,58 +454,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
       for (int nt = 0; nt < NT; ++nt)
         if (co < a.Cout && pvalid[nt]) yb[(size_t)co * HW + poff[nt]] = acc[mt][nt][r];
     }
-  // ---- GroupNorm statistics of this wave's part of the tile (round 5; the layer's gn_stats launch re-read the whole tensor for
-  // them).  A lane holds 16 rows (channels) x NT pixels per 32-row M tile: rows (r & 3) + 8 (r >> 2) + 4 half.  With cpg = Cout / G
-  // channels per group in {4, 8, 16, 32} (the host checks) a group is: cpg 4 -> the four r & 3 of one (r >> 2, half); cpg 8 -> the
-  // same over both halves; cpg 16 -> r >> 3; cpg 32 -> the whole M tile.  Per lane the four (r >> 2) sums are formed first, folded
-  // to the group count, then added over the 32 pixel lanes (and the halves, cpg >= 8) by a fixed shuffle tree; fp32 partial sums of
-  // <= 32 rows x 64 pixels, converted to double for gn_apply, which adds the slots in a fixed order: deterministic.
-  if (a.gn_stats != nullptr && !split && gn_tile >= 0) {
-    const int cpg = a.Cout / a.gn_G;
-    const int lane = (int)(threadIdx.x & 63);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float s1[4], s2[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float v = pvalid[nt] ? acc[mt][nt][4 * q + k] : 0.f;
-            t1 += v;
-            t2 = fmaf(v, v, t2);
-          }
-        s1[q] = t1; s2[q] = t2;
-      }
-      if (cpg >= 16) { s1[0] += s1[1]; s2[0] += s2[1]; s1[2] += s1[3]; s2[2] += s2[3]; s1[1] = s1[2]; s2[1] = s2[2]; }
-      if (cpg >= 32) { s1[0] += s1[1]; s2[0] += s2[1]; }
-      const int ng = cpg >= 32 ? 1 : (cpg >= 16 ? 2 : 4);        // groups this lane holds partial sums of
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (q < ng) {
-#pragma unroll
-          for (int d = 1; d < 32; d <<= 1) { s1[q] += __shfl_xor(s1[q], d); s2[q] += __shfl_xor(s2[q], d); }
-          if (cpg >= 8) { s1[q] += __shfl_xor(s1[q], 32); s2[q] += __shfl_xor(s2[q], 32); }
-        }
-      // writers: lane 0 (every cpg) and, for cpg == 4, lane 32 (the other half's groups)
-      if ((lane & 31) == 0 && (cpg == 4 || half == 0)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < ng) {
-            // first channel of the group inside the 32-row M tile
-            const int row0 = cpg == 4 ? 8 * q + 4 * half : (cpg == 8 ? 8 * q : (cpg == 16 ? 16 * q : 0));
-            const int co = co0 + mt * 32 + row0;
-            if (co < a.Cout) {
-              double* p = a.gn_stats + (((size_t)b * a.gn_G + co / cpg) * a.gn_nslot + (size_t)gn_tile * 4 + gn_wave) * 2;
-              p[0] = (double)s1[q];
-              p[1] = (double)s2[q];
-            }
-          }
-      }
-    }
-  }
+  (void)gn_tile; (void)gn_wave;       // (round 5's GroupNorm statistics from this epilogue are gone: measured neutral twice)
 }
 
 // second stage of a K-split launch: y = bias + sum over the splits' slabs, in split order (bit-reproducible) [+ addend, last]
@@ -989,33 +926,18 @@ extern "C" int pnsfm_debug_set_trace(void* p) { g_trace_buf = (long long*)p; ret
 extern "C" int pnsfm_debug_set_trace_flags(int f) { g_trace_flags = f; return 0; }
 #endif
 
-// GroupNorm statistics wanted from the launch's epilogue (pnsfm_conv2d_forward_gn): where, for how many groups, and the slot count the
-// launch produced (0: this launch could not -- K split, or channels per group not in {4, 8, 16, 32} -- the caller runs gn_stats)
+// extras of a launch's epilogue: the addend of ConvArgs (round 5; null: none).  (The GroupNorm statistics that rode along here in round 5
+// -- pnsfm_conv2d_forward_gn -- were measured neutral twice and removed in round 6.)
 struct ConvGnOut {
-  double* stats;
-  int G;
-  int nslot;
-  const float* addend;      // round 5: the launch's epilogue extras also carry the addend of ConvArgs (null: none)
+  const float* addend;
   size_t addend_bs;
 };
-static bool conv_gn_ok(const ConvGeom& g, int Cout, int G) {
-  if (G <= 0 || Cout % G != 0 || g.splitK != 1) return false;
-  const int cpg = Cout / G;
-  return cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32;
-}
 
 static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int B, int Cin,
                         int Cout, int H, int W, int ks, hipStream_t stream, const char* what, int S, int Hi, int Wi,
                         const ConvSrc* ms = nullptr, ConvGnOut* gn = nullptr) {
   ConvArgs a;
-  a.gn_stats = nullptr; a.gn_G = 0; a.gn_nslot = 0;
   a.addend = gn ? gn->addend : nullptr; a.addend_bs = gn ? gn->addend_bs : 0;
-  if (gn) {
-    gn->nslot = 0;
-    if (gn->stats && conv_gn_ok(g, Cout, gn->G)) {
-      a.gn_stats = gn->stats; a.gn_G = gn->G; a.gn_nslot = gn->nslot = g.tiles_per_img * 4;
-    }
-  }
   a.x = x; a.wp = wp; a.bias = bias; a.y = y;
   a.x1 = ms ? ms->x1 : nullptr; a.x2 = ms ? ms->x2 : nullptr;
   a.C0 = ms ? ms->C0 : Cin; a.C01 = ms ? ms->C0 + ms->C1 : Cin;
@@ -1055,7 +977,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     const double wbytes = 6.0 * Cout * (double)Cin * ks * ks, xbytes = 4.0 * B * (double)Cin * Hi * Wi * wratio;
     if (wmap && wbytes > xbytes && grid.x > 1) a.bmap = 3;
   }
-  { static const int pl = [] { const char* e = getenv("PNSFM_PATCH_LAYOUT"); return (e && e[0] == '0') ? 0 : 1; }(); a.playout = pl; }
+  a.playout = 1;
 #ifdef PNSFM_BX3_ABLATE
   a.ablate = g_ablate;
 #endif
@@ -1704,7 +1626,7 @@ int pnsfm_conv2d_backward_data_add(const float* dy, const float* wp_bwd, float* 
                                    int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
   if (!addend) return pnsfm_conv2d_backward_data(dy, wp_bwd, dx, B, Cin, Cout, H, W, ks, stream);
   if (addend_bstride < (long long)Cin * H * W) { set_error("conv2d_backward_data_add: addend_bstride smaller than a sample"); return -1; }
-  ConvGnOut ex = {nullptr, 0, 0, addend, (size_t)addend_bstride};
+  ConvGnOut ex = {addend, (size_t)addend_bstride};
   return launch_conv(dy, wp_bwd, nullptr, dx, B, Cout, Cin, H, W, ks, (hipStream_t)stream, "conv2d_backward_data_add", 1, 1, 0, 0, nullptr, &ex);
 }
 
@@ -1715,34 +1637,6 @@ static bool conv_ms_ok(int C0, int C1, int C2, int granule, const char* what) {
     return false;
   }
   return true;
-}
-
-// Forward convolution that also leaves the GroupNorm statistics of its output behind (round 5): stats_ws receives, per (sample, group),
-// *nslot partial {sum, sum of squares} pairs as doubles -- the layout pnsfm_groupnorm_act_apply reads -- written by the epilogue of the
-// conv kernel, so the layer needs no gn_stats pass over y.  *nslot == 0 on return: this launch could not produce them (K-split
-// configuration, or Cout / G not in {4, 8, 16, 32}); the caller falls back to pnsfm_groupnorm_act_forward.
-size_t pnsfm_conv2d_gn_ws_doubles(int B, int G, int H, int W) {
-  // slots per image <= 4 waves x pixel tiles; the smallest tile has 128 pixels, ragged rows / columns add at most one tile per row / column band
-  const size_t tiles = (size_t)ceil_div(H, 4) * ceil_div(W, 32) + (size_t)ceil_div(H, 8) * ceil_div(W, 16) + (size_t)ceil_div(H * W, 128) + 8;
-  return (size_t)2 * B * G * tiles * 4;
-}
-int pnsfm_conv2d_forward_gn(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* wp_fwd,
-                            const float* bias, float* y, double* stats_ws, int G, int* nslot, int B, int Cout, int H, int W, int ks,
-                            void* stream) {
-  if (!nslot) { set_error("conv2d_forward_gn: null nslot"); return -1; }
-  ConvGnOut gn = {stats_ws, G, 0, nullptr, 0};
-  int rc;
-  if (C1 == 0 && C2 == 0) {
-    rc = launch_conv(x0, wp_fwd, bias, y, B, C0, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward", 0, 1, 0, 0, nullptr, &gn);
-  } else {      // the decoder's concatenations folded into the K loop (pnsfm_conv2d_forward_cat)
-    const int Cin = C0 + C1 + C2;
-    if (!conv_ms_ok(C0, C1, C2, 16, "conv2d_forward_gn")) return -1;
-    if (!conv_use_bx3(Cin, ks)) { set_error("conv2d_forward_gn: several inputs need the split-bf16 arithmetic (>= 16 channels)"); return -1; }
-    const ConvSrc ms = {x1, x2, C0, C1};
-    rc = launch_conv(x0, wp_fwd, bias, y, B, Cin, Cout, H, W, ks, (hipStream_t)stream, "conv2d_forward_cat", 0, 1, 0, 0, &ms, &gn);
-  }
-  *nslot = gn.nslot;
-  return rc;
 }
 
 int pnsfm_conv2d_forward_cat(const float* x0, int C0, const float* x1, int C1, const float* x2, int C2, const float* wp_fwd,

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256, OCC) conv2d_bx3_kernel(ConvArgs a) {
   const int PS = a.PH * a.PW;
   const int planeB = a.pstride;                  // bytes of one piece plane of the patch
   const int halfB = planeB >> 1;                 // ... which is two half planes: channels 0-7 and 8-15 of the chunk, [pixel][8 ch]
-  const bool hp = a.playout != 0;                // (0: round 2's [pixel][half][8 ch] layout, kept selectable for the A/B: PNSFM_PATCH_LAYOUT)
+  constexpr bool hp = true;                      // half-plane patch layout (round 2's [pixel][half][8 ch] layout and its A/B switch are gone)
   const int tapB = hp ? 16 : 32;                 // bytes between horizontally adjacent pixels of a plane
   const int patchB = 3 * planeB;
   const int G = a.G;

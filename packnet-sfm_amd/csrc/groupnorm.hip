@@ -139,8 +139,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   const int cpg = C / G;
   const int b = bc / C, c = bc - b * C;
   const int gi = c / cpg;
-  // (nslot: partial {sum, sumsq} pairs per (sample, group) -- cpg * nchunk from gn_stats_kernel, or whatever the producing conv
-  // kernel's epilogue wrote: pnsfm_conv2d_forward_gn)
+  // (nslot: partial {sum, sumsq} pairs per (sample, group): cpg * nchunk from gn_stats_kernel)
   const double* sp = stats + (size_t)(b * G + gi) * nslot * 2;
   double t1 = 0.0, t2 = 0.0;
   for (int k = l; k < nslot; k += g.T) { t1 += sp[2 * k]; t2 += sp[2 * k + 1]; }
@@ -682,23 +681,6 @@ int pnsfm_groupnorm_act_forward(const float* x, const float* res, const float* g
   const double n = (double)cpg * (double)HW;
   if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g, cpg * g.nchunk);
   else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, (const double*)stats_ws, mean, rstd, y, BC, C, HW, G, act, n, eps, g, cpg * g.nchunk);
-  return check_launch("gn_apply");
-}
-
-// Second half of the forward pass alone: the statistics were left behind by the producing convolution (pnsfm_conv2d_forward_gn:
-// stats[(b G + g)][nslot][2] doubles).  One launch per layer instead of two, and y is read once instead of twice.
-int pnsfm_groupnorm_act_apply(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                              const double* stats, int nslot, int B, int C, int HW, int G, float eps, int act, void* stream) {
-  if (C % G != 0 || B <= 0 || HW <= 0 || nslot <= 0) { set_error("groupnorm_apply: bad shape C=%d G=%d nslot=%d", C, G, nslot); return -1; }
-  hipStream_t s = (hipStream_t)stream;
-  const bool vec = (HW % 4 == 0);
-  const int BC = B * C;
-  const GnGeom g = gn_geom(BC, HW, vec, PNSFM_GN_MAX_SPLIT);
-  dim3 grid(ceil_div(BC, g.rows), g.nchunk);
-  const double n = (double)(C / G) * (double)HW;
-  const float* res = nullptr;
-  if (vec) PNSFM_LAUNCH((gn_apply_kernel<true>), grid, dim3(256), 0, s, x, res, gamma, beta, stats, mean, rstd, y, BC, C, HW, G, act, n, eps, g, nslot);
-  else PNSFM_LAUNCH((gn_apply_kernel<false>), grid, dim3(256), 0, s, x, res, gamma, beta, stats, mean, rstd, y, BC, C, HW, G, act, n, eps, g, nslot);
   return check_launch("gn_apply");
 }
 

@@ -123,8 +123,8 @@ __device__ __forceinline__ float pad_coordinate(float x, int size, int mode, flo
 }
 
 // The bilinear sample of the three channels of context image (j, b) at the projection of target pixel (u, v): the body of
-// view_synthesis_fwd_kernel, shared with the fused photometric kernels (round 5: they compute the warped images in their tile loaders
-// instead of reading a materialised `warped` tensor).
+// view_synthesis_fwd_kernel.  (Round 5 also called it from photometric kernels that computed the warped images in their tile loaders;
+// measured -0.3 % twice, profiles/r05_ab_loss_fuse.txt, removed in round 6.)
 __device__ __forceinline__ void warp_sample3(const Cam& cam, const float* Tm, float rho, int u, int v, int H, int W, int pad_mode,
                                              const float* __restrict__ rb, float (&out)[3]) {
   const int HW = H * W;
@@ -205,15 +205,6 @@ __device__ __forceinline__ float warp_backward3(const Cam& cam, const float* Tm,
   }
   return rho >= 1e-6f ? -gd * q.d * q.d : 0.f;
 }
-
-// Inputs of the fused view synthesis (inv_depth == null: the photometric kernels read a materialised `warped` tensor as before)
-struct WarpIn {
-  const float* inv_depth;   // [B][H][W]
-  const float* K;           // [B][3][3]
-  const float* refK;        // [B][3][3]
-  const float* T;           // [J][B][4][4]
-  int pad_mode;
-};
 
 // grid: (ceil(HW/256), B, J)
 __global__ void __launch_bounds__(256) view_synthesis_fwd_kernel(const float* __restrict__ inv_depth, const float* __restrict__ ref,
@@ -435,8 +426,7 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
                                                                const float* __restrict__ target, double* __restrict__ loss_sum,
                                                                uint8_t* __restrict__ argmin, int J, int B, int H, int W,
                                                                float ssim_w, float C1, float C2, int automask, int reduce_op,
-                                                               const float* __restrict__ clip_thr, double* __restrict__ stats,
-                                                               WarpIn wi) {
+                                                               const float* __restrict__ clip_thr, double* __restrict__ stats) {
   PNSFM_DYN_SMEM(float, smem);
   __shared__ double red[4];
   const int HW = H * W;
@@ -448,7 +438,6 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
   const int b = (int)(Lb / (gridDim.x * gridDim.y));
   const int tx0 = lbx * PH_T, ty0 = lby * PH_T;
   const int plane = PH_S1 * PH_S1;
-  const bool fused = wi.inv_depth != nullptr;
   // image slots: 0 = target, 1+2j = warped[j], 2+2j = ref[j]
   const int nimg = 1 + 2 * J;
   for (int e = threadIdx.x; e < nimg * 3 * plane; e += 256) {
@@ -462,30 +451,11 @@ __global__ void __launch_bounds__(256) photometric_fwd_kernel(const float* __res
     if (img == 0) src = target + (size_t)b * 3 * HW;
     else {
       const int j = (img - 1) >> 1;
-      if (fused && !((img - 1) & 1)) continue;       // warped slot: computed below
       src = (((img - 1) & 1) ? ref : warped) + ((size_t)j * B + b) * 3 * HW;
     }
     float v = 0.f;
     if (img == 0 || !(((img - 1) & 1) && !automask)) v = src[(size_t)c * HW + gy * W + gx];
     smem[e] = v;
-  }
-  if (fused) {
-    // fused view synthesis: the warped value of every pixel of the tile + halo (the reflected halo pixels are image pixels) is
-    // computed here -- one projection and 4 x 3 taps of the context image per (context, pixel) -- and never goes through memory
-    Cam cam;
-    load_cam(wi.K, wi.refK, b, cam);
-    for (int e = threadIdx.x; e < J * plane; e += 256) {
-      const int j = e / plane, r = e - j * plane;
-      const int ly = r / PH_S1, lx = r - ly * PH_S1;
-      const int gy = reflect_idx(ty0 + ly - 1, H), gx = reflect_idx(tx0 + lx - 1, W);
-      float Tm[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Tm[i] = wi.T[((size_t)j * B + b) * 16 + i];
-      float out[3];
-      warp_sample3(cam, Tm, wi.inv_depth[(size_t)b * HW + gy * W + gx], gx, gy, H, W, wi.pad_mode, ref + ((size_t)j * B + b) * 3 * HW, out);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) smem[((1 + 2 * j) * 3 + c) * plane + r] = out[c];
-    }
   }
   __syncthreads();
   const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
@@ -545,11 +515,8 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
                                                                const uint8_t* __restrict__ argmin, float* __restrict__ d_warped,
                                                                float grad_scale, int J, int B, int H, int W, float ssim_w,
                                                                float C1, float C2, int automask, int reduce_op, int clip,
-                                                               const float* __restrict__ gdev, WarpIn wi,
-                                                               const float* __restrict__ ref, float* __restrict__ d_inv_depth,
-                                                               double* __restrict__ posepart) {
+                                                               const float* __restrict__ gdev) {
   PNSFM_DYN_SMEM(float, smem);
-  __shared__ float redT[4][12];
   if (gdev) grad_scale *= gdev[0];        // upstream gradient of the scalar loss, still on the device (no `d * g` pass over d_warped)
   const int HW = H * W;
   // logical tile order: one contiguous range per XCD (see photometric_fwd_kernel)
@@ -558,12 +525,9 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
   const int b = (int)(Lb / (gridDim.x * gridDim.y));
   const int tx0 = lbx * PH_T, ty0 = lby * PH_T;
   const int plane2 = PH_S2 * PH_S2, plane1 = PH_S1 * PH_S1;
-  const bool fused = wi.inv_depth != nullptr;
-  Cam cam;
-  if (fused) load_cam(wi.K, wi.refK, b, cam);
   float* imgs = smem;                           // [(1+J)][3][20*20]; slot 0 = target, 1+j = warped[j]
   float* coef = smem + (1 + J) * 3 * plane2;    // [J][3 ch][3 (alpha,beta,gamma)][18*18]
-  for (int e = threadIdx.x; e < (fused ? 1 : 1 + J) * 3 * plane2; e += 256) {
+  for (int e = threadIdx.x; e < (1 + J) * 3 * plane2; e += 256) {
     const int img = e / (3 * plane2);
     int r = e - img * 3 * plane2;
     const int c = r / plane2;
@@ -572,20 +536,6 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
     const int gy = reflect_idx(ty0 + ly - 2, H), gx = reflect_idx(tx0 + lx - 2, W);
     const float* src = img == 0 ? target + (size_t)b * 3 * HW : warped + ((size_t)(img - 1) * B + b) * 3 * HW;
     imgs[e] = src[(size_t)c * HW + gy * W + gx];
-  }
-  if (fused) {      // fused view synthesis: the warped images of the tile + 2-pixel halo are recomputed (see photometric_fwd_kernel)
-    for (int e = threadIdx.x; e < J * plane2; e += 256) {
-      const int j = e / plane2, r = e - j * plane2;
-      const int ly = r / PH_S2, lx = r - ly * PH_S2;
-      const int gy = reflect_idx(ty0 + ly - 2, H), gx = reflect_idx(tx0 + lx - 2, W);
-      float Tm[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Tm[i] = wi.T[((size_t)j * B + b) * 16 + i];
-      float out[3];
-      warp_sample3(cam, Tm, wi.inv_depth[(size_t)b * HW + gy * W + gx], gx, gy, H, W, wi.pad_mode, ref + ((size_t)j * B + b) * 3 * HW, out);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) imgs[((1 + j) * 3 + c) * plane2 + r] = out[c];
-    }
   }
   __syncthreads();
   const int ncand = J * (automask ? 2 : 1);
@@ -632,18 +582,14 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
   const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
   const int qy = ty0 + ly, qx = tx0 + lx;
   const bool active = qy < H && qx < W;
-  if (!active && !fused) return;
+  if (!active) return;
   const int q2 = (ly + 2) * PH_S2 + lx + 2;
   int selq = -1;
   if (active && (reduce_op == 0 || clip)) selq = (int)argmin[(size_t)b * HW + qy * W + qx];
-  const float rho = (fused && active) ? wi.inv_depth[(size_t)b * HW + qy * W + qx] : 1.f;
-  float g_rho = 0.f;
   for (int j = 0; j < J; ++j) {
     const int cand = j * (automask ? 2 : 1);
     const float uq = reduce_op == 0 ? (selq == cand ? grad_scale : 0.f)
                                     : ((clip && ((selq >> cand) & 1)) ? 0.f : grad_scale / (float)ncand);
-    float gq[3] = {0.f, 0.f, 0.f};
-    if (active) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float* cp = coef + ((j * 3 + c) * 3) * plane1;
@@ -671,40 +617,9 @@ __global__ void __launch_bounds__(256) photometric_bwd_kernel(const float* __res
       const float diff = xq - yq;
       const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
       g += uq * (1.f - ssim_w) * (1.f / 3.f) * sgn;
-      gq[c] = g;
-      if (!fused) d_warped[(((size_t)j * B + b) * 3 + c) * HW + qy * W + qx] = g;
-    }
-    }
-    if (fused) {
-      // fused view synthesis, backward: this pixel's d loss / d warped[j] goes straight through the bilinear sample and the projection
-      // (warp_backward3 = view_synthesis_bwd_kernel's body): its share of d loss / d inv_depth and of the 12 pose-gradient entries,
-      // which meet per tile like view_synthesis_bwd_kernel's meet per 256-pixel block (fixed order: bit-reproducible)
-      float gT[12];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) gT[i] = 0.f;
-      if (active) {
-        float Tm[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) Tm[i] = wi.T[((size_t)j * B + b) * 16 + i];
-        g_rho += warp_backward3(cam, Tm, rho, qx, qy, H, W, wi.pad_mode, ref + ((size_t)j * B + b) * 3 * HW, gq, gT);
-      }
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) {
-        float v = gT[i];
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
-        if (lane == 0) redT[wave][i] = v;
-      }
-      __syncthreads();
-      if (threadIdx.x < 12) {
-        const int i = threadIdx.x;
-        const size_t nblk = (size_t)gridDim.x * gridDim.y, blk = (size_t)lby * gridDim.x + lbx;
-        posepart[(((size_t)j * B + b) * nblk + blk) * 12 + i] = (double)redT[0][i] + (double)redT[1][i] + (double)redT[2][i] + (double)redT[3][i];
-      }
-      __syncthreads();
+      d_warped[(((size_t)j * B + b) * 3 + c) * HW + qy * W + qx] = g;
     }
   }
-  if (fused && active) d_inv_depth[(size_t)b * HW + qy * W + qx] = g_rho;
 }
 
 // ---- smoothness ------------------------------------------------------------------------------------
@@ -956,61 +871,7 @@ __global__ void __launch_bounds__(256) sn_bwd_apply_kernel(float* __restrict__ d
 
 using namespace pnsfm;
 
-static const WarpIn kNoWarp = {nullptr, nullptr, nullptr, nullptr, 0};
-
 extern "C" {
-
-// Round 5: view synthesis FUSED into the photometric loss (SURVEY 8d's fused loss; reference call sites camera_utils.py:27-59,
-// multiview_photometric_loss.py:127-223): the photometric kernels compute the warped context images of their tile (+ halo) themselves
-// -- one projection and 4 x 3 taps per (context, pixel), through the L1 / L2-resident context image -- instead of reading a `warped`
-// tensor that view_synthesis_fwd had to write first; backward pushes d loss / d warped of a pixel straight through the bilinear
-// sample and the projection, so neither `warped` nor its gradient ([J, B, 3, H, W] each) ever exists.  Two launches forward (loss
-// tiles, scalar finish) and two backward (tiles, pose-gradient finish) per scale instead of 3 + 3, and ~120 B per pixel less traffic.
-// No clipping, ssim_weight > 0 (the configurations the other entry points keep serving).
-int pnsfm_photometric_warp_forward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
-                                   const float* T, float* loss_mean, uint8_t* argmin, int J, int B, int H, int W, float ssim_weight,
-                                   float C1, float C2, int automask, int reduce_op, int padding_mode, void* stream) {
-  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_warp_forward: bad shape (J=%d H=%d W=%d; J<=3)", J, H, W); return -1; }
-  if (!(ssim_weight > 0.f)) { set_error("photometric_warp_forward: ssim_weight must be > 0"); return -1; }
-  if (automask && reduce_op != 0) { set_error("photometric_warp_forward: automask requires the 'min' reduce op"); return -1; }
-  if (padding_mode < 0 || padding_mode > 2) { set_error("photometric_warp_forward: bad padding_mode"); return -1; }
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
-  const int nblk = (int)(grid.x * grid.y * grid.z);
-  ScratchLease lease(s, (size_t)nblk * sizeof(double));
-  double* part = lease.as<double>();
-  if (!part) return -1;
-  const WarpIn wi = {inv_depth, K, refK, T, padding_mode};
-  const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
-  PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, (const float*)nullptr, ref, target, part, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr, wi);
-  PNSFM_LAUNCH(sum_partials_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, 1.0 / ((double)B * H * W), 0.0,
-               (double*)nullptr, loss_mean);
-  return check_launch("photometric_warp_forward");
-}
-
-// d_inv_depth [B][H][W] and dT [J][B][4][4] (last row zero) = grad_scale * upstream[0] * d(loss_sum) / d(.); upstream: device scalar
-int pnsfm_photometric_warp_backward(const float* inv_depth, const float* ref, const float* target, const float* K, const float* refK,
-                                    const float* T, const uint8_t* argmin, float* d_inv_depth, float* dT, float grad_scale,
-                                    const float* upstream, int J, int B, int H, int W, float ssim_weight, float C1, float C2,
-                                    int automask, int reduce_op, int padding_mode, void* stream) {
-  if (J < 1 || J > 3 || H < 3 || W < 3) { set_error("photometric_warp_backward: bad shape (J<=3)"); return -1; }
-  if (padding_mode < 0 || padding_mode > 2) { set_error("photometric_warp_backward: bad padding_mode"); return -1; }
-  hipStream_t s = (hipStream_t)stream;
-  dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
-  const int nblk = (int)(grid.x * grid.y);          // pose-gradient partials per (context, sample)
-  ScratchLease lease(s, (size_t)J * B * nblk * 12 * sizeof(double));
-  double* const part = lease.as<double>();
-  if (!part) return -1;
-  const WarpIn wi = {inv_depth, K, refK, T, padding_mode};
-  const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
-  PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, s, (const float*)nullptr, target, argmin, (float*)nullptr, grad_scale, J, B,
-               H, W, ssim_weight, C1, C2, automask, reduce_op, 0, upstream, wi, ref, d_inv_depth, part);
-  int e = check_launch("photometric_warp_backward");
-  if (e) return e;
-  PNSFM_LAUNCH(view_synthesis_bwd_finish_kernel, dim3(J * B), dim3(64), 0, s, (const double*)part, dT, nblk);
-  return check_launch("photometric_warp_backward_finish");
-}
 
 int pnsfm_view_synthesis_forward_pad(const float* inv_depth, const float* ref, const float* K, const float* refK,
                                      const float* T, float* warped, int J, int B, int H, int W, int padding_mode,
@@ -1084,11 +945,11 @@ int pnsfm_photometric_forward_clip(const float* warped, const float* ref, const 
   if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op, (const float*)nullptr, stats_ws, kNoWarp);
+               C1, C2, automask, reduce_op, (const float*)nullptr, stats_ws);
   PNSFM_LAUNCH(photometric_clip_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)stats_ws, thr_ws, ncand,
                (double)B * H * W, clip_loss);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr, kNoWarp);
+               C1, C2, automask, reduce_op, (const float*)thr_ws, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
   return check_launch("photometric_forward_clip");
 }
@@ -1112,7 +973,7 @@ int pnsfm_photometric_forward(const float* warped, const float* ref, const float
   if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr, kNoWarp);
+               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, loss_sum);
   return check_launch("photometric_forward");
 }
@@ -1124,8 +985,7 @@ static int photometric_backward_impl(const float* warped, const float* target, c
   dim3 grid(ceil_div(W, PH_T), ceil_div(H, PH_T), B);
   const size_t smem = ((size_t)(1 + J) * 3 * PH_S2 * PH_S2 + (size_t)J * 9 * PH_S1 * PH_S1) * sizeof(float);
   PNSFM_LAUNCH(photometric_bwd_kernel, grid, dim3(256), smem, (hipStream_t)stream, warped, target, argmin, d_warped,
-               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op, clip, gdev, kNoWarp, (const float*)nullptr,
-               (float*)nullptr, (double*)nullptr);
+               grad_scale, J, B, H, W, ssim_weight, C1, C2, automask, reduce_op, clip, gdev);
   return check_launch("photometric_backward");
 }
 
@@ -1172,7 +1032,7 @@ int pnsfm_photometric_forward_mean(const float* warped, const float* ref, const 
   if (!part) return -1;
   const size_t smem = (size_t)(1 + 2 * J) * 3 * PH_S1 * PH_S1 * sizeof(float);
   PNSFM_LAUNCH(photometric_fwd_kernel, grid, dim3(256), smem, s, warped, ref, target, part, argmin, J, B, H, W, ssim_weight,
-               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr, kNoWarp);
+               C1, C2, automask, reduce_op, (const float*)nullptr, (double*)nullptr);
   PNSFM_LAUNCH(sum_partials_scaled_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nblk, 1, 1.0 / ((double)B * H * W), 0.0,
                (double*)nullptr, loss_mean);
   return check_launch("photometric_forward_mean");

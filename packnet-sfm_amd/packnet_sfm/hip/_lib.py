@@ -30,8 +30,6 @@ SIGNATURES = {
     "pnsfm_conv2d_pack_item_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i]),
     "pnsfm_conv2d_pack_table": (_i, [_p, _i, _i, _p]),
     "pnsfm_conv2d_forward": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "pnsfm_conv2d_gn_ws_doubles": (_sz, [_i, _i, _i, _i]),
-    "pnsfm_conv2d_forward_gn": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_data_add": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_conv2d_backward_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -42,7 +40,6 @@ SIGNATURES = {
     "pnsfm_conv2d_backward_weight_strided": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "pnsfm_groupnorm_ws_doubles": (_sz, [_i, _i, _i]),
     "pnsfm_groupnorm_act_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
-    "pnsfm_groupnorm_act_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "pnsfm_groupnorm_act_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pnsfm_set_gn_fused": (_i, [_i]),
     "pnsfm_space_to_depth": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -89,8 +86,6 @@ SIGNATURES = {
     "pnsfm_adam_flat_step": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "pnsfm_adam_flat_update": (_i, [_p, _p, _p, _p, _sz, _p, _i, _p]),
     "pnsfm_stream_wait_stream": (_i, [_p, _p]),
-    "pnsfm_photometric_warp_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _p]),
-    "pnsfm_photometric_warp_backward": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _f, _f, _f, _i, _i, _i, _p]),
     "pnsfm_adam_pack_item_bytes": (_sz, []),
     "pnsfm_adam_pack_item_fill": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i]),
     "pnsfm_adam_pack_table": (_i, [_p, _i, _i, _p]),

@@ -157,7 +157,7 @@ def _pack_batch_on():
 
 def repack_all(exclude=None):
     """Re-pack every registered conv weight whose forward AND backward-data buffers exist, one launch per device, and stamp the
-    caches fresh.  `exclude`: ids of parameters already re-packed (repack_subset).  Returns the number of weights packed.  No-op
+    caches fresh.  `exclude`: ids of parameters already re-packed (the optimizer's fused tail).  Returns the number of weights packed.  No-op
     under PNSFM_PACK_BATCH=0 and while a stream is being captured."""
     if not _pack_batch_on():
         return 0
@@ -167,19 +167,6 @@ def repack_all(exclude=None):
         stamp_packed(covered)
         done += len(covered)
     return done
-
-
-def repack_subset(slot, param_ids):
-    """Re-pack the registered conv weights among `param_ids` (ids of parameters) in one launch on the CURRENT stream WITHOUT stamping
-    their caches -- FlatAdam calls this for a bucket it has just updated in the middle of the backward pass, before the optimizer
-    epoch of the step is bumped; it stamps the returned (cache, parameter) pairs in step() (stamp_packed).  `slot`: cache key of
-    the device table (one per bucket)."""
-    if not _pack_batch_on():
-        return []
-    out = []
-    for dev, pairs in _pack_pairs(only=param_ids).items():
-        out += _run_pack_table((dev, slot), dev, pairs)
-    return out
 
 
 def stamp_packed(pairs):
@@ -193,12 +180,6 @@ class _nullctx:
 
     def __exit__(self, *a):
         return False
-
-
-# HIP priority of the weight-gradient side stream (torch numbering: 0 = lowest, negative = higher).  The data gradient on the compute
-# stream is the critical path of backward; PNSFM_SIDE_PRIORITY exists to measure whether the dispatcher honours that
-# (profiles/r05_ab_side_priority.txt).
-_SIDE_PRIORITY = int(os.environ.get('PNSFM_SIDE_PRIORITY', '0'))
 
 
 class _WgradStream:
@@ -292,7 +273,7 @@ class _WgradStream:
     def get(cls, device):
         st = cls._streams.get(device)
         if st is None:
-            st = cls._streams[device] = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
+            st = cls._streams[device] = torch.cuda.Stream(device=device)
         return st
 
     @classmethod
@@ -460,26 +441,6 @@ def set_branch_stream(on):
 def branch_stream(t):
     """The second compute stream of t's device, or None (CPU tensors, switched off)."""
     if not (_BRANCH_ON and torch.is_tensor(t) and t.is_cuda):
-        return None
-    st = _BRANCH_STREAMS.get(t.device)
-    if st is None:
-        st = _BRANCH_STREAMS[t.device] = torch.cuda.Stream(device=t.device)
-    return st
-
-
-# Residual shortcuts (networks/layers/packnet/layers01.py: ResidualConv): the 1x1 convolution of the block input runs on the
-# independent-branch stream as well (one extra stream per device serves both uses; the pose network is enqueued behind the whole
-# depth network, so the two never queue behind each other for long).  PNSFM_SHORTCUT_STREAM=0 switches it off.
-_SHORTCUT_ON = os.environ.get('PNSFM_SHORTCUT_STREAM', '0') == '1'
-
-
-def set_shortcut_stream(on):
-    global _SHORTCUT_ON
-    _SHORTCUT_ON = bool(on)
-
-
-def shortcut_stream(t):
-    if not (_SHORTCUT_ON and torch.is_tensor(t) and t.is_cuda and torch.is_grad_enabled()):
         return None
     st = _BRANCH_STREAMS.get(t.device)
     if st is None:
@@ -1545,52 +1506,11 @@ class PhotometricL1Fn(Function):
         return ops.photometric_l1_backward(warped, target, rec, 1.0 / n, up, automask, reduce_op), None, None, None, None, None
 
 
-class WarpPhotometricFn(Function):
-    """Round 5: view synthesis FUSED into the photometric loss (csrc/loss.hip: pnsfm_photometric_warp_*): the photometric kernels
-    warp the J context images to the target view inside their tile loaders, backward pushes a pixel's gradient straight through the
-    bilinear sample and the projection -- neither `warped` nor its gradient ([J, B, 3, H, W] each) exists, and a scale is 2 + 2
-    launches instead of 3 + 3.  Differentiable w.r.t. inv_depth and the [J, B, 4, 4] pose matrices."""
-
-    @staticmethod
-    def forward(ctx, inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, padding_mode):
-        inv_depth, ref, target, K, refK, T = (t.contiguous() for t in (inv_depth, ref, target, K, refK, T))
-        J, B, _, H, W = ref.shape
-        loss, argmin = ops.photometric_warp_forward(inv_depth, ref, target, K, refK, T.detach(), ssim_w, C1, C2, automask, reduce_op,
-                                                    padding_mode)
-        ctx.save_for_backward(inv_depth, ref, target, K, refK, T, argmin)
-        ctx.meta = (ssim_w, C1, C2, automask, reduce_op, padding_mode, B * H * W)
-        return loss.reshape(())
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
-        inv_depth, ref, target, K, refK, T, argmin = ctx.saved_tensors
-        ssim_w, C1, C2, automask, reduce_op, padding_mode, n = ctx.meta
-        up = g.reshape(1).to(torch.float32).contiguous()
-        d_inv, dT = ops.photometric_warp_backward(inv_depth, ref, target, K, refK, T.detach(), argmin, 1.0 / n, up, ssim_w, C1, C2, automask,
-                                                  reduce_op, padding_mode)
-        return d_inv, None, None, None, None, dT, None, None, None, None, None, None
-
-
-# Measured (profiles/r05_ab_loss_fuse.txt, same box, alternating): 162.7 img/s fused vs 163.2 two-step at 192x640 batch 4 -- the
-# 51 MB per step it stops moving are ~10 us of HBM time, while every tile re-projects its halo (1.27x the pixels forward, 1.56x
-# backward) and backward re-samples what the two-step path kept in `warped`.  Parked OFF (PNSFM_LOSS_FUSE=1 / set_loss_fuse(True));
-# both paths are pinned by the same goldens.
-_LOSS_FUSE = os.environ.get('PNSFM_LOSS_FUSE', '0') != '0'
-
-
-def set_loss_fuse(on):
-    global _LOSS_FUSE
-    _LOSS_FUSE = bool(on)
-
-
 def warp_photometric(inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, clip_loss=0.0, padding_mode='zeros'):
-    """view_synthesis + photometric of one scale: two-step by default, the fused kernels (SSIM + L1 loss without clipping) behind
-    PNSFM_LOSS_FUSE=1."""
+    """view_synthesis + photometric terms of one scale.  (Round 5's single-kernel form -- the warp inside the photometric tile loaders --
+    measured -0.3 % twice, profiles/r05_ab_loss_fuse.txt, and was removed in round 6.)"""
     if padding_mode not in ops.PADDING_MODES:
         raise ValueError('Unknown padding_mode {}'.format(padding_mode))
-    if _LOSS_FUSE and clip_loss == 0.0 and ssim_w > 0.0:
-        return WarpPhotometricFn.apply(inv_depth, ref, target, K, refK, T, ssim_w, C1, C2, automask, reduce_op, ops.PADDING_MODES[padding_mode])
     warped = view_synthesis(inv_depth, ref, K, refK, T, padding_mode)
     return photometric(warped, ref, target, ssim_w, C1, C2, automask, reduce_op, clip_loss)
 

@@ -232,30 +232,6 @@ def conv2d_forward_cat(xs, wp_fwd, bias, Cout, ks):
     return y
 
 
-_CONV_GN_WS = {}
-
-
-def conv2d_forward_gn(xs, wp_fwd, bias, Cout, ks, G):
-    """conv(cat(xs, 1)) (xs: 1..3 NCHW tensors) whose epilogue also leaves the GroupNorm(G) statistics of y behind.  Returns
-    (y, stats workspace, nslot); nslot == 0: the launch could not produce them (K split / unsupported channels per group) and the
-    caller runs groupnorm_act_forward."""
-    _chk(*xs, wp_fwd, bias); _f32(*xs, wp_fwd, bias)
-    B, _, H, W = xs[0].shape
-    C = [t.shape[1] for t in xs] + [0] * (3 - len(xs))
-    lib = _lib.get()
-    key = (B, G, H, W)
-    n = _CONV_GN_WS.get(key)
-    if n is None:
-        n = _CONV_GN_WS[key] = int(lib.pnsfm_conv2d_gn_ws_doubles(B, G, H, W))
-    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xs[0].device)
-    ws = torch.empty((n,), dtype=torch.float64, device=xs[0].device)
-    nslot = ctypes.c_int(0)
-    rc = lib.pnsfm_conv2d_forward_gn(_ptr(xs[0]), C[0], _ptr(xs[1] if len(xs) > 1 else None), C[1], _ptr(xs[2] if len(xs) > 2 else None), C[2],
-                                     _ptr(wp_fwd), _ptr(bias), _ptr(y), _ptr(ws), G, ctypes.byref(nslot), B, Cout, H, W, ks, _stream(xs[0]))
-    _lib.check(rc, "conv2d_forward_gn")
-    return y, ws, int(nslot.value)
-
-
 def conv2d_cat_wgrad_supported(channels, Cout, H, W, ks, B=1):
     """Will conv2d_backward_weight_cat take sources with these channel counts (list of 2 or 3)?  Pure query."""
     C = list(channels) + [0] * (3 - len(channels))
@@ -330,20 +306,6 @@ def groupnorm_act_forward(x, res, gamma, beta, G, eps, act):
     rc = _lib.get().pnsfm_groupnorm_act_forward(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
                                                 None, B, C, HW, G, float(eps), act, _stream(x))
     _lib.check(rc, "groupnorm_act_forward")
-    return y, mean, rstd
-
-
-def groupnorm_act_apply(x, gamma, beta, stats, nslot, G, eps, act):
-    """act(GroupNorm_G(x)) from statistics a convolution left behind (conv2d_forward_gn): one launch, x read once."""
-    _chk(x, gamma, beta, stats); _f32(x, gamma, beta)
-    B, C = x.shape[0], x.shape[1]
-    HW = x.numel() // (B * C)
-    y = torch.empty_like(x)
-    ms = torch.empty((2, B * G), dtype=torch.float32, device=x.device)
-    mean, rstd = ms[0], ms[1]
-    rc = _lib.get().pnsfm_groupnorm_act_apply(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(stats), nslot,
-                                              B, C, HW, G, float(eps), act, _stream(x))
-    _lib.check(rc, "groupnorm_act_apply")
     return y, mean, rstd
 
 
@@ -642,31 +604,6 @@ def photometric_backward_dev(warped, target, argmin, grad_scale, upstream, ssim_
                                                          int(automask), int(reduce_op), int(bool(clip)), _stream(warped)),
                "photometric_backward_dev")
     return d_warped
-
-
-def photometric_warp_forward(inv_depth, ref, target, K, refK, T, ssim_weight, C1, C2, automask, reduce_op, padding_mode=0):
-    """View synthesis fused into the photometric loss -> (loss float32[1], argmin uint8[B,H,W])."""
-    _chk(inv_depth, ref, target, K, refK, T); _f32(inv_depth, ref, target, K, refK, T)
-    J, B, _, H, W = ref.shape
-    loss = torch.empty((1,), dtype=torch.float32, device=ref.device)
-    argmin = torch.empty((B, H, W), dtype=torch.uint8, device=ref.device)
-    _lib.check(_lib.get().pnsfm_photometric_warp_forward(_ptr(inv_depth), _ptr(ref), _ptr(target), _ptr(K), _ptr(refK), _ptr(T), _ptr(loss),
-                                                         _ptr(argmin), J, B, H, W, float(ssim_weight), float(C1), float(C2), int(automask),
-                                                         int(reduce_op), int(padding_mode), _stream(ref)), "photometric_warp_forward")
-    return loss, argmin
-
-
-def photometric_warp_backward(inv_depth, ref, target, K, refK, T, argmin, grad_scale, upstream, ssim_weight, C1, C2, automask, reduce_op,
-                              padding_mode=0):
-    _chk(inv_depth, ref, target, K, refK, T, argmin, upstream); _f32(inv_depth, ref, target, K, refK, T, upstream)
-    J, B, _, H, W = ref.shape
-    d_inv = torch.empty_like(inv_depth)
-    dT = torch.empty_like(T)
-    _lib.check(_lib.get().pnsfm_photometric_warp_backward(_ptr(inv_depth), _ptr(ref), _ptr(target), _ptr(K), _ptr(refK), _ptr(T), _ptr(argmin),
-                                                          _ptr(d_inv), _ptr(dT), float(grad_scale), _ptr(upstream), J, B, H, W,
-                                                          float(ssim_weight), float(C1), float(C2), int(automask), int(reduce_op),
-                                                          int(padding_mode), _stream(ref)), "photometric_warp_backward")
-    return d_inv, dT
 
 
 def photometric_l1_forward(warped, ref, target, automask, reduce_op, clip_loss):

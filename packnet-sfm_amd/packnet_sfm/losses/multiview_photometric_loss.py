@@ -7,8 +7,6 @@ reference collapse into a handful of HIP launches (csrc/loss.hip):
 
     view synthesis   inv2depth -> reconstruct -> rigid transform -> project -> bilinear gather   (all J contexts)
     photometric      SSIM(3x3, reflect) + L1, automask candidates, per-pixel min/mean, pixel mean (one scalar)
-                     (round 5: PNSFM_LOSS_FUSE=1 computes the view synthesis inside these kernels, no `warped` tensor --
-                     measured 0.3 % slower at 192x640, parked)
     smoothness       edge-aware first differences, |.| means
 
 and the backward pass mirrors them (hand-written derivatives, incl. the 12-float pose gradient).

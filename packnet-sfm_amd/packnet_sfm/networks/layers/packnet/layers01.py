@@ -53,7 +53,7 @@ class Conv2D(nn.Module):
 
     def forward(self, x):
         base, norm = self.conv_base, self.normalize
-        # one autograd node and two launches: the conv kernel's epilogue leaves the GroupNorm statistics behind (HF.ConvGnActFn)
+        # one autograd node whose forward and backward bodies are single calls into the block sequencer (HF.ConvGnActFn)
         return HF.conv2d_gn_act(x, base.weight, base.bias, norm.weight, norm.bias, base._packed, 16, norm.eps, _ops.ACT_ELU)
 
     def forward_tap(self, x):
@@ -90,31 +90,16 @@ class ResidualConv(nn.Module):
 
     def forward(self, x, tap=False):
         """tap=True: (out, x_tap) -- x_tap is what a further consumer of x (a decoder skip) reads, see _HipConv2d.forward_tap."""
-        # The 1x1 shortcut depends on the block input only and is launch-latency-sized (240-512 workgroups of a few microseconds:
-        # tools/bx3_ablate.py puts its floor at 9-14 us whatever it computes), so it goes to the second compute stream
-        # (hip/functional.py: shortcut_stream) underneath conv1 -> GroupNorm -> conv2; autograd replays its backward-data and
-        # weight-gradient kernels on the same stream, underneath the main path's.  Same kernels and the same order of operations
-        # within each result: bit-identical to the single-stream form (PNSFM_SHORTCUT_STREAM=0).
-        side = HF.shortcut_stream(x)
         x_tap = x
-        if side is None and HF.grad_taps() and isinstance(self.conv3, _HipConv2d):
+        if HF.grad_taps() and isinstance(self.conv3, _HipConv2d):
             # x feeds conv1 and the shortcut (and, through x_tap, maybe a skip connection): chained taps -- conv1's backward-data adds
             # the skip's gradient, the shortcut's backward-data adds conv1's: no elementwise gradient sums (round 5)
             shortcut, xa = self.conv3.forward_tap(x)
             y1, x_tap = self.conv1.forward_tap(xa)
             main = self.conv2(y1)
-        elif side is None:
+        else:
             main = self.conv2(self.conv1(x))
             shortcut = self.conv3(x)
-        else:
-            cur = torch.cuda.current_stream(x.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                shortcut = self.conv3(x)
-            x.record_stream(side)
-            main = self.conv2(self.conv1(x))
-            cur.wait_stream(side)
-            shortcut.record_stream(cur)
         out = HF.groupnorm_act(main, self.normalize.weight, self.normalize.bias, 16, self.normalize.eps, _ops.ACT_ELU,
                                res=shortcut)
         return (out, x_tap) if tap else out

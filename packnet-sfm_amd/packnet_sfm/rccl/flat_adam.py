@@ -16,22 +16,13 @@ compatible (`param_groups[i]['lr']` is read before every step; `default_config.p
 `load_state_dict()` speak torch.optim.Adam's layout ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups'}), which
 is what the reference's checkpoints store (`model.optimizer.state_dict()`), so optimizer state moves between the two.
 
-Round 5 -- (a) the FUSED TAIL (on by default; PNSFM_ADAM_FUSED=0 / FlatAdam(..., fused=False) switch it off): once the conv layers own
+Round 5 -- the FUSED TAIL (on by default; PNSFM_ADAM_FUSED=0 / FlatAdam(..., fused=False) switch it off): once the conv layers own
 packed weight copies, step() is two launches for the whole model -- `adam_pack_table_kernel` (csrc/conv2d_bx3.h) updates every
 split-bf16 conv weight AND writes its forward / backward-data images from the values it holds (40 B per parameter instead of the 28 of
 the flat update + the 20 of the re-pack), `adam_segments_kernel` updates the rest of the arenas; both use the inline update of
 csrc/adam_math.h, like the flat kernel: bit-identical parameters and moments (tests/test_kernels_emulated.py).
-(b) the update UNDERNEATH the backward pass (`overlap`, OFF by default -- measured +0.2 % for +1.5 ms of host work per step;
-PNSFM_ADAM_OVERLAP=1 or FlatAdam(..., overlap=True) switch it on).  The arenas are laid out in the order backward produces gradients, so they are cut into the same
-<= 32 MiB buckets the gradient all-reduce uses, and the moment the last gradient of a bucket has been accumulated (post-accumulate
-hooks) its Adam update AND the re-pack of its conv weights are enqueued on a side HIP stream: 1.3 ms of
-HBM-bound work per step (28 B/parameter + the packer's 21 B) that used to sit exposed between backward and the next forward now runs
-next to the MFMA-bound backward kernels.  Nothing on the compute stream reads a weight after its own gradient exists (its
-backward-data kernel was enqueued by the same autograd node, before the hook), and `step()` joins the side stream, updates whatever
-did not get a gradient-complete bucket, and stamps the packed copies fresh.  The early update presumes the reference's loop --
-`zero_grad(); backward(); step()` (trainers/horovod_trainer.py:85-93): with several backward() calls per step (gradient
-accumulation) construct the optimizer with overlap=False.  Under hvd.DistributedOptimizer the gradients have to be averaged across
-ranks first: the reducer owns the hooks there and the update stays in step().
+(Round 5 also had the update bucket by bucket UNDERNEATH the backward pass -- post-accumulate hooks, an update stream: +0.2 % for 1.5 ms of
+host work per step, profiles/r05_ab_adam_overlap.txt -- removed in round 6.)
 """
 import os
 
@@ -48,8 +39,7 @@ def _round_up(n, a):
 
 
 class FlatAdam:
-    def __init__(self, param_groups, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_slots=True, overlap=None,
-                 bucket_bytes=32 << 20, fused=None):
+    def __init__(self, param_groups, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_slots=True, fused=None):
         if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
             param_groups = [{'params': list(param_groups)}]
         self.param_groups = []
@@ -82,37 +72,6 @@ class FlatAdam:
             self._sync_group(group)
             self.param_groups.append(group)
             slots += [(p, self.grad_view(group, p)) for p in order]
-        # ---- buckets of the overlapped update: per group, in arena order (= the order backward completes them)
-        self._overlap = (os.environ.get('PNSFM_ADAM_OVERLAP', '0') == '1') if overlap is None else bool(overlap)
-        self._armed = False             # zero_grad() arms the hooks for ONE backward pass; step() disarms
-        self._side = {}                 # device -> the update stream
-        self._hooks = []
-        self._stamp = []                # (cache, parameter) pairs re-packed early this step: stamped fresh in step()
-        for gi, g in enumerate(self.param_groups):
-            chunks, cur, start, end = [], [], None, None
-            for p in g['_order']:
-                o = g['_offs'][id(p)]
-                e = o + _round_up(p.numel(), _ALIGN)
-                if cur and (e - start) * 4 > bucket_bytes:
-                    chunks.append({'params': cur, 'start': start, 'end': end})
-                    cur, start = [], None
-                if start is None:
-                    start = o
-                cur.append(p)
-                end = e
-            if cur:
-                chunks.append({'params': cur, 'start': start, 'end': end})
-            for ci, ch in enumerate(chunks):
-                ch.update(pending=len(ch['params']), done=False, ids=frozenset(id(p) for p in ch['params']), slot=('adam', gi, ci))
-            g['_chunks'], g['_next'], g['_ticked'] = chunks, 0, False
-            if self._overlap:
-                for ci, ch in enumerate(chunks):
-                    for p in ch['params']:
-                        self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(gi, ci)))
-        if self._hooks:
-            import weakref as _wr
-            hooks = self._hooks
-            _wr.finalize(self, lambda: [h.remove() for h in hooks])
         # ---- the fused optimizer tail (round 5): conv weights updated AND re-packed by one launch, everything else by a second one
         self._fused = (os.environ.get('PNSFM_ADAM_FUSED', '1') != '0') if fused is None else bool(fused)
         self._plan = None               # [signature, item table, n, blocks, (cache, parameter) pairs it covers, segment table, n, blocks]
@@ -162,72 +121,6 @@ class FlatAdam:
         """Push lr / betas / eps / weight decay / grad_scale to the device if they changed (`step()` does it itself)."""
         for g in self.param_groups:
             self._sync_group(g)
-
-    # ---- the update underneath backward ---------------------------------------------------------------------------------
-    def disable_overlap(self):
-        """The gradient all-reduce owns the post-accumulate hooks (hvd.DistributedOptimizer): the update stays in step()."""
-        self._overlap = False
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
-
-    def _make_hook(self, gi, ci):
-        # (the hook is stored on the parameter's C++ autograd metadata, which the cycle collector cannot traverse: it must not hold
-        # the optimizer -- and through it the parameter -- strongly)
-        import weakref
-        ref = weakref.ref(self)
-
-        def hook(param):
-            opt = ref()
-            if opt is None:
-                return
-            g = opt.param_groups[gi]
-            chunks = g['_chunks']
-            ch = chunks[ci]
-            ch['pending'] -= 1
-            # (any order: the buckets are disjoint slices and whichever goes first advances the step counter -- unlike the gradient
-            # all-reduce, whose collectives must pair up across ranks, nothing here needs the arena order)
-            if opt._armed and opt._overlap and ch['pending'] == 0 and not ch['done']:
-                opt._update_chunk(g, ch, early=True)
-        return hook
-
-    def _update_chunk(self, g, ch, early):
-        """Adam on one bucket of the arenas (+ the re-pack of its conv weights), on the update stream when `early` (called from a
-        hook in the middle of backward), else on the current stream."""
-        dev = g['_flat'].device
-        side = None
-        if early and dev.type == 'cuda':
-            side = self._side.get(dev)
-            if side is None:
-                side = self._side[dev] = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))       # every kernel of the nodes that produced these gradients
-        with (torch.cuda.stream(side) if side is not None else HF._nullctx()):
-            HF.join_wgrad_stream(dev)                              # ... incl. weight gradients / pose-branch kernels still in flight
-            src, dst, missing = [], [], []
-            for p in ch['params']:
-                view = self.grad_view(g, p)
-                if p.grad is None:
-                    view.zero_()
-                    missing.append(p)
-                elif p.grad.data_ptr() != view.data_ptr():
-                    if side is not None:
-                        p.grad.record_stream(side)
-                    src.append(p.grad.detach().reshape(view.shape))
-                    dst.append(view)
-            if src:
-                torch._foreach_copy_(dst, src)
-            self._sync_group(g)
-            keep = None
-            if missing:
-                views = [g[k][g['_offs'][id(p)]:g['_offs'][id(p)] + p.numel()] for p in missing for k in ('_flat', '_m', '_v')]
-                keep = (views, [v.clone() for v in views])
-            a, b = ch['start'], ch['end']
-            ops.adam_flat_update(g['_flat'][a:b], g['_grad'][a:b], g['_m'][a:b], g['_v'][a:b], g['_hp'], tick=not g['_ticked'])
-            g['_ticked'] = True
-            if keep is not None:
-                torch._foreach_copy_(keep[0], keep[1])
-            self._stamp += HF.repack_subset(ch['slot'], ch['ids'])
-        ch['done'] = True
 
     # ---- fused tail: Adam + re-pack of the conv weights in one launch, the rest of the arenas in a second ---------------------------
     def _fused_plan(self):
@@ -282,16 +175,10 @@ class FlatAdam:
     # ---- torch.optim.Optimizer surface --------------------------------------------------------------------------------
     def zero_grad(self, set_to_none=True):
         """Gradients are dropped, not zero-filled: the next backward writes every element of the arena slices it uses (the
-        conv kernels directly, the rest through the gather), and a parameter without a gradient is zeroed in the gather.
-        Arms the overlapped update for the backward pass that follows."""
+        conv kernels directly, the rest through the gather), and a parameter without a gradient is zeroed in the gather."""
         for g in self.param_groups:
             for p in g['params']:
                 p.grad = None
-            for ch in g['_chunks']:
-                ch['pending'], ch['done'] = len(ch['params']), False
-            g['_next'], g['_ticked'] = 0, False
-        self._stamp = []
-        self._armed = True
 
     def _gather_grads(self, g):
         """Make g['_grad'] hold the gradients: no copy for gradients that already live in their arena slice.  Returns the
@@ -329,12 +216,7 @@ class FlatAdam:
         hvd.DistributedOptimizer unused parameters arrive with ZERO gradients (the reducer fills their bucket slice, as
         horovod's synchronize() does for the reference) and are therefore updated, exactly like the reference's DDP path."""
         loss = closure() if closure is not None else None
-        self._armed = False
-        for dev, side in self._side.items():
-            torch.cuda.current_stream(dev).wait_stream(side)       # join the updates enqueued during backward (they ticked the step counters)
-        plan = None
-        if not any(ch['done'] for g in self.param_groups for ch in g['_chunks']):
-            plan = self._fused_plan()
+        plan = self._fused_plan()
         if plan is not None:
             # the two-launch tail: every gradient present (a parameter without one is skipped like torch does: plain path this step)
             missing = [self._gather_grads(g) for g in self.param_groups]
@@ -347,37 +229,20 @@ class FlatAdam:
                 HF.bump_weight_epoch()
                 HF.stamp_packed(plan[4])
                 HF.repack_all(exclude={id(w) for _, w in plan[4]})
-                for g in self.param_groups:
-                    for ch in g['_chunks']:
-                        ch['pending'], ch['done'] = len(ch['params']), False
-                    g['_next'], g['_ticked'] = 0, False
-                self._stamp = []
                 return loss
         for g in self.param_groups:
-            if not any(ch['done'] for ch in g['_chunks']):
-                # nothing of this group was updated underneath backward (overlap off, no zero_grad() since the last step, a reducer
-                # owns the hooks): the whole arena in one launch, as before round 5
-                missing = self._gather_grads(g)
-                self._sync_group(g)
-                keep = None
-                if missing:
-                    views = [g[k][g['_offs'][id(p)]:g['_offs'][id(p)] + p.numel()] for p in missing for k in ('_flat', '_m', '_v')]
-                    keep = (views, [v.clone() for v in views])
-                ops.adam_flat_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['_hp'])
-                if keep is not None:
-                    torch._foreach_copy_(keep[0], keep[1])
-                continue
-            for ch in g['_chunks']:         # buckets whose gradients never all arrived (unused parameters): now, on this stream
-                if not ch['done']:
-                    self._update_chunk(g, ch, early=False)
-        for g in self.param_groups:         # a step() without a zero_grad() in between must not see stale bucket states
-            for ch in g['_chunks']:
-                ch['pending'], ch['done'] = len(ch['params']), False
-            g['_next'], g['_ticked'] = 0, False
+            # the whole arena in one launch (a parameter without a gradient keeps parameter and moments, like torch.optim.Adam)
+            missing = self._gather_grads(g)
+            self._sync_group(g)
+            keep = None
+            if missing:
+                views = [g[k][g['_offs'][id(p)]:g['_offs'][id(p)] + p.numel()] for p in missing for k in ('_flat', '_m', '_v')]
+                keep = (views, [v.clone() for v in views])
+            ops.adam_flat_step(g['_flat'], g['_grad'], g['_m'], g['_v'], g['_hp'])
+            if keep is not None:
+                torch._foreach_copy_(keep[0], keep[1])
         HF.bump_weight_epoch()      # parameters changed through raw pointers: invalidate packed conv weights ...
-        stamp, self._stamp = self._stamp, []
-        HF.stamp_packed(stamp)      # ... except the copies re-packed right behind their bucket's update ...
-        HF.repack_all(exclude={id(w) for _, w in stamp} if stamp else None)   # ... and re-pack the rest in one launch (the lazy path covers what is left)
+        HF.repack_all()             # ... and re-pack them in one launch (the lazy path covers what is left)
         return loss
 
     # ---- checkpoints in torch.optim.Adam's layout ----------------------------------------------------------------------

@@ -75,8 +75,6 @@ class DistributedOptimizer:
         params = [p for g in optimizer.param_groups for p in g['params']]
         # an optimizer that keeps its gradients in a flat arena (rccl/flat_adam.py) lends its buckets: reduce + update in place
         buckets = optimizer.grad_buckets(bucket_bytes) if hasattr(optimizer, 'grad_buckets') else None
-        if hasattr(optimizer, 'disable_overlap'):
-            optimizer.disable_overlap()      # gradients are averaged across ranks first: FlatAdam's update stays in step()
         self._reducer = GradBucketReducer(params, bucket_bytes=bucket_bytes, average=True,
                                           force_collectives=force_collectives, buckets=buckets, overlap=overlap,
                                           chunk_bytes=chunk_bytes)

@@ -177,23 +177,6 @@ def test_collapsed_pack_on_maps_smaller_than_two_strips(hw):
             assert float((g0[n] - g1[n]).abs().max()) <= 5e-4 * max(float(g0[n].abs().max()), 1e-2 * gmax), (k, hw, n)
 
 
-@pytest.mark.parametrize('shape,pad,automask,reduce_op', [((2, 4, 192, 640), 'zeros', True, 0), ((1, 1, 33, 65), 'border', False, 1),
-                                                         ((3, 2, 97, 131), 'reflection', True, 0), ((2, 3, 5, 7), 'zeros', False, 0)])
-def test_warp_photometric_fused(shape, pad, automask, reduce_op):
-    """Round 5: fused view synthesis + photometric kernels vs the two-step path (full bench size and ragged maps)."""
-    P.case_warp_photometric_fused('cuda', shape, pad, automask, reduce_op)
-
-
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_border', 'loss_reflection'])
-def test_loss_goldens_through_the_fused_kernels(name):
-    from packnet_sfm.hip import functional as HF
-    HF.set_loss_fuse(True)
-    try:
-        P.case_loss(name, 'cuda')
-    finally:
-        HF.set_loss_fuse(False)
-
-
 @pytest.mark.parametrize('shape', [(4, 64, 192, 640), (4, 64, 96, 320), (2, 64, 384, 1280), (1, 19, 13, 70)])
 def test_invdepth_conv_strip_kernel_is_bit_identical(monkeypatch, shape):
     """Round 5: strip form of the InvDepth forward kernel (what 192x640 / 96x320 run) vs the 64-pixel kernel: equal bits."""

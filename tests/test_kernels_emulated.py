@@ -734,62 +734,6 @@ def test_flat_adam_fused_tail(emulated_kernels):
     P.case_flat_adam_fused_tail('cpu')
 
 
-def test_flat_adam_update_underneath_backward(emulated_kernels):
-    """Round 5: FlatAdam updates a group bucket by bucket from post-accumulate hooks while backward is still running
-    (rccl/flat_adam.py: _update_chunk) and re-packs the bucket's conv weights right behind it.  Several small buckets, a parameter
-    that gets no gradient on some steps (its bucket is finished by step()), a step() without zero_grad() in front (no early update:
-    the hooks are armed by zero_grad only) -- parameters, moments and the packed weight copies must equal the overlap=False optimizer's
-    bit for bit, and the hooks must have done the work."""
-    from packnet_sfm.hip import functional as HF
-    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D
-    from packnet_sfm.rccl.flat_adam import FlatAdam
-
-    class Net(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.a, self.b, self.c = Conv2D(16, 32, 3, 1), Conv2D(32, 32, 3, 1), Conv2D(32, 16, 3, 1)
-            self.side = torch.nn.Linear(4, 4)          # no gradient on odd steps
-
-        def forward(self, x, use_side):
-            y = self.c(self.b(self.a(x))).pow(2).mean()
-            return y + self.side(x[:, 0, :4, :4]).sum() * 1e-3 if use_side else y
-
-    torch.manual_seed(7)
-    nets = [Net(), Net()]
-    nets[1].load_state_dict(nets[0].state_dict())
-    opts = [FlatAdam([{'params': list(nets[0].parameters()), 'lr': 1e-2}], overlap=False),
-            FlatAdam([{'params': list(nets[1].parameters()), 'lr': 1e-2}], overlap=True, bucket_bytes=8 << 10)]
-    assert len(opts[1].param_groups[0]['_chunks']) >= 3
-    x = torch.randn(2, 16, 6, 32)
-    early_total = 0
-    for step in range(5):
-        for net, opt in zip(nets, opts):
-            if step != 3:
-                opt.zero_grad()
-            else:                                       # step 3: gradients dropped by hand -> the hooks stay disarmed
-                for p in net.parameters():
-                    p.grad = None
-            net(x, step % 2 == 0).backward()
-            if opt is opts[1]:
-                done = sum(ch['done'] for ch in opt.param_groups[0]['_chunks'])
-                assert (done > 0) == (step != 3), (step, done)
-                early_total += done
-            opt.step()
-        for (n, pa), pb in zip(nets[0].named_parameters(), nets[1].parameters()):
-            assert torch.equal(pa.detach(), pb.detach()), 'step %d: %s differs between the overlapped and the plain update' % (step, n)
-    for k in ('_m', '_v', '_hp'):
-        assert torch.equal(opts[0].param_groups[0][k], opts[1].param_groups[0][k]), k
-    assert early_total >= 8
-    # the packed copies were refreshed by the early re-pack and stamped in step(): the next forward packs nothing and sees the new weights
-    for net in nets:
-        net.eval()
-    with torch.no_grad():
-        ya, yb = nets[0](x, False), nets[1](x, False)
-    assert torch.equal(ya, yb)
-    for opt in opts:
-        opt._slots.remove()
-
-
 def test_flat_adam_gradient_slots(emulated_kernels):
     """The conv weight-gradient kernel writes straight into FlatAdam's gradient arena (hip.functional.register_grad_slots):
     after backward the parameter's .grad IS the arena view (no gather copy), a parameter used twice falls back to the normal
@@ -1097,23 +1041,6 @@ def test_conv2d_cat_multi_source(emulated_kernels, case):
     if case[1] in ((64, 1), (32, 33)):
         from packnet_sfm.hip import ops
         assert ops.conv2d_cat_wgrad_supported(list(case[1]), case[2], case[3], case[4], case[5], B=case[0])
-
-
-@pytest.mark.parametrize('shape,pad,automask,reduce_op', [((2, 2, 21, 37), 'zeros', True, 0), ((1, 1, 16, 16), 'border', False, 1),
-                                                         ((3, 1, 19, 50), 'reflection', True, 0), ((2, 3, 5, 7), 'zeros', False, 0)])
-def test_warp_photometric_fused(emulated_kernels, shape, pad, automask, reduce_op):
-    P.case_warp_photometric_fused('cpu', shape, pad, automask, reduce_op)
-
-
-@pytest.mark.parametrize('name', ['loss_default', 'loss_multires_mean', 'loss_border', 'loss_reflection'])
-def test_loss_goldens_through_the_fused_kernels(emulated_kernels, name):
-    """The reference's loss goldens with view synthesis fused into the photometric kernels (PNSFM_LOSS_FUSE=1)."""
-    from packnet_sfm.hip import functional as HF
-    HF.set_loss_fuse(True)
-    try:
-        P.case_loss(name, 'cpu')
-    finally:
-        HF.set_loss_fuse(False)
 
 
 @pytest.mark.parametrize('shape,cfg', [((2, 48, 64, 9, 32, 3), c) for c in [(2, 3, 0, 1), (1, 4, 1, 3), (2, 7, 0, 1), (1, 7, 1, 2), (2, 6, 0, 1)]] +

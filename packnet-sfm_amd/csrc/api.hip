@@ -129,7 +129,7 @@ int ensure_lds_limit(const void* kernel, unsigned long long* mask, int bytes, co
 // stream the kernel is launched on.  When enabled, each profiled launch records a (start, stop)
 // event pair; collect() synchronises on them and adds up hipEventElapsedTime.
 #ifndef PNSFM_EMU
-struct ProfRec { hipEvent_t a, b; double flops; int meta[8]; };
+struct ProfRec { hipEvent_t a, b; double flops; int meta[9]; };      // meta[8]: which kernel ran (prof_dump's `kernel` column)
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs[2];
 static std::vector<hipEvent_t> g_pool;
@@ -157,7 +157,7 @@ void prof_begin(int kind, double flops, hipStream_t stream, const int* meta) {
   r.a = get_event();
   r.b = get_event();
   r.flops = flops;
-  for (int i = 0; i < 8; ++i) r.meta[i] = meta ? meta[i] : 0;
+  for (int i = 0; i < 9; ++i) r.meta[i] = meta ? meta[i] : 0;
   hipEventRecord(r.a, stream);
   g_recs[kind].push_back(r);
 }
@@ -293,14 +293,16 @@ int pnsfm_prof_dump(const char* path) {
   std::lock_guard<std::mutex> lk(pnsfm::g_prof_mu);
   FILE* f = fopen(path, "w");
   if (!f) { pnsfm::set_error("prof_dump: cannot open %s", path); return -1; }
-  fprintf(f, "kind,B,Cin,Cout,H,W,ks,split,blocks,ms,gflop,tflops\n");
+  // kernel: forward / backward-data (kind 0) = the variant of pnsfm_conv2d_last_config (0-2 f32 stagings, 3-6 split-bf16 plans, 7 ping-pong);
+  // weight gradient (kind 1) = 0 generic f32, 2 tap-major f32, 3 split-bf16 one kernel row per workgroup, 4 split-bf16 nine taps
+  fprintf(f, "kind,B,Cin,Cout,H,W,ks,split,blocks,ms,gflop,tflops,kernel\n");
   for (int k = 0; k < 2; ++k)
     for (auto& r : pnsfm::g_recs[k]) {
       hipEventSynchronize(r.b);
       float t = 0.f;
       if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-      fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.2f\n", k, r.meta[0], r.meta[1], r.meta[2], r.meta[3], r.meta[4],
-              r.meta[5], r.meta[6], r.meta[7], t, r.flops * 1e-9, t > 0 ? r.flops / (t * 1e-3) * 1e-12 : 0.0);
+      fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.3f,%.2f,%d\n", k, r.meta[0], r.meta[1], r.meta[2], r.meta[3], r.meta[4],
+              r.meta[5], r.meta[6], r.meta[7], t, r.flops * 1e-9, t > 0 ? r.flops / (t * 1e-3) * 1e-12 : 0.0, r.meta[8]);
     }
   fclose(f);
 #else

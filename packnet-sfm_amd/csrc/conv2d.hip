@@ -1168,7 +1168,7 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
   if (g.DMA >= 3 && g.smem_bytes + (size_t)g_smem_pad <= kMaxSmemPipe) g.smem_bytes += (size_t)g_smem_pad;
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
-  const int meta[8] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK)};
+  const int meta[9] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK), g.DMA};
   g_last_conv = {g.DMA, g.NT, g.MT, g.G, g.splitK, g.mode == 2 ? (g.TW == 16 ? 1 : 2) : 0, meta[7], (int)g.smem_bytes};
   prof_begin(0, flops, stream, meta);
   const int rc = enqueue_conv(g, x, wp, bias, y, B, Cin, Cout, H, W, ks, stream, what, S, Hi, Wi, ms, gn);
@@ -1888,27 +1888,27 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   }
   const double flops = 2.0 * Cout * (double)Cin * KK * (double)B * HW;
   if (variant == 3) {
-    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split4, wgrad4_base_blocks(Cin, Cout, (cfg4 & 15) == 1 ? 1 : 2) * split4};
+    const int meta[9] = {B, Cin, Cout, a.cstride, W0, ks, split4, wgrad4_base_blocks(Cin, Cout, (cfg4 & 15) == 1 ? 1 : 2) * split4, 4};
     prof_begin(1, flops, s, meta);
     const int rc = enqueue_wgrad4(x, dy, dw, dbias, B, Cin, Cout, H0, W0, split4, cfg4, s, ms);
     prof_end(1, s);
     return rc;
   }
   if (variant == 2) {
-    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3};
+    const int meta[9] = {B, Cin, Cout, a.cstride, W0, ks, split3, wgrad3_base_blocks(Cin, Cout, ks, nt3, wm3) * split3, 3};
     prof_begin(1, flops, s, meta);
     const int rc = enqueue_wgrad3(x, dy, dw, dbias, B, Cin, Cout, H3, W3, ks, split3, nt3, wm3, s, ms);
     prof_end(1, s);
     return rc;
   }
   if (variant == 1) {
-    const int meta[8] = {B, Cin, Cout, a.cstride, W0, ks, split2, wgrad2_base_blocks(Cin, Cout, ks) * split2};
+    const int meta[9] = {B, Cin, Cout, a.cstride, W0, ks, split2, wgrad2_base_blocks(Cin, Cout, ks) * split2, 2};
     prof_begin(1, flops, s, meta);
     const int rc = enqueue_wgrad2(x, dy, dw, dbias, B, Cin, Cout, H0, W0, ks, split2, s);
     prof_end(1, s);
     return rc;
   }
-  const int meta[8] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(n_tiles * m_tiles * a.splitP)};
+  const int meta[9] = {B, Cin, Cout, a.cstride, W, ks, a.splitP, (int)(n_tiles * m_tiles * a.splitP), 0};
   prof_begin(1, flops, s, meta);
   const int rc = enqueue(a.splitP);
   prof_end(1, s);

@@ -67,11 +67,11 @@ prof)
   timeout 600 python bench.py --height 384 --width 1280 --batch 2 --steps 8 --warmup 2 $BARGS --layer-table $O/r06_conv_layer_table_384x1280.csv > $O/r06_bench_384.log 2>&1
   tail -1 $O/r06_bench_384.log > $O/r06_bench_384x1280.json; cut -c1-200 $O/r06_bench_384x1280.json
   # (side streams OFF under the profiler: per-kernel durations of kernels that run alone, like the PMC passes)
-  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r06 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS > $O/r06_rocprof.log 2>&1)
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r06 -o bench -- python $R/bench.py --steps 6 --warmup 2 $BARGS --no-calibration > $O/r06_rocprof.log 2>&1)
   f=$(find $O/prof_r06 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r06_bench_kernel_stats.csv && head -12 $f | cut -c1-140
   t=$(find $O/prof_r06 -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r06_step_breakdown.txt 2>&1 && head -8 $O/r06_step_breakdown.txt
   rm -rf $O/prof_r06
-  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r06b -o bench -- python $R/bench.py --height 384 --width 1280 --batch 2 --steps 6 --warmup 2 $BARGS > $O/r06_rocprof_384.log 2>&1)
+  (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r06b -o bench -- python $R/bench.py --height 384 --width 1280 --batch 2 --steps 6 --warmup 2 $BARGS --no-calibration > $O/r06_rocprof_384.log 2>&1)
   f=$(find $O/prof_r06b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r06_bench_kernel_stats_384x1280.csv
   t=$(find $O/prof_r06b -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/step_breakdown.py $t 90 > $O/r06_step_breakdown_384x1280.txt 2>&1 && head -4 $O/r06_step_breakdown_384x1280.txt
   rm -rf $O/prof_r06b ;;
@@ -83,7 +83,7 @@ proflite)
 pmc)
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-24)
-    (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r06_$n -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-prof $BARGS > $O/r06_pmc_$n.log 2>&1)
+    (cd /tmp && PNSFM_WGRAD_STREAM=0 PNSFM_BRANCH_STREAM=0 PNSFM_SHORTCUT_STREAM=0 PNSFM_TUNE_DB=$DB timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r06_$n -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-prof --no-calibration $BARGS > $O/r06_pmc_$n.log 2>&1)
     echo "pass $n: $(tail -1 $O/r06_pmc_$n.log | cut -c1-100)"
   done
   python tools/pmc_traffic.py $(find $O/pmc_r06_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $O/pmc_r06_WRITE_SIZE -name "*counter_collection.csv" | head -1) $O/r06_traffic.json $O/r06_conv_layer_table.csv 192,640,4 | head -8

@@ -62,8 +62,23 @@ if layer_csv:
         a = acc.setdefault(name, [0.0, 0])
         a[0] += by
         a[1] += 1
+        # round 6: the table says which kernel ran the launch (`kernel` column) -- the algorithmic bytes of the ping-pong kernel and of the
+        # nine-taps weight gradient are recorded under their own names as well (the family averages above stay for bench.py)
+        own = {('0', '7'): 'pnsfm::conv2d_bx3pp_kernel', ('1', '4'): 'pnsfm::conv2d_wgrad4_kernel', ('1', '2'): 'pnsfm::conv2d_wgrad2_kernel'}.get((r['kind'], r.get('kernel', '')))
+        if own is not None:
+            a = acc.setdefault(own, [0.0, 0])
+            a[0] += by
+            a[1] += 1
+        elif r.get('kernel') is not None and (r['kind'], split) in (('0', True), ('1', True)):
+            a = acc.setdefault(name + ' (own launches)', [0.0, 0])
+            a[0] += by
+            a[1] += 1
     for name, a in acc.items():
-        if name in res and a[1]:
+        if name.endswith(' (own launches)'):
+            base = name[:-len(' (own launches)')]
+            if base in res and a[1]:
+                res[base]['algorithmic_bytes_per_own_launch'] = a[0] / a[1]
+        elif name in res and a[1]:
             res[name]['algorithmic_bytes_per_launch'] = a[0] / a[1]
 res['workload_shape'] = [int(v) for v in sys.argv[5].split(',')] if len(sys.argv) > 5 else [192, 640, 4]      # H, W, batch of the bench.py run the passes were collected on (bench.py only quotes
                                            # these numbers for that workload)

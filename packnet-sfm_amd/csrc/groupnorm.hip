@@ -602,11 +602,9 @@ static bool gn_fused_ok(int C, int HW, int G) {
 }
 static int gn_fused_threads(long n4) { return n4 > 2048 ? 1024 : 256; }
 // workgroups per slab: the normalisation (exponentials) is most of a slab's arithmetic; 4 on the slabs of >= 4 float4 per thread of a
-// 1024-thread workgroup (env PNSFM_GN_FUSED_S overrides: lab)
+// 1024-thread workgroup
 static int gn_fused_parts(long n4, int T) {
-  static const int forced = [] { const char* e = getenv("PNSFM_GN_FUSED_S"); return e && e[0] ? atoi(e) : 0; }();
   const long nv = (n4 + T - 1) / T;
-  if (forced == 1 || forced == 2 || forced == 4) return nv >= forced && T == 1024 ? forced : 1;
   return (T == 1024 && nv >= 4) ? 4 : 1;
 }
 

@@ -272,3 +272,30 @@ def test_groupnorm_one_launch_form_is_deterministic_and_close_to_the_two_launch_
         assert torch.equal(a, b)
     for a, b, name in zip(out[1][0], out[0][0], ('y', 'mean', 'rstd', 'dx', 'dgamma', 'dbeta')):
         P.check(a, b, 2e-6, 'one-launch vs two-launch ' + name)
+
+
+# ------------------------------------------------------------------------------------------------ block sequencer
+def test_block_sequencer_is_bit_identical_to_the_python_bodies():
+    """csrc/seq/pnsfm_seq.cpp holds the bodies of the hot autograd nodes (Conv2D block, plain / multi-source convolution, GroupNorm with
+    residual, region_ops) as single C++ calls over the C ABI; hip/functional.py keeps a pure-Python body for each (PNSFM_SEQ=0).  Same
+    launches in the same per-stream order: loss and every gradient of the golden training step agree BIT FOR BIT between the two."""
+    from packnet_sfm.hip import _seq
+    from test_gpu_parity import _selfsup, _step_batch
+    from test_gpu_round4 import _grads_of_one_step
+    fx = dict(P.golden('step')['step_flip0'])
+    model, dn, pn = _selfsup(DEV, fx)
+    batch = _step_batch(fx)
+    assert _seq.get() is not None, 'the sequencer extension must be loaded on the GPU box'
+    _grads_of_one_step(model, batch, False)             # autotuning
+    try:
+        _seq.set_enabled(False)
+        assert _seq.get() is None
+        l0, g0 = _grads_of_one_step(model, batch, False)
+        _seq.set_enabled(True)
+        for rep in range(2):
+            l1, g1 = _grads_of_one_step(model, batch, False)
+            assert torch.equal(l0, l1), (l0.item(), l1.item())
+            bad = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+            assert not bad and g0.keys() == g1.keys(), bad[:3]
+    finally:
+        _seq.set_enabled(True)

@@ -1106,3 +1106,34 @@ def test_gradient_taps_match_the_plain_graph(emulated_kernels):
     y, _ = blk.forward_tap(x * 1.0)
     y.sum().backward()
     assert x.grad is not None
+
+
+def test_block_sequencer_equals_python_bodies(emulated_kernels):
+    """The block sequencer (csrc/seq/pnsfm_seq.cpp) bound to the EMULATED kernels against the pure-Python bodies of hip/functional.py on a
+    stack of real blocks (Conv2D with a multi-source input, ResidualConv with taps, collapsed PackLayerConv3d, UnpackLayerConv3d): the
+    same launches, so outputs and every gradient agree bit for bit."""
+    from packnet_sfm.hip import _seq
+    from packnet_sfm.networks.layers.packnet.layers01 import Conv2D, ResidualConv, PackLayerConv3d, UnpackLayerConv3d
+    torch.manual_seed(7)
+    blocks = [Conv2D(32, 32, 3, 1), ResidualConv(32, 32, 1), PackLayerConv3d(32, 3), UnpackLayerConv3d(32, 32, 3)]
+    x0 = torch.randn(1, 16, 12, 32)
+    x1 = torch.randn(1, 16, 12, 32)
+    assert _seq.get() is not None
+    res = {}
+    try:
+        for on in (False, True):
+            _seq.set_enabled(on)
+            for m in blocks:
+                for p in m.parameters():
+                    p.grad = None
+            a, b = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+            y = blocks[0]((a, b))
+            y = blocks[1](y)
+            y = blocks[3](blocks[2](y))
+            (y * torch.linspace(0.5, 1.5, y.numel()).view_as(y)).sum().backward()
+            res[on] = [y.detach().clone(), a.grad.clone(), b.grad.clone()] + [p.grad.clone() for m in blocks for p in m.parameters()]
+    finally:
+        _seq.set_enabled(True)
+    assert len(res[False]) == len(res[True])
+    for i, (u, v) in enumerate(zip(res[False], res[True])):
+        assert torch.equal(u, v), 'tensor %d differs between the Python bodies and the sequencer (max |d| %.3e)' % (i, float((u - v).abs().max()))

@@ -87,7 +87,7 @@ def resize_frames(frames, shape):
 
 def draw_jitter(parameters, prob=1.0):
     """One sample's colour-jitter decision, consuming Python's RNG exactly like colorjitter_sample +
-    random_color_jitter_transform (augmentations.py:254-337) -> packed 40-byte record for the kernel."""
+    random_color_jitter_transform (augmentations.py:254-337) -> packed 56-byte record for the kernel (order, four factors, hue, enable flag, 3-entry colour scale: include/pnsfm.h)."""
     if not (random.random() < prob):
         return ops.jitter_record()
     brightness, contrast, saturation, hue = parameters[:4]

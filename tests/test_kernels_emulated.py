@@ -1108,6 +1108,15 @@ def test_gradient_taps_match_the_plain_graph(emulated_kernels):
     assert x.grad is not None
 
 
+def test_groupnorm_one_launch_form_other_group_counts(emulated_kernels):
+    """Four workgroups per slab with a slab count that is NOT a multiple of 8 (3 samples x 4 groups: the parts of a slab fall back to
+    consecutive blocks), and one channel per group."""
+    from packnet_sfm.hip import _lib
+    _lib.get().pnsfm_set_gn_fused(1)
+    P.case_groupnorm('cpu', (3, 16, 64, 64), 1, True, G=4)
+    P.case_groupnorm('cpu', (2, 8, 8, 16), 2, False, G=8)
+
+
 def test_block_sequencer_equals_python_bodies(emulated_kernels):
     """The block sequencer (csrc/seq/pnsfm_seq.cpp) bound to the EMULATED kernels against the pure-Python bodies of hip/functional.py on a
     stack of real blocks (Conv2D with a multi-source input, ResidualConv with taps, collapsed PackLayerConv3d, UnpackLayerConv3d): the

@@ -74,7 +74,8 @@ class PackedConvWeight:
             self._serial += 1
             key = ('volatile', self._serial)
         else:
-            key = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
+            # (torch.Size and torch.device compare and hash natively: no tuple() / str() per call -- ~300 calls per step)
+            key = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], weight.shape, weight.device)
         do_f = self.key_fwd != key
         do_b = need_bwd and self.key_bwd != key
         if do_f or do_b:
@@ -95,7 +96,7 @@ class PackedConvWeight:
 
     @staticmethod
     def key_of(weight):
-        return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], tuple(weight.shape), str(weight.device))
+        return (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0], weight.shape, weight.device)
 
 
 # ---- batched re-pack: every conv weight of the model in ONE launch, right after the optimizer step ----------------------------

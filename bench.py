@@ -374,6 +374,36 @@ def _gpu_sysfs_dir(device):
         return None
 
 
+def pin_to_gpu_numa(device):
+    """Keep this process (and the autograd threads it creates later) on the host cores next to `device` (sysfs local_cpulist of the
+    GPU's PCI function): the host enqueue time of one step scattered 9-18 ms from process to process on one box depending on where the
+    scheduler had put the process.  Returns (cpus pinned to | None, all cpus before)."""
+    try:
+        before = os.sched_getaffinity(0)
+        pr = torch.cuda.get_device_properties(device)
+        addr = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        txt = open('/sys/bus/pci/devices/%s/local_cpulist' % addr).read().strip()
+        cpus = set()
+        for part in txt.split(','):
+            if '-' in part:
+                a, b = part.split('-')
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        cpus &= before
+        # (one hardware thread per core: on these hosts the second half of the CPU numbers are the SMT siblings of the first half)
+        half = (os.cpu_count() or 0) // 2
+        phys = {c for c in cpus if c < half}
+        if len(phys) >= 4 and os.environ.get('PNSFM_PIN_SMT', '0') != '1':
+            cpus = phys
+        if len(cpus) >= 4:
+            os.sched_setaffinity(0, cpus)
+            return sorted(cpus), before
+        return None, before
+    except Exception:
+        return None, None
+
+
 class ClockSampler:
     """Shader clock and socket power of the GPU, read from sysfs by a background thread every 20 ms while a region runs (one pread
     of two tiny files per sample: ~30 us of host time, 0.15 % of a core)."""
@@ -604,13 +634,14 @@ def run_workload(model, optimizer, H, W, B, steps, warmup, ctx, want_prof=True, 
     # step synchronises, and one step's ~800 launches never fill the queue, so the GPU cannot push back).  If this approaches
     # ms_per_step the step is host-bound; the GPU-side figure to compare with is ms_per_step itself.
     issue = []
-    for _ in range(3):
+    for _ in range(7):          # (median of 7: single steps scatter by +-20 % -- allocator state, the autograd thread's wake-up)
         fence()
         ti = time.perf_counter()
         step()
         issue.append(time.perf_counter() - ti)
     fence()
-    res['host_issue_ms'] = 1e3 * sorted(issue)[1]
+    res['host_issue_ms'] = 1e3 * sorted(issue)[3]
+    res['host_issue_ms_min'] = 1e3 * min(issue)
 
     # ---- roofline of the dominant kernel: per-launch hipEvent timing inside the library (pnsfm_prof_*), on the stream
     # each kernel is launched on, over a few extra steps right after the timed region: (a) as trained and (b), when weight
@@ -694,6 +725,7 @@ def main():
     torch.cuda.set_device(device)
 
     H, W, B = args.height, args.width, args.batch
+    pinned, all_cpus = pin_to_gpu_numa(device) if os.environ.get('PNSFM_PIN_NUMA', '1') != '0' else (None, None)
     model = build_model(device, args.depth_net)
     force_ddp = os.environ.get('PNSFM_FORCE_DDP') == '1'   # single-GPU rehearsal of the N>1 path (1-rank RCCL group)
     ddp = world > 1 or force_ddp
@@ -737,6 +769,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             # host time to ENQUEUE one step (empty queue in front of it, clock stopped before any fence) and its share of the step
             'host_issue_ms_per_step': round(m['host_issue_ms'], 3), 'host_issue_frac': round(m['host_issue_ms'] / ms_step, 3),
+            'host_issue_ms_min': round(m['host_issue_ms_min'], 3),
             'config': {'workload': args.depth_net + '(1A)+PoseNet self-supervised train step (fwd+photometric loss+bwd+allreduce+Adam), '
                                    'KITTI-shaped %dx%d triplets, batch %d/GPU (%s)' % (H, W, B, shape_tag),
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': round(m['loss'], 6),
@@ -751,6 +784,8 @@ def main():
                                  ('shipped database (%d decisions) + autotune for unlisted shapes' % ops.tune_shipped_entries()
                                   if ops.tune_shipped_entries() else 'autotune during warm-up'),
                        'step_launch': 'eager',
+                       # host cores this process was kept on (the GPU's local NUMA node, sysfs local_cpulist); null: not pinned
+                       'host_cpus_pinned': ('%d cpus: %d-%d' % (len(pinned), pinned[0], pinned[-1])) if pinned else None,
                        'collective_backend': backend, 'devices_visible': ndev,
                        # ranks of the RCCL communicator the gradient all-reduce ran on (null: single process, no collective)
                        'rccl_ranks': dist.get_world_size() if (dist.is_initialized() and backend == 'nccl') else None},
@@ -799,6 +834,8 @@ def main():
             torch.cuda.empty_cache()
             child = gpu_eager_baseline_start(H, W, B)
         if world == 1 and not args.no_cpu_baseline:
+            if pinned is not None and all_cpus:
+                os.sched_setaffinity(0, all_cpus)          # the CPU leg sweeps thread counts over the whole box
             result['cpu_baseline'] = cpu_baseline(H, W)
         if child is not None:
             result['gpu_eager_baseline'] = gpu_eager_baseline_finish(child, H, W, B, value, None if args.gpu_baseline == 'on' else 420.0)

@@ -1037,13 +1037,16 @@ class PackBorderSplitFn(Function):
     Round 4: the four strip gathers are ONE launch (ops.region_ops), and so are the four gradient accumulations."""
 
     @staticmethod
-    def forward(ctx, P, S):
+    def forward(ctx, P, S, lr_t=False):
         B, C, h, w = P.shape
-        ctx.S = S
+        ctx.S, ctx.lr_t = S, lr_t
         tb = P.new_empty((2 * B, C, S, w))
-        lr = P.new_empty((2 * B, C, h, S))
+        # lr_t (round 6): the column strips are stored TRANSPOSED, [2B, C, S, h] -- rows of h pixels instead of rows of S = 3 / 5 --
+        # so that every kernel behind them (Conv3d stencil, convolution, weight gradient) sees a map as wide as the row strips'
+        lr = P.new_empty((2 * B, C, S, h)) if lr_t else P.new_empty((2 * B, C, h, S))
+        lrv = lr.transpose(2, 3) if lr_t else lr
         ops.region_ops([_R(ops.REGION_COPY, tb[:B], P[:, :, :S]), _R(ops.REGION_COPY, tb[B:], P[:, :, h - S:]),
-                        _R(ops.REGION_COPY, lr[:B], P[:, :, :, :S]), _R(ops.REGION_COPY, lr[B:], P[:, :, :, w - S:])])
+                        _R(ops.REGION_COPY, lrv[:B], P[:, :, :, :S]), _R(ops.REGION_COPY, lrv[B:], P[:, :, :, w - S:])])
         return P.view_as(P), tb, lr
 
     @staticmethod
@@ -1068,12 +1071,14 @@ class PackBorderSplitFn(Function):
             add_pair(_R(ops.REGION_ADD, dP[:, :, :S], d_tb[:B]), _R(ops.REGION_ADD, dP[:, :, h - S:], d_tb[B:]), h < 2 * S)
         if d_lr is not None:
             d_lr = d_lr.contiguous()
+            if ctx.lr_t:
+                d_lr = d_lr.transpose(2, 3)
             add_pair(_R(ops.REGION_ADD, dP[:, :, :, :S], d_lr[:B]), _R(ops.REGION_ADD, dP[:, :, :, w - S:], d_lr[B:]), w < 2 * S)
-        return dP, None
+        return dP, None, None
 
 
-def pack_border_split(P, S):
-    return PackBorderSplitFn.apply(P, S)
+def pack_border_split(P, S, lr_t=False):
+    return PackBorderSplitFn.apply(P, S, lr_t)
 
 
 class StripSelectFn(Function):
@@ -1120,16 +1125,19 @@ class PackBorderPasteFn(Function):
     backward (every element of d_tb, d_lr and dy has exactly one writer)."""
 
     @staticmethod
-    def forward(ctx, y, o_tb, o_lr, r):
+    def forward(ctx, y, o_tb, o_lr, r, lr_t=False):
         B, h, w = y.shape[0], y.shape[2], y.shape[3]
-        ctx.r = r
+        ctx.r, ctx.lr_t = r, lr_t
         o_tb, o_lr = o_tb.contiguous(), o_lr.contiguous()
+        s_lr = tuple(o_lr.shape)
+        if lr_t:                     # [2B, C, 2r, h] holds the column strips transposed
+            o_lr = o_lr.transpose(2, 3)
         ops.region_ops([_R(ops.REGION_COPY, y[:, :, r:h - r, :r], o_lr[:B, :, r:h - r, :r]),
                         _R(ops.REGION_COPY, y[:, :, r:h - r, w - r:], o_lr[B:, :, r:h - r, r:]),
                         _R(ops.REGION_COPY, y[:, :, :r], o_tb[:B, :, :r]),
                         _R(ops.REGION_COPY, y[:, :, h - r:], o_tb[B:, :, r:])])
         ctx.mark_dirty(y)
-        ctx.shapes = (tuple(o_tb.shape), tuple(o_lr.shape))
+        ctx.shapes = (tuple(o_tb.shape), s_lr)
         return y
 
     @staticmethod
@@ -1139,7 +1147,8 @@ class PackBorderPasteFn(Function):
         g = g.contiguous()
         B, h, w = g.shape[0], g.shape[2], g.shape[3]
         s_tb, s_lr = ctx.shapes
-        d_tb, d_lr, dy = g.new_empty(s_tb), g.new_empty(s_lr), torch.empty_like(g)
+        d_tb, d_lr_st, dy = g.new_empty(s_tb), g.new_empty(s_lr), torch.empty_like(g)
+        d_lr = d_lr_st.transpose(2, 3) if ctx.lr_t else d_lr_st
         ops.region_ops([
             # d_tb [2B,C,2r,w]: leading half rows 0..r-1 <- top frame, rows r.. zero; trailing half rows r.. <- bottom frame, rows ..r-1 zero
             _R(ops.REGION_COPY, d_tb[:B, :, :r], g[:, :, :r]), _R(ops.REGION_ZERO, d_tb[:B, :, r:]),
@@ -1153,11 +1162,11 @@ class PackBorderPasteFn(Function):
             _R(ops.REGION_COPY, d_lr[:B, :, r:h - r, :r], g[:, :, r:h - r, :r]), _R(ops.REGION_ZERO, d_lr[:B, :, r:h - r, r:]),
             _R(ops.REGION_COPY, d_lr[B:, :, r:h - r, r:], g[:, :, r:h - r, w - r:]), _R(ops.REGION_ZERO, d_lr[B:, :, r:h - r, :r]),
             _R(ops.REGION_ZERO, d_lr[:, :, :r]), _R(ops.REGION_ZERO, d_lr[:, :, h - r:])])
-        return dy, d_tb, d_lr, None
+        return dy, d_tb, d_lr_st, None, None
 
 
-def pack_border_paste(y, o_tb, o_lr, r):
-    return PackBorderPasteFn.apply(y, o_tb, o_lr, r)
+def pack_border_paste(y, o_tb, o_lr, r, lr_t=False):
+    return PackBorderPasteFn.apply(y, o_tb, o_lr, r, lr_t)
 
 
 class InvDepthActFn(Function):

@@ -184,6 +184,11 @@ class PackLayerConv3d(nn.Module):
     """
 
     collapse = 'auto'
+    # round 6: the column strips of the collapsed form live TRANSPOSED ([2B, C, S, h]: rows of h pixels), with the (y, x) taps of both
+    # kernels swapped -- conv(x^T, w^T) = conv(x, w)^T -- so that their convolutions and weight gradients run on a map as wide as the
+    # row strips' instead of on rows of 2 - 5 pixels (the weight gradient of those fell back to the generic f32 kernel: 28 - 83 TFLOP/s)
+    # (+0.5 % images/s, weight-gradient frac 0.366 -> 0.380 same-box: profiles/r06_ab_transposed_column_strips.txt; False = the old form)
+    lr_transposed = True
 
     def __init__(self, in_channels, kernel_size, r=2, d=8):
         super().__init__()
@@ -193,6 +198,7 @@ class PackLayerConv3d(nn.Module):
         self.conv = Conv2D(in_channels * (r ** 2) * d, in_channels, kernel_size, 1)
         self.conv3d = nn.Conv3d(1, d, kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=(1, 1, 1))
         self._eff_packed = HF.PackedConvWeight(volatile=True)
+        self._lr_packed = HF.PackedConvWeight()        # packed copies of the (y, x)-transposed Conv2d weight (column strips)
 
     def _use_collapsed(self, h, w):
         k = self.conv.kernel_size
@@ -221,11 +227,18 @@ class PackLayerConv3d(nn.Module):
         # border frame (r pixels): original formula on strips of 2r+1 packed rows / columns (top+bottom and left+right
         # are batched together); only rows/cols whose Conv3d neighbourhood lies inside the strip are kept.  The three
         # helper Functions do the strip gather / select / paste without full-size zero-fills and adds in backward.
-        P_main, tb, lr = HF.pack_border_split(P, S)
+        lr_t = bool(self.lr_transposed)
+        P_main, tb, lr = HF.pack_border_split(P, S, lr_t)
         y = HF.conv2d(P_main, W_eff, bias_eff, self._eff_packed)
         o_tb = base(HF.strip_select(HF.conv3d_1to8(tb, W3, b3), B, r, 2))        # [2B, C, 2r, w]
-        o_lr = base(HF.strip_select(HF.conv3d_1to8(lr, W3, b3), B, r, 3))        # [2B, C, h, 2r]
-        return HF.pack_border_paste(y, o_tb, o_lr, r)
+        if lr_t:
+            # transposed space: strips [2B, C, S, h], Conv3d taps (dz, dx, dy), Conv2d taps (kx, ky); the result [2B, C, 2r, h] is pasted
+            # through a transposed view (autograd carries the weight gradients back through the two transpose views)
+            z = HF.conv3d_1to8(lr, W3.transpose(3, 4), b3)
+            o_lr = HF.conv2d(HF.strip_select(z, B, r, 2), W2.transpose(2, 3), b2, self._lr_packed)
+        else:
+            o_lr = base(HF.strip_select(HF.conv3d_1to8(lr, W3, b3), B, r, 3))    # [2B, C, h, 2r]
+        return HF.pack_border_paste(y, o_tb, o_lr, r, lr_t)
 
     def forward(self, x):
         P = HF.space_to_depth(x)

@@ -299,3 +299,31 @@ def test_block_sequencer_is_bit_identical_to_the_python_bodies():
             assert not bad and g0.keys() == g1.keys(), bad[:3]
     finally:
         _seq.set_enabled(True)
+
+
+@pytest.mark.parametrize('k', [3, 5])
+def test_collapsed_pack_transposed_column_strips(k):
+    """Round 6: the column strips of the collapsed PackLayerConv3d are stored transposed and convolved with (y, x)-swapped kernels
+    (layers01.py: lr_transposed).  Forward and every gradient against the un-transposed form of the SAME module (which the reference
+    goldens pin: test_pack_golden) on a map with distinct height and width."""
+    from packnet_sfm.networks.layers.packnet.layers01 import PackLayerConv3d
+    torch.manual_seed(11)
+    m = PackLayerConv3d(16, k).to(DEV)
+    m.collapse = True
+    x = torch.randn(2, 16, 28, 72, device=DEV, requires_grad=True)
+    res = {}
+    for form in (False, True):
+        m.lr_transposed = form
+        for p in m.parameters():
+            p.grad = None
+        x.grad = None
+        y = m(x)
+        (y * torch.linspace(0.5, 1.5, y.numel(), device=DEV).view_as(y)).sum().backward()
+        res[form] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    y0, dx0, g0 = res[False]
+    y1, dx1, g1 = res[True]
+    P.check(y1, y0, 1e-5, 'forward')
+    P.check(dx1, dx0, 5e-5, 'dx')
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        P.check(g1[n], g0[n], 1e-4, 'd' + n, floor=0.05 * gmax)

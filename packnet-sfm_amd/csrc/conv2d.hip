@@ -68,6 +68,7 @@ static const size_t kPipeThreeBlocks = 53 * 1024;  // variant 6 of the split-bf1
 static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int NT, int want_split, ConvGeom& g, int DMA = 0,
                             int S = 1, int forceMT = 0, int tm = 0) {
   g.DMA = DMA;
+  g.stem = 0;
   g.TW = g.TH = 0;
   if (tm != 0 && DMA < 3) return false;
   const int HW = H * W;
@@ -199,6 +200,11 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
   while (smem_for(g.CI) > kMaxSmem && g.CI > 8) g.CI /= 2;
   g.smem_bytes = smem_for(g.CI);
   g.nchunks = ceil_div(Cin, g.CI);
+  // the depth networks' stem (3 -> C, 5x5, stride 1) on 32-wide tiles: its own kernel under variant 0 (conv2d_stem5_kernel below)
+  if (DMA == 0 && Cin == 3 && ks == 5 && S == 1 && g.mode == 0) {
+    g.stem = 1;
+    g.smem_bytes = ((size_t)76 * BM + (size_t)3 * g.PH * g.PW) * sizeof(float);
+  }
   if (want_split < 1) want_split = 1;
   if (want_split > g.nchunks) want_split = g.nchunks;
   const int cps = ceil_div(g.nchunks, want_split);
@@ -674,6 +680,103 @@ __global__ void __launch_bounds__(256) conv2d_mfma_kernel(ConvArgs a) {
 }
 
 
+// ---- the stem: 3 input channels, 5x5, stride 1, 32-wide pixel tiles (round 6) ---------------------------------------------
+// conv2d_mfma_kernel stages >= 8 channels per chunk and meets a barrier per tap: on the 3 -> 64 stem at 192x640 that is 4 k-steps of
+// v_mfma_f32_32x32x2_f32 per tap for 1.5 k-steps of channels and 25 barriers for 200 MFMAs -- 145 us for 4.7 GFLOP (32 TFLOP/s), the
+// first kernel of every step.  Here K is the flat (tap, channel) index: 75 -> 38 k-steps; the tile's WHOLE weight matrix
+// (76 x 32 MT floats) and the 3-channel patch are staged once, and the k loop is 38 straight-line steps without a barrier: per k-step
+// MT + NT ds_read_b32 for MT NT MFMAs, the patch offsets of the two k of a step compile-time constants.  The sum runs over the same
+// non-zero terms in the same order as the generic kernel's (tap-major, channel inside): the same bits.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) conv2d_stem5_kernel(ConvArgs a) {
+  constexpr int KS = 5, CIN = 3, K = KS * KS * CIN, KSTEPS = (K + 1) / 2, BM = 32 * MT;
+  constexpr int PH = 4 * NT + KS - 1, PW = 32 + KS - 1, PS = PH * PW, PTOT = CIN * PS;
+  PNSFM_DYN_SMEM(float, smem);
+  float* const wl = smem;                        // [2 * KSTEPS][BM]: row k = tap * 3 + ci (row 75: zeros)
+  float* const patch = smem + 2 * KSTEPS * BM;   // [CIN][PH][PW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int b = blockIdx.x / a.tiles_per_img;
+  const int t = blockIdx.x - b * a.tiles_per_img;
+  const int co0 = blockIdx.y * BM;
+  const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+  const int y0 = ty * 4 * NT, x0 = tx * 32;
+  const int py0 = y0 - KS / 2, px0 = x0 - KS / 2;
+  int boff[NT], oy[NT], ox[NT];
+  bool pvalid[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int row = wave * NT + nt;
+    oy[nt] = y0 + row;
+    ox[nt] = x0 + l32;
+    pvalid[nt] = oy[nt] < H;
+    boff[nt] = row * PW + l32;
+  }
+
+  // ---- stage the patch (through registers: all loads in flight together) and the weight matrix
+  {
+    const float* xb = a.x + (size_t)b * CIN * HW;
+    constexpr int NP = (PTOT + 255) / 256;
+    float pv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int idx = i * 256 + tid;
+      const int ci = idx / PS, e = idx - ci * PS, r = e / PW, c = e - r * PW;
+      const int yy = py0 + r, xx = px0 + c;
+      const bool ok = idx < PTOT && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pv[i] = *(ok ? xb + ((size_t)ci * HW + yy * W + xx) : pnsfm_zero_page);
+    }
+    constexpr int NW = (2 * KSTEPS * (BM / 4) + 255) / 256;
+    float4 wv[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = i * 256 + tid;
+      const int k = idx / (BM / 4), c4 = idx - k * (BM / 4);
+      const int tap = k / CIN, ci = k - tap * CIN;
+      const bool ok = k < K;
+      wv[i] = *reinterpret_cast<const float4*>(ok ? a.wp + (((size_t)tap * a.KP + ci) * a.MP + co0 + c4 * 4) : pnsfm_zero_page);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (i * 256 + tid < PTOT) patch[i * 256 + tid] = pv[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+      if (i * 256 + tid < 2 * KSTEPS * (BM / 4)) *reinterpret_cast<float4*>(wl + (size_t)(i * 256 + tid) * 4) = wv[i];
+  }
+  __syncthreads();
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // ---- 38 k-steps; lane half h of step s holds k = 2 s + h -> (tap, ci) -> patch offset ci PS + ky PW + kx (k = 75: any, its weights are 0)
+  const float* const wb = wl + half * BM + l32;
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int k0 = 2 * s, k1 = 2 * s + 1 < K ? 2 * s + 1 : 0;
+    const int o0 = (k0 % CIN) * PS + ((k0 / CIN) / KS) * PW + (k0 / CIN) % KS;
+    const int o1 = (k1 % CIN) * PS + ((k1 / CIN) / KS) * PW + (k1 / CIN) % KS;
+    const float* pb = patch + (half ? o1 : o0);
+    float av[MT], bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[mt] = wb[s * 2 * BM + mt * 32];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = pb[boff[nt]];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = pnsfm_mfma_32x32x2(av[mt], bv[nt], acc[mt][nt]);
+  }
+
+  conv_epilogue<MT, NT, false>(a, acc, b, co0, half, oy, ox, pvalid, 0, nullptr, t, wave);
+}
+
 // ---- pipelined variant (DMA == 2) ------------------------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles, so ONE wave per SIMD saturates it as long as that
 // wave never waits: the kernel is organised so that nothing it waits for is on the critical path.
@@ -1062,6 +1165,12 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
     else { PNSFM_PIPE_ATTR(1, 1); PNSFM_LAUNCH((conv2d_pipe_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a); }
 #undef PNSFM_PIPE_ATTR
   } else if (g.DMA) PNSFM_CONV_DISPATCH(true);
+  else if (g.stem) {
+    if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv2d_stem5_kernel<2, 2>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv2d_stem5_kernel<2, 1>), grid, dim3(256), g.smem_bytes, stream, a);
+    else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv2d_stem5_kernel<1, 2>), grid, dim3(256), g.smem_bytes, stream, a);
+    else PNSFM_LAUNCH((conv2d_stem5_kernel<1, 1>), grid, dim3(256), g.smem_bytes, stream, a);
+  }
   else PNSFM_CONV_DISPATCH(false);
 #undef PNSFM_CONV_DISPATCH
   int rc = check_launch(what);

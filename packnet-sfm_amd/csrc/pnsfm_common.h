@@ -224,6 +224,7 @@ struct ConvGeom {
   int PH, PW;         // staged input patch (rows, cols) incl. halo
   int KP, MP;         // padded K-channels / M-channels of the packed weight
   int nchunks, splitK;
+  int stem;           // variant 0 only: 1 = the 3-channel 5x5 stem kernel (conv2d_stem5_kernel) takes the launch
   int DMA;            // 0: patch staged through registers; 1: patch double-buffered in LDS, fetched by LDS-DMA;
                       // 2: fully pipelined kernel -- patch AND per-kernel-row weight slabs double-buffered by LDS-DMA
                       // 3..5: split-bf16 kernels (fp32 rebuilt from 6 bf16 MFMA products; conv2d_bx3.h)

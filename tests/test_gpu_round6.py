@@ -327,3 +327,36 @@ def test_collapsed_pack_transposed_column_strips(k):
     gmax = max(float(v.abs().max()) for v in g0.values())
     for n in g0:
         P.check(g1[n], g0[n], 1e-4, 'd' + n, floor=0.05 * gmax)
+
+
+# ---- the 3-channel 5x5 stem kernel (conv2d.hip: conv2d_stem5_kernel; variant 0 of the f32 kernels on 32-multiple widths)
+@pytest.mark.parametrize('NT', [1, 2])
+@pytest.mark.parametrize('shape', [(4, 3, 64, 192, 640, 5), (2, 3, 32, 96, 320, 5), (1, 3, 40, 45, 96, 5), (3, 3, 64, 6, 32, 5)])
+def test_stem_kernel_vs_cpu_oracle_and_generic_kernel(shape, NT):
+    """The depth networks' first layer (PackNet01.py:42 `Conv2D(3, 64, 5, 1)`) on its own kernel: against the oracle's convolution at
+    2e-5 (full size, PackNetSlim01's 32 channels, 40 channels = a padded 32-row M tile with 45 rows = ragged tile rows, a map of a single
+    tile row) and BIT-identical to the generic f32 kernel (variant 1), whose non-zero terms it adds in the same order."""
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b, _ = _data(shape, 3)
+    yr = F.conv2d(x, w, b, padding=ks // 2)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    key = (ctypes.c_int * 7)(10, B, Cin, Cout, H, W, ks)
+    lib.pnsfm_set_autotune(0)
+    try:
+        wf, _wb = ops.conv2d_pack(wd)
+        assert lib.pnsfm_tune_set(key, _cfg(NT, 0), 1) == 0
+        y0 = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+        c = _last(lib)
+        MT = 2 if Cout > 32 else 1
+        assert c['variant'] == 0 and c['NT'] == NT and c['lds'] == 4 * (76 * 32 * MT + 3 * (4 * NT + 4) * 36), c      # the stem kernel's LDS image
+        assert lib.pnsfm_tune_set(key, _cfg(NT, 1), 1) == 0
+        y1 = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+        assert _last(lib)['variant'] == 1
+    finally:
+        lib.pnsfm_set_conv_variant(0)
+        lib.pnsfm_set_conv_variant(3)
+        lib.pnsfm_set_autotune(1)
+    P.check(y0, yr, 2e-5, 'stem fwd')
+    assert torch.equal(y0, y1)

@@ -151,13 +151,14 @@ def test_smoothness_norm_fused(emulated_kernels, scale):
 @pytest.mark.parametrize('direct_a', [6, 5, 4, 3, 2, 1, 0])
 @pytest.mark.parametrize('shape', [(1, 4, 8, 8, 32, 3), (2, 3, 5, 6, 20, 3), (1, 6, 4, 4, 32, 7), (2, 20, 70, 5, 7, 1),
                                    (1, 96, 64, 6, 20, 3), (1, 40, 33, 9, 32, 5), (1, 24, 40, 10, 32, 7), (2, 129, 16, 5, 24, 3),
-                                   (2, 32, 64, 4, 40, 1), (1, 48, 33, 12, 40, 1)])
+                                   (2, 32, 64, 4, 40, 1), (1, 48, 33, 12, 40, 1), (2, 3, 40, 9, 64, 5), (1, 3, 24, 6, 32, 5)])
 def test_conv2d_raw(emulated_kernels, shape, direct_a):
     """Raw C-ABI conv entry points vs torch: 2-D tiles, linear tiles, odd channels, split-K, every kernel size; every
     variant of the forward/backward-data kernel: f32 MFMA (0 patch through registers, 1 patch by LDS-DMA, 2 fully pipelined)
     and the split-bf16 arithmetic (3 one patch buffer, 4 two, 5 whole kernel rows per stage, 6 three workgroups per CU; shapes with < 16 K-channels or
     fall through to the f32 kernels there; 1x1 layers run the split kernels since round 3, on 32-wide rows of the flattened map
-    when H*W is a multiple of 32)."""
+    when H*W is a multiple of 32).  The last two shapes are the depth networks' stem (3 channels, 5x5, 32-multiple width): variant 0 runs
+    conv2d_stem5_kernel there (ragged tile rows, 40 / 24 output channels: padded M tiles)."""
     import torch.nn.functional as F
     from packnet_sfm.hip import _lib, ops
     _lib.get().pnsfm_set_conv_math(1 if direct_a >= 3 else 0)

@@ -123,6 +123,23 @@ static bool conv_geom_fixed(int B, int Cin, int Cout, int H, int W, int ks, int 
     g.KP = round_up(Cin, 16);
     g.nchunks = g.KP / 16;
     g.PB = (DMA == 3 || DMA == 6 || DMA == 7) ? 1 : 2;
+    if (DMA == 8) {
+      // 1x1 without LDS (conv2d_bx3_1x1.h): runs of 128 NT consecutive pixels of one image, no patch, no weight stages
+      if (ks != 1 || S != 1 || tm != 0) return false;
+      if ((size_t)g.KP * HW * 4 >= (1ull << 31)) return false;      // 32-bit buffer offsets inside an image
+      g.mode = 1;
+      g.tiles_x = 0;
+      g.tiles_per_img = ceil_div(HW, 128 * NT);
+      g.PH = g.PW = 0;
+      g.PB = 0;
+      g.G = 1;
+      g.smem_bytes = 0;
+      if (want_split < 1) want_split = 1;
+      if (want_split > g.nchunks) want_split = g.nchunks;
+      const int cps8 = ceil_div(g.nchunks, want_split);
+      g.splitK = ceil_div(g.nchunks, cps8);
+      return true;
+    }
     if (DMA == 6 && g.MT * NT > 2) return false;           // three workgroups per CU: <= 168 VGPRs only without the (2,2) tile
     const int KK = ks * ks;
     const size_t plane = (size_t)round_up(g.PH * g.PW * 32, 1024);
@@ -496,6 +513,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const float* __
 
 #include "conv2d_bx3.h"
 #include "conv2d_bx3pp.h"
+#include "conv2d_bx3_1x1.h"
 
 // DMA = 0: the halo patch of a channel chunk is staged through registers (8 loads in flight per thread) between two
 //          barriers;
@@ -1045,6 +1063,7 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
   a.x1 = ms ? ms->x1 : nullptr; a.x2 = ms ? ms->x2 : nullptr;
   a.C0 = ms ? ms->C0 : Cin; a.C01 = ms ? ms->C0 + ms->C1 : Cin;
   if (ms && g.DMA < 3) { set_error("%s: several input tensors need the split-bf16 kernels", what); return -1; }
+  if (ms && g.DMA == 8) { set_error("%s: the LDS-free 1x1 kernel reads one input tensor", what); return -1; }
   if (a.addend && g.DMA < 3) { set_error("%s: an addend needs the split-bf16 kernels (>= 16 channels of dy, 'bx3' arithmetic)", what); return -1; }
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.KS = ks;
   a.S = S; a.Hi = Hi; a.Wi = Wi;
@@ -1104,7 +1123,13 @@ static int enqueue_conv(const ConvGeom& g, const float* x, const float* wp, cons
 #else
 #define PNSFM_BX3_ATTR(MTv, NTv) do {} while (0)
 #endif
-    if (g.DMA == 7) {         // ping-pong workgroup: 512 threads, up to 160 KB of LDS, taps per stage a template parameter (conv2d_bx3pp.h)
+    if (g.DMA == 8) {         // 1x1 without LDS (conv2d_bx3_1x1.h)
+      if (g.MT == 2 && g.NT == 2) PNSFM_LAUNCH((conv1x1_bx3_kernel<2, 2>), grid1, dim3(256), 0, stream, a);
+      else if (g.MT == 2 && g.NT == 1) PNSFM_LAUNCH((conv1x1_bx3_kernel<2, 1>), grid1, dim3(256), 0, stream, a);
+      else if (g.MT == 1 && g.NT == 2) PNSFM_LAUNCH((conv1x1_bx3_kernel<1, 2>), grid1, dim3(256), 0, stream, a);
+      else PNSFM_LAUNCH((conv1x1_bx3_kernel<1, 1>), grid1, dim3(256), 0, stream, a);
+    }
+    else if (g.DMA == 7) {         // ping-pong workgroup: 512 threads, up to 160 KB of LDS, taps per stage a template parameter (conv2d_bx3pp.h)
 #ifndef PNSFM_EMU
 #define PNSFM_PP_ATTR(MTv, NTv, Gv)                                                                                \
       do {                                                                                                         \
@@ -1244,10 +1269,18 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
       // PNSFM_PP: which launches may take the ping-pong workgroup (variant 7): bit 0 forward, bit 1 backward-data (default 3: both)
       static const int pp_mask = [] { const char* e = getenv("PNSFM_PP"); return (e && e[0]) ? atoi(e) : 3; }();
       const bool pp_on = ((pp_mask >> (kind_tag & 1)) & 1) != 0;
-      const int nVar = bx3 ? (pp_on ? 5 : 4) : 3;         // LDS plans: f32 0..2, split-bf16 3..7 (6 = three workgroups per CU, 7 = ping-pong workgroup)
+      // LDS plans: f32 0..2, split-bf16 3..8 (6 = three workgroups per CU, 7 = ping-pong workgroup, 8 = 1x1 without LDS)
+      int vars[6], nVar = 0;
+      if (bx3) {
+        for (int v = 3; v <= 6; ++v) vars[nVar++] = v;
+        if (pp_on) vars[nVar++] = 7;
+        if (ks == 1 && S == 1 && !ms) vars[nVar++] = 8;
+      } else {
+        for (int v = 0; v <= 2; ++v) vars[nVar++] = v;
+      }
       for (int cfgt = 0; cfgt < 2 * nVar * nMT * nTM; ++cfgt) {
         const int cfg = cfgt % (2 * nVar * nMT), tm = cfgt / (2 * nVar * nMT);
-        const int NT = 2 - (cfg & 1), DA = (cfg >> 1) % nVar + (bx3 ? 3 : 0), fMT = cfg / (2 * nVar);
+        const int NT = 2 - (cfg & 1), DA = vars[(cfg >> 1) % nVar], fMT = cfg / (2 * nVar);
         int last_split = -1;
         for (int want : kSplits) {
           ConvGeom c;
@@ -1267,14 +1300,14 @@ static int launch_conv(const float* x, const float* wp, const float* bias, float
 #endif
     if (dec) {
       ConvGeom t;
-      const int DA = ((*dec)[0] >> 4) & 7;
+      const int DA = ((*dec)[0] >> 4) & 15;
       if ((DA >= 3) == bx3 &&
           conv_geom_fixed(B, Cin, Cout, H, W, ks, (*dec)[0] & 15, (*dec)[1], t, DA, S, ((*dec)[0] >> 8) & 1, ((*dec)[0] >> 9) & 3))
         g = t;
     }
   }
 #ifdef PNSFM_BX3_ABLATE
-  if (g.DMA >= 3 && g.smem_bytes + (size_t)g_smem_pad <= kMaxSmemPipe) g.smem_bytes += (size_t)g_smem_pad;
+  if (g.DMA >= 3 && g.DMA != 8 && g.smem_bytes + (size_t)g_smem_pad <= kMaxSmemPipe) g.smem_bytes += (size_t)g_smem_pad;
 #endif
   const double flops = 2.0 * Cout * (double)Cin * ks * ks * (double)B * H * W;   // useful flops (output pixels)
   const int meta[9] = {B, Cin, Cout, H, W, ks, g.splitK, (int)(B * g.tiles_per_img * (g.MP / (32 * g.MT)) * g.splitK), g.DMA};

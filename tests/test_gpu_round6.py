@@ -360,3 +360,64 @@ def test_stem_kernel_vs_cpu_oracle_and_generic_kernel(shape, NT):
         lib.pnsfm_set_autotune(1)
     P.check(y0, yr, 2e-5, 'stem fwd')
     assert torch.equal(y0, y1)
+
+
+# ---- the LDS-free 1x1 kernel (csrc/conv2d_bx3_1x1.h, tuner variant 8): the shortcuts of the residual blocks (layers01.py:57-60)
+def _flat32(H, W):
+    return ((H * W) // 32, 32) if (H * W) % 32 == 0 and W % 32 != 0 else (H, W)       # launch_conv's 32-wide rows of a 1x1 layer
+
+
+# (shape, (NT, narrow M), K split): the shipped database's decisions at BASELINE.json configs[1] / [2], then ragged pixel tiles and
+# K chunks, padded M tiles, K splits (with fewer chunks per split than the prefetch depth)
+C1_CASES = [
+    ((4, 256, 256, 24, 80, 1), (1, 0), 1), ((4, 512, 512, 12, 40, 1), (1, 1), 1), ((4, 64, 64, 96, 320, 1), (2, 0), 1),
+    ((4, 128, 256, 24, 80, 1), (1, 0), 1), ((2, 256, 256, 48, 160, 1), (2, 0), 1), ((2, 64, 64, 192, 640, 1), (2, 0), 1),
+    ((3, 48, 33, 13, 19, 1), (2, 0), 1), ((2, 144, 70, 9, 35, 1), (1, 1), 4), ((4, 512, 512, 12, 40, 1), (2, 0), 16),
+    ((1, 20, 40, 7, 5, 1), (1, 0), 1),
+]
+
+
+@pytest.mark.parametrize('case', C1_CASES, ids=lambda c: 'x'.join(map(str, c[0])) + '-s%d' % c[2])
+def test_conv1x1_kernel_vs_cpu_oracle_and_lds_kernel(case):
+    """Forward and backward-data (the latter also with an addend in the epilogue: the gradient taps of the residual blocks) of the
+    LDS-free 1x1 kernel against the oracle's convolution at 2e-5, BIT-identical to conv2d_bx3_kernel (variant 3) at the same K split
+    -- same six piece products per chunk in the same order -- and bit-identical over 20 repeated launches."""
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    lib = _lib.get()
+    shape, (NT, narrow), split = case
+    B, Cin, Cout, H, W, ks = shape
+    Hk, Wk = _flat32(H, W)
+    x, w, b, dy = _data(shape, 8)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b)
+    yr.backward(dy)
+    g = torch.Generator().manual_seed(5)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    xd, wd, bd, dyd, addd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV), add.to(DEV)
+    HF.set_conv_math('bx3')
+    lib.pnsfm_set_autotune(0)
+    out = {}
+    try:
+        wf, wb = ops.conv2d_pack(wd)
+        for variant in (8, 3):
+            _pin(lib, 0, B, Cin, Cout, Hk, Wk, ks, NT | (variant << 4) | (narrow << 8), split)
+            _pin(lib, 1, B, Cout, Cin, Hk, Wk, ks, NT | (variant << 4) | (narrow << 8), split)
+            y = ops.conv2d_forward(xd, wf, bd, Cout, ks)
+            c = _last(lib)
+            assert c['variant'] == variant and c['NT'] == NT, c
+            dx = ops.conv2d_backward_data(dyd, wb, Cin, ks)
+            assert _last(lib)['variant'] == variant
+            dxa = ops.conv2d_backward_data(dyd, wb, Cin, ks, addend=addd)
+            out[variant] = (y, dx, dxa)
+            if variant == 8:
+                for _ in range(20):
+                    assert torch.equal(ops.conv2d_forward(xd, wf, bd, Cout, ks), y)
+    finally:
+        lib.pnsfm_set_conv_variant(3)
+        lib.pnsfm_set_autotune(1)
+    y, dx, dxa = out[8]
+    P.check(y, yr, 2e-5, '1x1 fwd')
+    P.check(dx, xr.grad, 2e-5, '1x1 dgrad')
+    P.check(dxa, xr.grad + add, 2e-5, '1x1 dgrad + addend')
+    for got, ref, what in zip(out[8], out[3], ('fwd', 'dgrad', 'dgrad + addend')):
+        assert torch.equal(got, ref), what

@@ -255,6 +255,48 @@ def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):
     lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
+def _flat32(H, W):
+    """launch_conv tiles a 1x1 layer whose H*W is a multiple of 32 (and W is not) as 32-wide rows: the tuning key carries those."""
+    return ((H * W) // 32, 32) if (H * W) % 32 == 0 and W % 32 != 0 else (H, W)
+
+
+@pytest.mark.parametrize('shape,cfg', [((2, 32, 64, 4, 40, 1), (1, 0, 1)), ((2, 32, 64, 4, 40, 1), (2, 0, 1)), ((1, 48, 33, 12, 40, 1), (1, 0, 1)),
+                                       ((1, 48, 33, 12, 40, 1), (2, 1, 1)), ((2, 20, 70, 5, 7, 1), (1, 0, 1)), ((2, 20, 70, 5, 7, 1), (2, 1, 1)),
+                                       ((1, 256, 64, 6, 20, 1), (1, 0, 3)), ((1, 256, 64, 6, 20, 1), (2, 0, 16)), ((3, 80, 96, 9, 32, 1), (2, 0, 2)),
+                                       ((1, 144, 40, 17, 19, 1), (1, 1, 4)), ((1, 64, 64, 8, 64, 1), (2, 0, 1))])
+def test_conv1x1_lds_free_kernel(emulated_kernels, shape, cfg):
+    """The LDS-free 1x1 kernel (csrc/conv2d_bx3_1x1.h, tuner variant 8) vs torch, forward and backward-data, pinned as the autotuner
+    would: cfg = (NT, narrow-M, K split).  Ragged last pixel tiles (160 / 35 / 323 pixels per image), a ragged last K chunk (20, 48,
+    144 = 9 chunks over 4 splits: 3 + 3 + 3), padded M tiles (33, 70, 40 channels), every wave tile and prefetch depth (D = 2, 3, 4),
+    K splits with fewer chunks than the prefetch depth, several images."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    NT, narrow, split = cfg
+    lib.pnsfm_set_conv_math(1)
+    B, Cin, Cout, H, W, ks = shape
+    Hk, Wk = _flat32(H, W)
+    for kind, K, M in ((0, Cin, Cout), (1, Cout, Cin)):
+        key = (ctypes.c_int * 7)(kind + 10 + 100, B, K, M, Hk, Wk, ks)
+        assert lib.pnsfm_tune_set(key, NT | (8 << 4) | (narrow << 8), split) == 0
+    g = torch.Generator().manual_seed(sum(shape) + NT)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wf, wb = ops.conv2d_pack(w)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    out = (ctypes.c_int * 8)()
+    P.check(ops.conv2d_forward(x, wf, b, Cout, ks), yr, 1e-5, 'fwd (1x1, no LDS)')
+    assert lib.pnsfm_conv2d_last_config(out) == 0 and out[0] == 8 and out[1] == NT, list(out)
+    P.check(ops.conv2d_backward_data(dy, wb, Cin, ks), xr.grad, 1e-5, 'dgrad (1x1, no LDS)')
+    assert lib.pnsfm_conv2d_last_config(out) == 0 and out[0] == 8, list(out)
+    lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
+
+
 @pytest.mark.parametrize('shape', [(1, 64, 64, 4, 32, 3), (2, 33, 70, 5, 16, 3), (1, 130, 20, 9, 8, 3), (2, 16, 96, 3, 64, 1),
                                    (1, 40, 64, 6, 24, 5), (3, 17, 31, 7, 40, 1), (2, 64, 64, 8, 32, 3)])
 def test_conv2d_wgrad_tap_major(emulated_kernels, shape):

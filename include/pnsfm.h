@@ -138,11 +138,12 @@ int pnsfm_set_wgrad_variant(int tap_major);
  * kind = 0 forward / 1 backward-data / 2 backward-weight, + 10 * stride; for kind 2 the key holds H*W in place of H and the
  * tiling width in place of W (32 for a 1x1 convolution).  forward / backward-data (+ 100 on `kind` for the split-bf16 arithmetic): v0 = NT | variant << 4 | narrow-M << 8,
  * v1 = K-split; backward-weight: v0 = pixel split, v1 = kernel (0 generic, 1 tap-major, 2 | NT << 4 | WM << 6 split-bf16 one
- * kernel row per workgroup, 3 | (WCI | TG << 4 | TR << 8) << 4 split-bf16 nine taps per workgroup).  Used by the determinism sweep
+ * kernel row per workgroup, 3 | (WCI | TG << 4 | TR << 8) << 4 split-bf16 nine taps per workgroup).  Forward / backward-data variants:
+ * 0..2 f32 stagings, 3..6 split-bf16 LDS plans, 7 ping-pong workgroup, 8 the 1x1 kernel without LDS.  Used by the determinism sweep
  * (tools/conv_config_sweep.py), which checks EVERY configuration the autotuner may pick against the oracle's convolution. */
 int pnsfm_tune_set(const int* key7, int v0, int v1);
 /* What the calling thread's most recent forward / backward-data launch actually ran: out8 = {variant (0..2 f32 stagings, 3..6
- * split-bf16 LDS plans, 7 ping-pong workgroup), pixel tiles per wave NT, M tiles per wave MT, taps per weight stage G, K-split,
+ * split-bf16 LDS plans, 7 ping-pong workgroup, 8 the 1x1 kernel without LDS), pixel tiles per wave NT, M tiles per wave MT, taps per weight stage G, K-split,
  * tile mode (0 classic, 1 16-wide rectangles, 2 row bands), workgroups, LDS bytes}.  A pinned configuration that does not fit
  * a shape silently falls back to the heuristic one; tests that pin a variant assert on this.  Returns 1 when no launch happened yet. */
 int pnsfm_conv2d_last_config(int* out8);

@@ -64,7 +64,10 @@ if layer_csv:
         a[1] += 1
         # round 6: the table says which kernel ran the launch (`kernel` column) -- the algorithmic bytes of the ping-pong kernel and of the
         # nine-taps weight gradient are recorded under their own names as well (the family averages above stay for bench.py)
-        own = {('0', '7'): 'pnsfm::conv2d_bx3pp_kernel', ('1', '4'): 'pnsfm::conv2d_wgrad4_kernel', ('1', '2'): 'pnsfm::conv2d_wgrad2_kernel'}.get((r['kind'], r.get('kernel', '')))
+        own = {('0', '7'): 'pnsfm::conv2d_bx3pp_kernel', ('0', '8'): 'pnsfm::conv1x1_bx3_kernel', ('1', '4'): 'pnsfm::conv2d_wgrad4_kernel',
+               ('1', '2'): 'pnsfm::conv2d_wgrad2_kernel'}.get((r['kind'], r.get('kernel', '')))
+        if r['kind'] == '0' and Cin == 3 and ks == 5 and r.get('kernel') == '0':
+            own = 'pnsfm::conv2d_stem5_kernel'
         if own is not None:
             a = acc.setdefault(own, [0.0, 0])
             a[0] += by

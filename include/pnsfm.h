@@ -145,7 +145,8 @@ int pnsfm_tune_set(const int* key7, int v0, int v1);
 /* What the calling thread's most recent forward / backward-data launch actually ran: out8 = {variant (0..2 f32 stagings, 3..6
  * split-bf16 LDS plans, 7 ping-pong workgroup, 8 the 1x1 kernel without LDS), pixel tiles per wave NT, M tiles per wave MT, taps per weight stage G, K-split,
  * tile mode (0 classic, 1 16-wide rectangles, 2 row bands), workgroups, LDS bytes}.  A pinned configuration that does not fit
- * a shape silently falls back to the heuristic one; tests that pin a variant assert on this.  Returns 1 when no launch happened yet. */
+ * a shape silently falls back to the heuristic one; tests that pin a variant assert on this.  A backward-weight call that ran the
+ * stem's kernel (3 input channels, 5x5) leaves {105, 0, MT, 0, pixel splits, 0, workgroups, 0}.  Returns 1 when no launch happened yet. */
 int pnsfm_conv2d_last_config(int* out8);
 /* Tuning database: environment PNSFM_TUNE_DB=<file> loads earlier autotune decisions when the library first tunes and
  * appends new ones (text, one line per layer shape) -- what MIOpen's user find-db does for the reference's cuDNN/MIOpen

@@ -1418,6 +1418,217 @@ int launch_sum_slabs(const float* ws, size_t zstride, int Z, float* out0, size_t
   return check_launch("conv2d_backward_weight (slab sum)");
 }
 
+// ---- weight gradient of the stem (3 input channels, 5x5, stride 1; round 6) ------------------------------------------------------------
+// conv2d_wgrad_kernel walks the pixels two at a time on v_mfma_f32_32x32x2_f32 with a 4 x 32-column N tile of which 75 columns exist:
+// 111 us for the 3 -> 64 stem at 4 x 192x640 (43 TFLOP/s) -- the LAST kernel of every backward pass, nothing left to hide it under.
+// Here the same GEMM (M = co, N = (ci, ky, kx) = 75 -> 96 columns, K = pixels) runs on the split-bf16 arithmetic (exact 3-way bf16
+// split, six piece products, fp32 accumulate: conv2d_bx3.h), 16 pixels per k-step:
+//   * pixel tile = 4 rows x 64 columns = 16 k-steps; the 3-channel patch (8 x 68 floats per channel) is staged fp32 in LDS once per
+//     tile, prefetched in registers under the previous tile's MFMAs;
+//   * A (dY): lane (co = l & 31, half = l >> 5) loads 8 consecutive pixels of its channel row straight from global memory -- every
+//     dY element is read exactly once by the launch -- one tile ahead, k-step by k-step;
+//   * B (X): lane (n = l & 31 -> (ci, ky, kx), half) reads its 8 pixels at the tap's shift from the LDS patch (8 ds_read_b32:
+//     the shift kx breaks every alignment) and splits them;
+//   * the 4 waves are MT co tiles x 4 / MT pixel parts (rows of the tile); every wave holds its co tile x all 96 columns (48
+//     accumulator registers); the parts meet in LDS at the end in a fixed order;
+//   * pixel tiles are split over blockIdx.y; a split launch writes [dW | dbias] slabs for sum_slabs_kernel (no atomics).
+// Needs W % 8 == 0 (a lane's 8 pixels never straddle the image edge).  Roofline: the 126 MB of dY (27 us); MFMA-bound 15 us.
+struct StemWgradArgs {
+  const float* x;    // [B][3][H][W]
+  const float* dy;   // [B][Cout][H][W]
+  float* dw;         // [Cout][75] (one split) or the first slab of the workspace
+  float* dbias;      // [Cout] / the slab's bias part / null
+  size_t zstride;    // floats between the slabs of two splits (0: one split)
+  int B, Cout, H, W;
+  int tiles_x, tiles_per_img, total_tiles, tiles_per_split;
+};
+
+template <int MT>
+__global__ void __launch_bounds__(256) conv2d_wgrad_stem5_kernel(StemWgradArgs a) {
+  constexpr int KS = 5, CIN = 3, NCOL = CIN * KS * KS;       // 75 columns
+  constexpr int TR = 4, TC = 64, PH = TR + KS - 1, PWs = TC + KS - 1, RS = 72, PS = PH * RS;      // patch rows of 68 (+4 pad) floats
+  constexpr int NPH = 4 / MT, RPP = TR / NPH, KPP = RPP * (TC / 16);      // pixel parts, rows per part, k-steps per part and tile
+  constexpr int NPV = (CIN * PH * PWs + 255) / 256;
+  __shared__ float patch[CIN * PS];
+  __shared__ float meet[(4 - MT) * 49 * 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = PNSFM_UNIFORM(tid >> 6), half = lane >> 5, l32 = lane & 31;
+  const int mt = wave % MT, ph = wave / MT;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int co = blockIdx.x * 32 * MT + 32 * mt + l32;
+  const int bz = blockIdx.y;
+  const int t_begin = bz * a.tiles_per_split;
+  int t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.total_tiles) t_end = a.total_tiles;
+
+  const pnsfm_buf dybuf = pnsfm_make_buf(a.dy, (unsigned)((size_t)a.B * a.Cout * HW * 4));
+  const pnsfm_buf xbuf = pnsfm_make_buf(a.x, (unsigned)((size_t)a.B * CIN * HW * 4));
+
+  // column n = 32 nt + l32 -> (ci, ky, kx) -> offset inside the patch (columns >= 75 are never stored: any in-range address)
+  int nbase[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const int n = 32 * nt + l32;
+    const int ci = n / (KS * KS), tap = n - ci * KS * KS, ky = tap / KS, kx = tap - ky * KS;
+    nbase[nt] = n < NCOL ? ci * PS + ky * RS + kx + 8 * half : 8 * half;
+  }
+  // patch items of this thread: (channel, row, column) of the 3 x 8 x 68 halo patch
+  int pv_lds[NPV], pv_r[NPV], pv_c[NPV], pv_ci[NPV];
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    int e = i * 256 + tid;
+    const bool live = e < CIN * PH * PWs;
+    if (!live) e = 0;
+    const int ci = e / (PH * PWs), rem = e - ci * (PH * PWs), r = rem / PWs, c = rem - r * PWs;
+    pv_lds[i] = live ? ci * PS + r * RS + c : -1;
+    pv_r[i] = r - KS / 2; pv_c[i] = c - KS / 2; pv_ci[i] = ci;
+  }
+  struct Cur { int b, y0, x0; };
+  auto tile_of = [&](int t) {
+    Cur c;
+    c.b = t / a.tiles_per_img;
+    const int tt = t - c.b * a.tiles_per_img, ty = tt / a.tiles_x;
+    c.y0 = ty * TR; c.x0 = (tt - ty * a.tiles_x) * TC;
+    return c;
+  };
+  float pv[NPV];
+  auto load_patch = [&](const Cur& c) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int yy = c.y0 + pv_r[i], xx = c.x0 + pv_c[i];
+      const bool ok = pv_lds[i] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      pv[i] = pnsfm_buf_load(xbuf, ok ? (unsigned)((((c.b * CIN + pv_ci[i]) * H + yy) * W + xx) * 4) : PNSFM_DMA_INVALID, 0);
+    }
+  };
+  // dY fragment of k-step j of this wave's part: tile row ph * RPP + j / 4, columns 16 (j % 4) + 8 half .. + 7
+  float araw[KPP][8];
+  auto load_a = [&](float (&v)[8], const Cur& c, int j) {
+    const int yy = c.y0 + ph * RPP + j / 4, xx = c.x0 + 16 * (j % 4) + 8 * half;
+    const bool ok = co < a.Cout && yy < H && xx < W;
+    const unsigned off = ok ? (unsigned)((((c.b * a.Cout + co) * H + yy) * W + xx) * 4) : PNSFM_DMA_INVALID;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pnsfm_buf_load(dybuf, off + 4u * u, 0);
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  float bsum = 0.f;
+
+  if (t_begin < t_end) {
+    const Cur c0 = tile_of(t_begin);
+    load_patch(c0);
+#pragma unroll
+    for (int j = 0; j < KPP; ++j) load_a(araw[j], c0, j);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();           // every wave is done with the previous tile's patch
+#pragma unroll
+    for (int i = 0; i < NPV; ++i)
+      if (pv_lds[i] >= 0) patch[pv_lds[i]] = pv[i];
+    __syncthreads();
+    const bool more = t + 1 < t_end;
+    Cur cn = tile_of(more ? t + 1 : t);
+    if (more) load_patch(cn);
+#pragma unroll
+    for (int j = 0; j < KPP; ++j) {
+      pnsfm_u32x4 Ap[3];
+      bx3_split8(araw[j], Ap[0], Ap[1], Ap[2]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bsum += araw[j][u];
+      if (more) load_a(araw[j], cn, j);
+      const int poff = (ph * RPP + j / 4) * RS + 16 * (j % 4);
+      pnsfm_u32x4 Bp[3][3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = patch[nbase[nt] + poff + u];
+        bx3_split8(bv, Bp[nt][0], Bp[nt][1], Bp[nt][2]);
+      }
+      // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)   [dY piece, X piece]
+#define PNSFM_SW_P(sa_, sb_) _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) acc[nt] = pnsfm_mfma_bf16(Ap[sa_], Bp[nt][sb_], acc[nt])
+      PNSFM_SW_P(2, 0); PNSFM_SW_P(0, 2); PNSFM_SW_P(1, 1); PNSFM_SW_P(1, 0); PNSFM_SW_P(0, 1); PNSFM_SW_P(0, 0);
+#undef PNSFM_SW_P
+    }
+  }
+
+  // ---- the pixel parts of a co tile meet: parts 1 .. NPH-1 park their sums in LDS, part 0 adds them in part order
+  __syncthreads();
+  if (ph > 0) {
+    float* m = meet + (size_t)((ph - 1) * MT + mt) * 49 * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m[(nt * 16 + r) * 64] = acc[nt][r];
+    m[48 * 64] = bsum;
+  }
+  __syncthreads();
+  if (ph > 0) return;
+#pragma unroll
+  for (int p = 1; p < NPH; ++p) {
+    const float* m = meet + (size_t)((p - 1) * MT + mt) * 49 * 64 + lane;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] += m[(nt * 16 + r) * 64];
+    bsum += m[48 * 64];
+  }
+  // D row = (r & 3) + 8 (r >> 2) + 4 half -> co of this wave's tile, column = l32 -> n: consecutive lanes write consecutive n
+  float* const dwp = a.dw + (size_t)bz * a.zstride;
+  const int cow = blockIdx.x * 32 * MT + 32 * mt;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const int n = 32 * nt + l32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = cow + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < NCOL && c < a.Cout) dwp[(size_t)c * NCOL + n] = acc[nt][r];
+    }
+  }
+  if (a.dbias != nullptr) {
+    const float v = bsum + __shfl_xor(bsum, 32);      // the two 8-pixel halves of a channel row
+    if (half == 0 && co < a.Cout) (a.dbias + (size_t)bz * a.zstride)[co] = v;
+  }
+}
+
+static bool wgrad_stem5_supported(int B, int Cin, int Cout, int H, int W, int ks, int S) {
+  return S == 1 && Cin == 3 && ks == 5 && W % 8 == 0 && conv_math() == 1 && (size_t)B * Cout * H * W * 4 < (1ull << 31);
+}
+static int wgrad_stem5_total_tiles(int B, int H, int W) { return B * ceil_div(H, 4) * ceil_div(W, 64); }
+static int enqueue_wgrad_stem5(const float* x, const float* dy, float* dw, float* dbias, int B, int Cout, int H, int W, int split,
+                               hipStream_t s) {
+  StemWgradArgs a;
+  a.x = x; a.dy = dy; a.B = B; a.Cout = Cout; a.H = H; a.W = W;
+  a.tiles_x = ceil_div(W, 64);
+  a.tiles_per_img = a.tiles_x * ceil_div(H, 4);
+  a.total_tiles = B * a.tiles_per_img;
+  if (split < 1) split = 1;
+  if (split > a.total_tiles) split = a.total_tiles;
+  a.tiles_per_split = ceil_div(a.total_tiles, split);
+  const int splitP = ceil_div(a.total_tiles, a.tiles_per_split);
+  const size_t slab = (size_t)Cout * 75 + Cout;
+  ScratchLease lease(s, splitP > 1 ? (size_t)splitP * slab * sizeof(float) : 0);
+  a.dw = dw; a.dbias = dbias; a.zstride = 0;
+  if (splitP > 1) {
+    if (!lease.p) return -1;
+    a.dw = lease.as<float>();
+    a.dbias = dbias ? a.dw + (size_t)Cout * 75 : nullptr;
+    a.zstride = slab;
+  }
+  const int MT = Cout > 32 ? 2 : 1;
+  dim3 grid(ceil_div(Cout, 32 * MT), splitP);
+  g_last_conv = {105, 0, MT, 0, splitP, 0, (int)(grid.x * grid.y), 0};      // pnsfm_conv2d_last_config: 105 = the stem's weight gradient
+  if (MT == 2) PNSFM_LAUNCH((conv2d_wgrad_stem5_kernel<2>), grid, dim3(256), 0, s, a);
+  else PNSFM_LAUNCH((conv2d_wgrad_stem5_kernel<1>), grid, dim3(256), 0, s, a);
+  int rc = check_launch("conv2d_backward_weight (stem)");
+  if (!rc && splitP > 1) rc = launch_sum_slabs(a.dw, slab, splitP, dw, (size_t)Cout * 75, dbias, (size_t)Cout, s);
+  return rc;
+}
+
 // ---- backward-weight -------------------------------------------------------------------------------
 // dW[co][n] with n = ci*KK + tap (the reference's [Cout][Cin][k][k] layout, contiguous in n):
 //   dW[co][n] = sum_{b, pixel} dY[co][pixel] * X[ci(n)][pixel + off(tap(n))]
@@ -1874,8 +2085,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
   // kWgradScratchBudget (the split-bf16 kernels, the default arithmetic, keep far smaller partial tensors and are not affected).
   const size_t kWgradScratchBudget = (size_t)128 << 20;
   const int max_split_f32 = (int)std::max<size_t>(1, kWgradScratchBudget / (((size_t)Cout * N + Cout) * sizeof(float)));
+  const bool stem_wg = !ms && wgrad_stem5_supported(B, Cin, Cout, H0, W0, ks, S);      // the 3-channel 5x5 stem: its own kernel
   auto enqueue = [&](int split) -> int {
     if (split > max_split_f32) split = max_split_f32;
+    if (stem_wg) return enqueue_wgrad_stem5(x, dy, dw, dbias, B, Cout, H0, W0, split, s);
     WgradArgs c = a;
     c.tiles_per_split = ceil_div(a.total_tiles, split);
     c.splitP = ceil_div(a.total_tiles, c.tiles_per_split);

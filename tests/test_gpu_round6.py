@@ -421,3 +421,35 @@ def test_conv1x1_kernel_vs_cpu_oracle_and_lds_kernel(case):
     P.check(dxa, xr.grad + add, 2e-5, '1x1 dgrad + addend')
     for got, ref, what in zip(out[8], out[3], ('fwd', 'dgrad', 'dgrad + addend')):
         assert torch.equal(got, ref), what
+
+
+@pytest.mark.parametrize('shape,split', [((4, 3, 64, 192, 640, 5), 256), ((2, 3, 32, 96, 320, 5), 512), ((1, 3, 40, 45, 72, 5), 7), ((3, 3, 64, 8, 64, 5), 1)])
+def test_stem_weight_gradient_kernel_gpu(shape, split):
+    """The stem's weight gradient on conv2d_wgrad_stem5_kernel (split-bf16 arithmetic, 16 pixels per k-step): against the oracle at 5e-5,
+    against fp64 with the error bound of the other split-bf16 weight gradients (<= 16 * 2^-24 of sum |dy||x|), the same bits from
+    repeated launches; pnsfm_conv2d_last_config proves the kernel ran.  Reference: the autograd weight gradient of PackNet01.py:42."""
+    from packnet_sfm.hip import _lib, ops, functional as HF
+    lib = _lib.get()
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b, dy = _data(shape, 4)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv2d(x, wr, br, padding=ks // 2).backward(dy)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    ref64 = torch.nn.grad.conv2d_weight(xd.double(), (Cout, Cin, ks, ks), dyd.double(), padding=ks // 2)
+    mag = torch.nn.grad.conv2d_weight(xd.double().abs(), (Cout, Cin, ks, ks), dyd.double().abs(), padding=ks // 2)
+    HF.set_conv_math('bx3')
+    lib.pnsfm_set_autotune(0)
+    try:
+        key = (ctypes.c_int * 7)(12, B, Cin, Cout, H * W, W, ks)
+        assert lib.pnsfm_tune_set(key, split, 0) == 0
+        dw, db = ops.conv2d_backward_weight(xd, dyd, ks)
+        assert _last(lib)['variant'] == 105
+        for _ in range(10):
+            dw2, db2 = ops.conv2d_backward_weight(xd, dyd, ks)
+            assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    finally:
+        lib.pnsfm_set_wgrad_variant(-1)
+        lib.pnsfm_set_autotune(1)
+    P.check(dw, wr.grad, 5e-5, 'stem wgrad')
+    P.check(db, br.grad, 5e-5, 'stem dbias')
+    assert float(((dw.double() - ref64).abs() / mag).max()) <= 16 * 2.0 ** -24

@@ -255,6 +255,42 @@ def test_conv2d_rect_and_band_tiles(emulated_kernels, shape, cfg):
     lib.pnsfm_set_conv_variant(0)      # clears the pinned entries
 
 
+@pytest.mark.parametrize('shape,split', [((1, 3, 64, 8, 64, 5), 1), ((2, 3, 64, 6, 40, 5), 3), ((1, 3, 40, 9, 136, 5), 4), ((3, 3, 24, 4, 8, 5), 2),
+                                         ((2, 3, 32, 12, 64, 5), 100), ((1, 3, 70, 5, 72, 5), 2)])
+def test_conv2d_wgrad_stem_kernel(emulated_kernels, shape, split):
+    """The stem's weight gradient on its own split-bf16 kernel (conv2d.hip: conv2d_wgrad_stem5_kernel -- 3 input channels, 5x5) vs torch,
+    the pixel split pinned through pnsfm_tune_set: direct stores (one split) and slabs, ragged tiles in both directions (6 / 9 / 5 rows
+    of 4-row tiles, 40 / 136 / 8 / 72 columns of 64-column tiles), both wave layouts (<= 32 channels: four pixel parts; more: two co
+    tiles x two parts), padded co tiles (40, 24, 70 channels), more splits than tiles, several images."""
+    import ctypes
+    import torch.nn.functional as F
+    from packnet_sfm.hip import _lib, ops
+    lib = _lib.get()
+    lib.pnsfm_set_conv_math(1)
+    B, Cin, Cout, H, W, ks = shape
+    key = (ctypes.c_int * 7)(2 + 10, B, Cin, Cout, H * W, W, ks)
+    assert lib.pnsfm_tune_set(key, split, 0) == 0
+    g = torch.Generator().manual_seed(sum(shape) + split)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, br, padding=ks // 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    dw, db = ops.conv2d_backward_weight(x, dy, ks)
+    out = (ctypes.c_int * 8)()
+    tiles = B * -(-H // 4) * -(-W // 64)
+    assert lib.pnsfm_conv2d_last_config(out) == 0 and out[0] == 105 and out[4] == -(-tiles // -(-tiles // min(split, tiles))), list(out)
+    P.check(dw, wr.grad, 1e-5, 'wgrad (stem)')
+    P.check(db, br.grad, 1e-5, 'dbias (stem)')
+    lib.pnsfm_set_conv_math(0)           # the generic f32 kernel on the same data: the two agree to fp32 round-off
+    dw0, db0 = ops.conv2d_backward_weight(x, dy, ks)
+    lib.pnsfm_set_conv_math(1)
+    P.check(dw, dw0, 1e-5, 'wgrad (stem) vs generic')
+    lib.pnsfm_set_wgrad_variant(-1)      # clears the pinned entry
+
+
 def _flat32(H, W):
     """launch_conv tiles a 1x1 layer whose H*W is a multiple of 32 (and W is not) as 32-wide rows: the tuning key carries those."""
     return ((H * W) // 32, 32) if (H * W) % 32 == 0 and W % 32 != 0 else (H, W)

@@ -66,8 +66,8 @@ if layer_csv:
         # nine-taps weight gradient are recorded under their own names as well (the family averages above stay for bench.py)
         own = {('0', '7'): 'pnsfm::conv2d_bx3pp_kernel', ('0', '8'): 'pnsfm::conv1x1_bx3_kernel', ('1', '4'): 'pnsfm::conv2d_wgrad4_kernel',
                ('1', '2'): 'pnsfm::conv2d_wgrad2_kernel'}.get((r['kind'], r.get('kernel', '')))
-        if r['kind'] == '0' and Cin == 3 and ks == 5 and r.get('kernel') == '0':
-            own = 'pnsfm::conv2d_stem5_kernel'
+        if Cin == 3 and ks == 5 and r.get('kernel') == '0':      # the stem's own kernels run under the generic kernel ids
+            own = 'pnsfm::conv2d_stem5_kernel' if r['kind'] == '0' else 'pnsfm::conv2d_wgrad_stem5_kernel'
         if own is not None:
             a = acc.setdefault(own, [0.0, 0])
             a[0] += by
